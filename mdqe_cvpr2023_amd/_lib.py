@@ -1,0 +1,71 @@
+"""ctypes binding of libmdqe_hip.so (C ABI: include/mdqe_hip.h).  Fails loudly when absent."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmdqe_hip.so")
+
+i, f, p = c_int, c_float, c_void_p
+
+# name -> argtypes; every function returns int status (include/mdqe_hip.h)
+SIGNATURES = {
+    "mdqe_msda_forward_f32": [p, p, p, p, p, i, i, i, i, i, i, i, p, p],
+    "mdqe_msda_forward_grouped_f32": [p, p, p, p, p, i, i, i, i, i, i, i, i, f, p, p],
+}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class MdqeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise LibraryMissing(
+            f"{path} not found: build it with `make -C mdqe_cvpr2023_amd/csrc` (or "
+            f"`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU/PyTorch fallback.")
+    h = ctypes.CDLL(path)
+    h.mdqe_version.restype = c_int
+    h.mdqe_strerror.restype = c_char_p
+    h.mdqe_strerror.argtypes = [c_int]
+    for name, args in SIGNATURES.items():
+        fn = getattr(h, name)          # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = args
+        fn.restype = c_int
+    if path == LIB_PATH:
+        _lib = h
+    return h
+
+
+class _Lazy:
+    def __getattr__(self, name):
+        return getattr(load_library(), name)
+
+
+lib = _Lazy()
+
+
+def check(code, what=""):
+    if code != 0:
+        raise MdqeError(f"{what}: {load_library().mdqe_strerror(code).decode()} (code {code})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def cur_stream(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

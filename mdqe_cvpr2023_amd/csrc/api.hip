@@ -1,0 +1,11 @@
+#include "common.h"
+extern "C" int mdqe_version(void) { return 100; }
+extern "C" const char* mdqe_strerror(int code) {
+  switch (code) {
+    case MDQE_OK: return "ok";
+    case MDQE_EINVAL: return "invalid size or unsupported shape";
+    case MDQE_ELAUNCH: return "kernel launch failed";
+    case MDQE_ENULL: return "null pointer argument";
+    default: return "unknown error";
+  }
+}

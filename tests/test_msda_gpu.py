@@ -1,0 +1,89 @@
+"""GPU parity: HIP MSDA (through the C ABI) vs the oracle and the reference-generated goldens."""
+import pytest
+import torch
+
+import mdqe_oracle as O
+from _golden import Fixture, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def run_hip(value, shapes, starts, loc, attn):
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    sh = torch.as_tensor(shapes, dtype=torch.int64).cuda()
+    st = torch.as_tensor(starts, dtype=torch.int64).cuda()
+    return MSDA.ms_deform_attn_forward(dev(value), sh, st, dev(loc), dev(attn), 64).cpu()
+
+
+def test_reference_known_answer_float():
+    """mdqe/models/ops/test.py:46-60 asks rtol 1e-2 / atol 1e-3; we hold 1e-6."""
+    fx = Fixture("msda_reftest")
+    out = run_hip(fx.t("float_value"), fx.shapes(), fx.t("level_start").tolist(), fx.t("float_loc"), fx.t("float_attn"))
+    ref = fx.t("float_out")
+    assert torch.allclose(out, ref, rtol=1e-2, atol=1e-3)
+    assert maxdiff(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["enc", "dec_spatial", "dec_temporal", "swin_d24", "tiny_d8"])
+def test_golden_cases(case):
+    fx = Fixture("msda_cases")
+    out = run_hip(fx.t(f"{case}::value"), fx.shapes(f"{case}::shapes"), fx.t(f"{case}::level_start").tolist(),
+                  fx.t(f"{case}::loc"), fx.t(f"{case}::attn"))
+    assert maxdiff(out, fx.t(f"{case}::out")) < 2e-5     # O(1) values, fp32
+
+
+def test_edge_cases():
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    sh = torch.tensor([[4, 6]], dtype=torch.int64).cuda()
+    st = torch.tensor([0], dtype=torch.int64).cuda()
+    # empty query set
+    out = MSDA.ms_deform_attn_forward(torch.zeros(1, 24, 2, 4).cuda(), sh, st, torch.zeros(1, 0, 2, 1, 1, 2).cuda(),
+                                      torch.zeros(1, 0, 2, 1, 1).cuda(), 64)
+    assert out.shape == (1, 0, 8)
+    # all samples outside -> exact zeros; exactly-on-border samples follow the reference's strict inequalities
+    v = torch.randn(1, 24, 2, 4)
+    loc = torch.tensor([[-0.5, 0.5], [1.5, 0.5], [0.5, -0.3], [0.5, 1.4]]).view(1, 4, 1, 1, 1, 2).repeat(1, 1, 2, 1, 1, 1)
+    at = torch.ones(1, 4, 2, 1, 1)
+    out = MSDA.ms_deform_attn_forward(v.cuda(), sh, st, loc.cuda(), at.cuda(), 64).cpu()
+    assert torch.equal(out, torch.zeros_like(out))
+    loc = torch.tensor([[0.0, 0.0], [1.0, 1.0], [-1.0 / 12, 0.5], [1.0 + 1.0 / 12, 0.5]]).view(1, 4, 1, 1, 1, 2).repeat(1, 1, 2, 1, 1, 1)
+    out = MSDA.ms_deform_attn_forward(v.cuda(), sh, st, loc.cuda().contiguous(), at.cuda(), 64).cpu()
+    ref = O.msda_forward(v, [(4, 6)], [0], loc, at)
+    assert maxdiff(out, ref) < 1e-6
+    # contract errors are RuntimeErrors like the reference's AT_ASSERTM
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v, sh, st, loc, at, 64)             # CPU tensor
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v.cuda().transpose(1, 2), sh, st, loc.cuda(), at.cuda(), 64)   # non-contiguous
+
+
+def test_full_size_properties():
+    """R50_ovis_360 encoder shape (B=4,S=Q=5100,M=8,D=32,L=P=4): the oracle is too slow at this size, so
+    check size-independent properties: linearity in value, partition of unity (constant value map +
+    interior samples -> sum of weights), and agreement with the oracle on a slice."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    g = torch.Generator().manual_seed(0)
+    shapes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    S = sum(h * w for h, w in shapes)
+    starts = [0, 3840, 4800, 5040]
+    B, M, D, L, P = 4, 8, 32, 4, 4
+    sh = torch.tensor(shapes, dtype=torch.int64).cuda()
+    st = torch.tensor(starts, dtype=torch.int64).cuda()
+    v1 = torch.randn(B, S, M, D, generator=g)
+    v2 = torch.randn(B, S, M, D, generator=g)
+    loc = torch.rand(B, S, 1, 1, 1, 2, generator=g) + 0.08 * torch.randn(B, S, M, L, P, 2, generator=g)
+    at = torch.softmax(torch.randn(B, S, M, L * P, generator=g), -1).view(B, S, M, L, P)
+    f = lambda v: MSDA.ms_deform_attn_forward(v.cuda(), sh, st, loc.cuda(), at.cuda(), 64)
+    o1, o2, o12 = f(v1), f(v2), f(2 * v1 - 3 * v2)
+    assert maxdiff((2 * o1 - 3 * o2).cpu(), o12.cpu()) < 1e-4
+    # constant map, interior samples: every sample returns the constant, weights sum to 1
+    loc_in = 0.25 + 0.5 * torch.rand(B, S, M, L, P, 2, generator=g)
+    oc = MSDA.ms_deform_attn_forward(torch.full((B, S, M, D), 1.5).cuda(), sh, st, loc_in.cuda(), at.cuda(), 64).cpu()
+    assert maxdiff(oc, torch.full_like(oc, 1.5)) < 1e-5
+    # oracle on a slice of queries
+    ref = O.msda_forward(v1[:1], shapes, starts, loc[:1, :600], at[:1, :600])
+    assert maxdiff(o1[:1, :600].cpu(), ref) < 2e-5
