@@ -58,6 +58,57 @@ int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* shapes, con
                                   int B, int S, int M, int D, int G, int L, int Q, int P,
                                   float scale, float* out, void* stream);
 
+/* ---- fp32 NT GEMM with fused epilogue (v_mfma_f32_32x32x2_f32, exact fp32) ----------------------
+ * C[m,n] = mask( act(sum_k A[m*lda+k] * W[n*K+k] + bias[n]) + residual[(res_mod? m%res_mod : m)*ldr + n] )
+ * Serves nn.Linear / 1x1 conv call sites of the path: value_proj/output_proj/sampling_offsets/
+ * attention_weights (ops/modules/ms_deform_attn.py:136-171), FFNs (transformer_enc.py:106,
+ * transformer_dec.py:356,406), MLP heads (models/misc.py:6-18), MHA projections
+ * (transformer_dec.py:350,399), input_proj 1x1 (models/mdqe.py:34-37), dynamic mask product
+ * (mdqe/mdqe.py:384).  K % 4 == 0, lda % 4 == 0, A/W 16-B aligned.  act applies to columns
+ * < act_cols (<=0: all); rowmask (u8, 1 = zero the row) applies to columns < mask_cols
+ * (the masked_fill of ms_deform_attn.py:137-138).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64. */
+int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
+                     int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
+                     const unsigned char* rowmask, int mask_cols, int tile, void* stream);
+
+/* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
+ * X [NI,H,W,Cin] (Cin % 32 == 0), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,
+ * activation and residual (ResNet bottlenecks -- detectron2 build_resnet_backbone, call site
+ * mdqe/mdqe.py:27,33; input_proj 3x3 s2 models/mdqe.py:40-43; MaskHead 3x3 segmentation.py:42-57). */
+int mdqe_conv2d_nhwc_f32(const float* X, const float* Wt, const float* bias, float* Y, long ldy,
+                         int NI, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                         int act, const float* residual, long ldr, int tile, void* stream);
+
+/* ---- LayerNorm over the last dim: y = LN(x + res) * gamma + beta (res may be NULL) -----------------
+ * nn.LayerNorm call sites transformer_enc.py:103-108,136; transformer_dec.py:345-358,394-408,466,492. */
+int mdqe_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                       long rows, int C, float eps, void* stream);
+
+/* ---- GroupNorm on NHWC [NI, HW, C] (+ fused activation); workspace >= mdqe_groupnorm_workspace_bytes --
+ * nn.GroupNorm call sites models/mdqe.py:36,42; segmentation.py:21-26,104-105,112. */
+long mdqe_groupnorm_workspace_bytes(int NI, int G);
+int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, float* y, long ldy, int NI, int HW, int C, int G,
+                            const float* gamma, const float* beta, float eps, int act, void* workspace, void* stream);
+
+/* ---- stem: (x-mean)/std (mdqe/mdqe.py:473-484) + zero pad to /32 (ImageList.from_tensors, mdqe.py:318)
+ * + 7x7/s2/p3 im2col -> [NI*Hp/2*Wp/2, 160] (K=147 zero-padded) for the stem GEMM.
+ * frames: NI CHW images (u8 or f32) h x w, frame_stride elements apart; mean/std are HOST float[3]. */
+int mdqe_stem_im2col_f32(const void* frames, int is_u8, long frame_stride, int NI, int h, int w, int Hp, int Wp,
+                         const float* mean3_host, const float* std3_host, float* out, void* stream);
+
+/* ---- 3x3/s2/p1 max pool NHWC (ResNet stem) */
+int mdqe_maxpool3x3s2_nhwc_f32(const float* x, float* y, int NI, int H, int W, int C, void* stream);
+
+/* ---- y = a + nearest_upsample(b)  (segmentation.py:47-55) */
+int mdqe_upsample_nearest_add_nhwc_f32(const float* a, const float* b, float* y, int NI, int H, int W, int Hb, int Wb,
+                                       int C, void* stream);
+
+/* ---- depthwise 5x5 conv NHWC, weights [25][C]; up2 != 0 applies it to the virtual output of the depthwise
+ * ConvTranspose2d(k=1,s=2,output_padding=1) (weights tw,tb [C]) of an input stored at (H/2)x(W/2)
+ * (segmentation.py:28-31,59,92-98). H,W are output sizes. */
+int mdqe_dwconv5x5_nhwc_f32(const float* x, const float* wt, const float* bias, float* y, int NI, int H, int W, int C,
+                            int up2, const float* tw, const float* tb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,12 +6,21 @@ from ctypes import c_char_p, c_float, c_int, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdqe_hip.so")
 
-i, f, p = c_int, c_float, c_void_p
+from ctypes import c_long
+i, f, p, l = c_int, c_float, c_void_p, c_long
 
 # name -> argtypes; every function returns int status (include/mdqe_hip.h)
 SIGNATURES = {
     "mdqe_msda_forward_f32": [p, p, p, p, p, i, i, i, i, i, i, i, p, p],
     "mdqe_msda_forward_grouped_f32": [p, p, p, p, p, i, i, i, i, i, i, i, i, f, p, p],
+    "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, p, i, i, p],
+    "mdqe_conv2d_nhwc_f32": [p, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, p],
+    "mdqe_layernorm_f32": [p, p, p, p, p, l, i, f, p],
+    "mdqe_groupnorm_nhwc_f32": [p, l, p, l, i, i, i, i, p, p, f, i, p, p],
+    "mdqe_stem_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],
+    "mdqe_maxpool3x3s2_nhwc_f32": [p, p, i, i, i, i, p],
+    "mdqe_upsample_nearest_add_nhwc_f32": [p, p, p, i, i, i, i, i, i, p],
+    "mdqe_dwconv5x5_nhwc_f32": [p, p, p, p, i, i, i, i, i, p, p, p],
 }
 
 
@@ -39,6 +48,8 @@ def load_library(path=None):
     h.mdqe_version.restype = c_int
     h.mdqe_strerror.restype = c_char_p
     h.mdqe_strerror.argtypes = [c_int]
+    h.mdqe_groupnorm_workspace_bytes.restype = c_long
+    h.mdqe_groupnorm_workspace_bytes.argtypes = [c_int, c_int]
     for name, args in SIGNATURES.items():
         fn = getattr(h, name)          # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args

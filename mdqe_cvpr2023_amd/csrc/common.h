@@ -7,6 +7,9 @@
 #define MDQE_CHECK_PTR(p) do { if ((p) == nullptr) return MDQE_ENULL; } while (0)
 #define MDQE_REQUIRE(c) do { if (!(c)) return MDQE_EINVAL; } while (0)
 
+// hipGetLastError() is per-thread and sticky across *other* libraries' calls (torch's event queries
+// leave hipErrorNotReady behind), so entry points clear it before launching and read it after.
+static inline void mdqe_clear_error() { (void)hipGetLastError(); }
 static inline int mdqe_launch_status() {
   return hipGetLastError() == hipSuccess ? MDQE_OK : MDQE_ELAUNCH;
 }

@@ -1,0 +1,264 @@
+// fp32 NT GEMM / NHWC implicit-GEMM convolution on the gfx950 matrix cores.
+//
+//   C[m, n] = epilogue( sum_k A(m, k) * W[n, k] )          A, W, C fp32; exact fp32 arithmetic
+//
+// v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate; bit-for-bit an fmaf chain, 157 TFLOP/s peak)
+// is used because the path's parity bar is fp32 (north star: 1e-3 against the fp32 CPU path).
+//
+// Serves every Linear / 1x1 conv / KxK conv on the hot path:
+//   * plain mode:  A(m,k) = A[m*lda + k]
+//   * conv mode:   m = (img, oh, ow), k = (kh, kw, cin) over an NHWC input; zero padding comes
+//                  from the buffer-descriptor bounds check (out-of-range lanes return 0).
+// W is [N][K] row-major (nn.Linear layout; convs are pre-packed [Cout][KH][KW][Cin]).
+//
+// Structure (CDNA4): block tile BM x BN, K-step 32 floats (one 128-B line per row).  Tiles go
+// HBM/L2 -> LDS with buffer_load ... lds (16 B per lane, 1 KiB per wave-instruction, no VGPR round
+// trip), double buffered; the load of step k+1 is issued before the MFMAs of step k.  LDS rows are
+// 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the *source* side (the LDS write
+// of an LDS-DMA is lane-linear) and on the ds_read_b128 side, which makes every 16-lane read group
+// hit 16 distinct 16-B slots (conflict-free).  One ds_read_b128 per operand feeds four MFMAs:
+// lanes 0-31 carry k = 4c..4c+3 of their row, lanes 32-63 carry the next four.
+#include "common.h"
+
+struct GemmParams {
+  const float* A; const float* W; float* C;
+  int M, N, K;
+  long lda, ldc;
+  // conv mode (KH > 0): A is NHWC [NI, H, W_, Cin]
+  int conv; int H, Wd, Cin, OH, OW, KH, KW, stride, pad;
+  // epilogue
+  const float* bias;        // [N] or null
+  const float* residual;    // [res_rows, ldr] or null, added after activation
+  long ldr; int res_mod;    // row index = res_mod > 0 ? m % res_mod : m
+  const unsigned char* rowmask; int mask_cols;   // C[m, n < mask_cols] = 0 where rowmask[m] != 0
+  int act; int act_cols;    // activation on columns < act_cols (act_cols <= 0: all)
+  unsigned a_bytes, w_bytes;
+};
+
+#define OOB_OFF 0xFFFFFFF0u
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN)
+gemm_nt_f32_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int BK = 32;
+  constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+  constexpr int ROWS = BM + BN;              // A rows then W rows in one LDS image
+  constexpr int NINST = ROWS / 8;            // 1-KiB LDS-DMA instructions per stage
+  constexpr int IPW = NINST / NW;            // per wave
+  static_assert(NINST % NW == 0, "tile rows must split evenly over waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * ROWS * 32 floats
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware tile order: blocks that share an A row-panel run on the same XCD (same L2).
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int bm = bid / nbn, bn = bid % nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+
+  // Per-lane source bookkeeping for this lane's IPW rows (fixed over the K loop).
+  // instruction j of this wave covers image rows (wave*IPW + j)*8 .. +7; lane -> row += lane>>3, chunk' = lane&7
+  unsigned rowoff[IPW];    // byte offset of (row, k=0) in its tensor; conv: of (img, ih0, iw0, 0)
+  int ih0[IPW], iw0[IPW];
+  int csw[IPW];            // source chunk = (lane&7) ^ ((row>>1)&7)
+#pragma unroll
+  for (int j = 0; j < IPW; ++j) {
+    const int irow = (wave * IPW + j) * 8 + (lane >> 3);
+    csw[j] = (lane & 7) ^ ((irow >> 1) & 7);
+    ih0[j] = 0; iw0[j] = 0;
+    if (irow < BM) {
+      int m = m0 + irow; if (m > p.M - 1) m = p.M - 1;
+      if (p.conv) {
+        const int ow = m % p.OW; const int t = m / p.OW; const int oh = t % p.OH; const int img = t / p.OH;
+        ih0[j] = oh * p.stride - p.pad; iw0[j] = ow * p.stride - p.pad;
+        rowoff[j] = (unsigned)((((long)img * p.H + ih0[j]) * p.Wd + iw0[j]) * p.Cin * 4);   // may wrap; fixed below
+      } else {
+        rowoff[j] = (unsigned)((long)m * p.lda * 4);
+      }
+    } else {
+      int n = n0 + irow - BM; if (n > p.N - 1) n = p.N - 1;
+      rowoff[j] = (unsigned)((long)n * p.K * 4);
+    }
+  }
+
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    // conv: the 32-float K-step lies inside one filter tap (Cin % 32 == 0, checked on the host)
+    int tap_off = 0, kh = 0, kw = 0, cin0 = k0;
+    if (p.conv) {
+      const int tap = k0 / p.Cin; cin0 = k0 - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW;
+      tap_off = ((kh * p.Wd + kw) * p.Cin + cin0) * 4;
+    }
+    float* base = lds + buf * (ROWS * BK);
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int inst = wave * IPW + j;
+      const int irow0 = inst * 8;                    // wave-uniform
+      const int kk = k0 + csw[j] * 4;
+      unsigned off;
+      if (irow0 < BM) {
+        if (p.conv) {
+          const int ih = ih0[j] + kh, iw = iw0[j] + kw;
+          const bool ok = (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.Wd);
+          off = ok ? rowoff[j] + (unsigned)tap_off + (unsigned)(csw[j] * 16) : OOB_OFF;
+        } else {
+          off = kk < p.K ? rowoff[j] + (unsigned)(kk * 4) : OOB_OFF;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK),
+                                                 16, off, 0, 0, 0);
+      } else {
+        off = kk < p.K ? rowoff[j] + (unsigned)(kk * 4) : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + irow0 * BK),
+                                                 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int lr = lane & 31, lh = lane >> 5;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for step kt has landed
+    __syncthreads();                                   // ... and everybody else's; all reads of the other buffer are done
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const float* sA = lds + (kt & 1) * (ROWS * BK);
+    const float* sW = sA + BM * BK;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * (BM / WM) + i * 32 + lr;
+        const int ch = (kk * 2 + lh) ^ ((row >> 1) & 7);
+        a[i] = *reinterpret_cast<const f32x4*>(sA + row * BK + ch * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * (BN / WN) + j * 32 + lr;
+        const int ch = (kk * 2 + lh) ^ ((row >> 1) & 7);
+        b[j] = *reinterpret_cast<const f32x4*>(sW + row * BK + ch * 4);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: acc[i][j][r] is C(row = (r&3) + 8*(r>>2) + 4*lh, col = lr) of the 32x32 sub-tile
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 32 + lr;
+    const bool nok = n < p.N;
+    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+    const bool do_act = p.act != MDQE_ACT_NONE && (p.act_cols <= 0 || n < p.act_cols);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nok && m < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (do_act) v = mdqe_act(v, p.act);
+          if (p.residual != nullptr) {
+            const long rr = p.res_mod > 0 ? (m % p.res_mod) : m;
+            v += p.residual[rr * p.ldr + n];
+          }
+          if (p.rowmask != nullptr && n < p.mask_cols && p.rowmask[m]) v = 0.f;
+          p.C[(long)m * p.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmParams& p, hipStream_t st) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const size_t smem = 2 * (BM + BN) * 32 * sizeof(float);
+  auto kern = gemm_nt_f32_kernel<BM, BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(64 * WM * WN), smem, st, p);
+  return mdqe_launch_status();
+}
+
+static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
+  // tile: 0 = auto
+  if (tile == 0) {
+    const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
+    else if (b128 >= 192) tile = 1;
+    else tile = 3;
+  }
+  switch (tile) {
+    case 1: return launch_gemm<128, 128, 2, 2>(p, st);
+    case 2: return launch_gemm<128, 64, 2, 2>(p, st);
+    case 3: return launch_gemm<64, 64, 2, 2>(p, st);
+    default: return MDQE_EINVAL;
+  }
+}
+
+extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
+                                int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
+                                const unsigned char* rowmask, int mask_cols, int tile, void* stream) {
+  MDQE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N);
+  if (M == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
+  MDQE_REQUIRE((((uintptr_t)A | (uintptr_t)W) & 15) == 0);
+  const long ab = ((long)(M - 1) * lda + K) * 4, wb = (long)N * K * 4;
+  MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  GemmParams p = {};
+  p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
+  p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = res_mod; p.rowmask = rowmask; p.mask_cols = mask_cols;
+  p.act = act; p.act_cols = act_cols; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+  mdqe_clear_error();
+  return dispatch_gemm(p, tile, (hipStream_t)stream);
+}
+
+extern "C" int mdqe_conv2d_nhwc_f32(const float* X, const float* Wt, const float* bias, float* Y, long ldy,
+                                    int NI, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                    int act, const float* residual, long ldr, int tile, void* stream) {
+  MDQE_REQUIRE(NI >= 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+  MDQE_REQUIRE(Cin % 32 == 0);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
+  MDQE_REQUIRE(OH > 0 && OW > 0 && ldy >= Cout);
+  if (NI == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(X); MDQE_CHECK_PTR(Wt); MDQE_CHECK_PTR(Y);
+  MDQE_REQUIRE((((uintptr_t)X | (uintptr_t)Wt) & 15) == 0);
+  const long ab = (long)NI * H * Wd * Cin * 4, wb = (long)Cout * KH * KW * Cin * 4;
+  MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L && (long)NI * OH * OW < 0x7FFFFFFFL);
+  GemmParams p = {};
+  p.A = X; p.W = Wt; p.C = Y; p.M = NI * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.lda = 0; p.ldc = ldy;
+  p.conv = 1; p.H = H; p.Wd = Wd; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = 0; p.rowmask = nullptr; p.mask_cols = 0;
+  p.act = act; p.act_cols = 0; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+  mdqe_clear_error();
+  return dispatch_gemm(p, tile, (hipStream_t)stream);
+}

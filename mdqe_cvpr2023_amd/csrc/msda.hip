@@ -106,6 +106,7 @@ extern "C" int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* 
   MDQE_CHECK_PTR(value); MDQE_CHECK_PTR(shapes); MDQE_CHECK_PTR(level_start);
   MDQE_CHECK_PTR(loc); MDQE_CHECK_PTR(attn); MDQE_CHECK_PTR(out);
   hipStream_t st = (hipStream_t)stream;
+  mdqe_clear_error();
   const bool al16 = (((uintptr_t)value | (uintptr_t)out) & 15) == 0;
   const bool al8 = (((uintptr_t)value | (uintptr_t)out) & 7) == 0;
   if (D % 4 == 0 && al16) return launch_msda<4>(value, shapes, level_start, loc, attn, B, S, M, D, G, L, Q, P, scale, out, st);

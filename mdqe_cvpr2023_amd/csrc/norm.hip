@@ -1,0 +1,179 @@
+// LayerNorm and NHWC GroupNorm for gfx950.  Both are HBM-streaming kernels: 16-B lane accesses,
+// one wave per LayerNorm row, two deterministic passes (partials -> apply) for GroupNorm.
+#include "common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// y[r,:] = LN(x[r,:] + res[r,:]) * gamma + beta   (nn.LayerNorm eps=1e-5; transformer_enc.py:103-108,
+// transformer_dec.py:345-358).  Optional second output y2 = y + add2[(r % add2_mod), :].
+template <int NCH>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                 const float* __restrict__ beta, float* __restrict__ y, long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * (blockDim.x >> 6);
+  for (long r = wid; r < rows; r += nw) {
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < C) {
+        v[i] = *reinterpret_cast<const f32x4*>(x + r * C + c);
+        if (res != nullptr) v[i] += *reinterpret_cast<const f32x4*>(res + r * C + c);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < C) {
+        const f32x4 d = v[i] - mean;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < C) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        *reinterpret_cast<f32x4*>(y + r * C + c) = (v[i] - mean) * rstd * g + b;
+      }
+    }
+  }
+}
+
+extern "C" int mdqe_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                  long rows, int C, float eps, void* stream) {
+  MDQE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 1024);
+  if (rows == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta); MDQE_CHECK_PTR(y);
+  mdqe_clear_error();
+  long nb = (rows + 3) / 4;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, y, rows, C, eps);
+  else if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, y, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, y, rows, C, eps);
+  return mdqe_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm over NHWC [NI, HW, C] (ldx floats between pixels), G groups of C/G channels
+// (nn.GroupNorm eps 1e-5: models/mdqe.py:36,42; segmentation.py:21-26,104-105).
+// Pass 1: block (chunk, img) accumulates per-channel sum / sum-of-squares over its pixel chunk,
+//         folds channels into groups and writes partial[img][chunk][g][2] (double).
+// Pass 2: every block re-derives mean/rstd from the partials (<= 64 chunks) and applies
+//         y = act((x-mean)*rstd*gamma+beta) with 16-B accesses.  Deterministic (no atomics).
+// ---------------------------------------------------------------------------------------------
+#define GN_MAX_CHUNKS 64
+
+__global__ void __launch_bounds__(256)
+gn_partial_kernel(const float* __restrict__ x, long ldx, int HW, int C, int G, int nchunks, double* __restrict__ part) {
+  __shared__ float sh_s[1024], sh_q[1024];      // [rsub][channel] partial sums of the block's threads
+  __shared__ double ch_s[1024], ch_q[1024];     // per channel
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int c4n = C / 4;                        // float4 columns (<= 256)
+  const int tpr = 256 / c4n;                    // pixel rows handled in parallel
+  const int col = threadIdx.x % c4n, rsub = threadIdx.x / c4n;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (rsub < tpr) {
+    const float* base = x + (long)img * HW * ldx + col * 4;
+    for (int p = p0 + rsub; p < p1; p += tpr) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)p * ldx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s[k] += v[k]; q[k] += v[k] * v[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh_s[rsub * C + col * 4 + k] = s[k]; sh_q[rsub * C + col * 4 + k] = q[k]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < tpr; ++r) { a += (double)sh_s[r * C + c]; b += (double)sh_q[r * C + c]; }
+    ch_s[c] = a; ch_q[c] = b;
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  if (threadIdx.x < G) {
+    double a = 0.0, b = 0.0;
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { a += ch_s[c]; b += ch_q[c]; }
+    double* o = part + (((long)img * nchunks + chunk) * G + threadIdx.x) * 2;
+    o[0] = a; o[1] = b;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, int HW, int C, int G, int nchunks,
+                const double* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+                float eps, int act) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int img = blockIdx.y;
+  if (threadIdx.x < G) {
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+      const double* o = part + (((long)img * nchunks + c) * G + threadIdx.x) * 2;
+      s += o[0]; q += o[1];
+    }
+    const double n = (double)HW * (C / G);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    s_mean[threadIdx.x] = (float)mean;
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int c4n = C / 4, cpg = C / G;
+  const long total = (long)HW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % c4n);
+    const long p = i / c4n;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)img * HW + p) * ldx + col * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int gi = (col * 4 + k) / cpg;
+      o[k] = mdqe_act((v[k] - s_mean[gi]) * s_rstd[gi] * g[k] + b[k], act);
+    }
+    *reinterpret_cast<f32x4*>(y + ((long)img * HW + p) * ldy + col * 4) = o;
+  }
+}
+
+extern "C" long mdqe_groupnorm_workspace_bytes(int NI, int G) { return (long)NI * GN_MAX_CHUNKS * G * 2 * sizeof(double); }
+
+extern "C" int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, float* y, long ldy, int NI, int HW, int C, int G,
+                                       const float* gamma, const float* beta, float eps, int act, void* workspace,
+                                       void* stream) {
+  MDQE_REQUIRE(NI >= 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0 && C % 4 == 0 && C <= 1024);
+  MDQE_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0);
+  if (NI == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(y); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta); MDQE_CHECK_PTR(workspace);
+  mdqe_clear_error();
+  hipStream_t st = (hipStream_t)stream;
+  int nchunks = (HW + 255) / 256;
+  if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
+  if (nchunks < 1) nchunks = 1;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, NI), dim3(256), 0, st, x, ldx, HW, C, G, nchunks, (double*)workspace);
+  int rc = mdqe_launch_status();
+  if (rc) return rc;
+  long blocks = ((long)HW * (C / 4) + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, NI), dim3(256), 0, st, x, ldx, y, ldy, HW, C, G, nchunks,
+                     (const double*)workspace, gamma, beta, eps, act);
+  return mdqe_launch_status();
+}

@@ -1,0 +1,152 @@
+"""Host wrappers over the C ABI (include/mdqe_hip.h): torch owns memory + stream, HIP does the math.
+
+All tensors are CUDA fp32 contiguous unless stated; images are NHWC.  Nothing here falls back to
+torch arithmetic: a missing library or an unsupported shape raises.
+"""
+import torch
+
+from ._lib import check, cur_stream, lib, ptr
+
+ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "tanh": 4}
+
+_ws = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected contiguous CUDA {dtype} tensor, got {t.dtype} {t.device} "
+                           f"contiguous={t.is_contiguous()}")
+
+
+def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=None, mask_cols=0, act_cols=0,
+           out=None, ldc=None, tile=0):
+    """out[..., n] = epilogue(x[..., :] @ weight[n, :]).  x may be a 2-D row-strided view (last dim contiguous)."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    if x.dim() != 2:
+        x2 = x.reshape(-1, K)
+    else:
+        x2 = x
+    if x2.stride(-1) != 1:
+        raise RuntimeError("linear: last dim of x must be contiguous")
+    M = x2.shape[0]
+    lda = x2.stride(0) if M > 1 else K
+    _chk(weight, "weight"); _chk(bias, "bias")
+    if rowmask is not None and rowmask.dtype == torch.bool:
+        rowmask = rowmask.view(torch.uint8)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        ldc_ = N
+    else:
+        ldc_ = ldc if ldc is not None else out.stride(0) if out.dim() == 2 else N
+    ldr = 0
+    if residual is not None:
+        ldr = residual.stride(0) if residual.dim() == 2 else residual.shape[-1]
+    check(lib.mdqe_gemm_nt_f32(ptr(x2), lda, ptr(weight), ptr(bias), ptr(out), ldc_, M, N, K, ACT[act], act_cols,
+                               ptr(residual), ldr, res_mod, ptr(rowmask), mask_cols, tile, cur_stream()), "gemm_nt_f32")
+    if x.dim() != 2 and ldc is None and out.dim() == 2 and out.shape == (M, N):
+        return out.view(*x.shape[:-1], N)
+    return out
+
+
+def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None, out=None, tile=0):
+    """x [NI,H,W,Cin]; w_packed [Cout,KH,KW,Cin]; returns [NI,OH,OW,Cout]."""
+    _chk(x, "x"); _chk(w_packed, "w"); _chk(bias, "bias"); _chk(residual, "residual")
+    NI, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_packed.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((NI, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    ldy = out.stride(-2)
+    ldr = residual.stride(-2) if residual is not None else 0
+    check(lib.mdqe_conv2d_nhwc_f32(ptr(x), ptr(w_packed), ptr(bias), ptr(out), ldy, NI, H, W, Cin, Cout, KH, KW, stride,
+                                   pad, ACT[act], ptr(residual), ldr, tile, cur_stream()), "conv2d_nhwc_f32")
+    return out
+
+
+def layernorm(x, gamma, beta, res=None, eps=1e-5, out=None):
+    _chk(x, "x"); _chk(res, "res"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.mdqe_layernorm_f32(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(out), rows, C, eps, cur_stream()), "layernorm")
+    return out
+
+
+def groupnorm_nhwc(x, groups, gamma, beta, act=None, eps=1e-5, out=None):
+    """x [NI, ..., C] (NHWC, pixel stride = x.stride(-2)); in-place allowed (out=x)."""
+    NI, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (NI * C)
+    if out is None:
+        out = torch.empty_like(x)
+    ws = _workspace(lib.mdqe_groupnorm_workspace_bytes(NI, groups), x.device)
+    check(lib.mdqe_groupnorm_nhwc_f32(ptr(x), x.stride(-2), ptr(out), out.stride(-2), NI, HW, C, groups, ptr(gamma),
+                                      ptr(beta), eps, ACT[act], ptr(ws), cur_stream()), "groupnorm_nhwc")
+    return out
+
+
+def stem_im2col(frames, Hp, Wp, mean, std):
+    """frames [NI,3,h,w] uint8 or fp32 CUDA -> [NI*Hp/2*Wp/2, 160] normalised+padded im2col."""
+    import ctypes
+    if not frames.is_cuda or not frames.is_contiguous() or frames.dtype not in (torch.uint8, torch.float32):
+        raise RuntimeError("stem_im2col: frames must be contiguous CUDA uint8/float32 [NI,3,h,w]")
+    NI, _, h, w = frames.shape
+    out = torch.empty((NI * (Hp // 2) * (Wp // 2), 160), dtype=torch.float32, device=frames.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(lib.mdqe_stem_im2col_f32(ptr(frames), int(frames.dtype == torch.uint8), 3 * h * w, NI, h, w, Hp, Wp, m, s, ptr(out),
+                                   cur_stream()), "stem_im2col")
+    return out
+
+
+def maxpool3x3s2(x):
+    _chk(x, "x")
+    NI, H, W, C = x.shape
+    out = torch.empty((NI, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    check(lib.mdqe_maxpool3x3s2_nhwc_f32(ptr(x), ptr(out), NI, H, W, C, cur_stream()), "maxpool")
+    return out
+
+
+def upsample_nearest_add(a, b, out=None):
+    _chk(a, "a"); _chk(b, "b")
+    NI, H, W, C = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.mdqe_upsample_nearest_add_nhwc_f32(ptr(a), ptr(b), ptr(out), NI, H, W, b.shape[1], b.shape[2], C, cur_stream()),
+          "upsample_nearest_add")
+    return out
+
+
+def dwconv5x5(x, wt, bias, up2=False, tw=None, tb=None):
+    """x [NI,H,W,C]; wt [25,C]; if up2: output is [NI,2H,2W,C] over the virtual transposed-conv output."""
+    _chk(x, "x"); _chk(wt, "wt"); _chk(bias, "bias")
+    NI, H, W, C = x.shape
+    OH, OW = (2 * H, 2 * W) if up2 else (H, W)
+    out = torch.empty((NI, OH, OW, C), dtype=torch.float32, device=x.device)
+    check(lib.mdqe_dwconv5x5_nhwc_f32(ptr(x), ptr(wt), ptr(bias), ptr(out), NI, OH, OW, C, int(up2), ptr(tw), ptr(tb),
+                                      cur_stream()), "dwconv5x5")
+    return out
+
+
+def msda(value, shapes_dev, starts_dev, loc, attn, groups=1, scale=1.0, out=None):
+    """value [B,S,M,D]; shapes_dev [G*L,2] int64; loc [B,Q,M,L,P,2]; attn [B,Q,M,L,P] -> [B,Q,M*D]."""
+    B, S, M, D = value.shape
+    Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    if out is None:
+        out = torch.empty((B, Q, M * D), dtype=torch.float32, device=value.device)
+    check(lib.mdqe_msda_forward_grouped_f32(ptr(value), ptr(shapes_dev), ptr(starts_dev), ptr(loc), ptr(attn), B, S, M, D,
+                                            groups, L, Q, P, scale, ptr(out), cur_stream()), "msda")
+    return out

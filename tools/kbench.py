@@ -58,3 +58,33 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.what in ("msda", "all"):
         bench_msda(a)
+
+
+def bench_gemm(args):
+    from mdqe_cvpr2023_amd import ops
+    res = []
+    for name, M, N, K, tile in (("enc_qkv_30f", 153000, 640, 256, 1), ("enc_ffn1_30f", 153000, 1024, 256, 1),
+                                ("enc_ffn2_30f", 153000, 256, 1024, 1), ("enc_out_30f", 153000, 256, 256, 1),
+                                ("enc_ffn1_4f", 20400, 1024, 256, 1), ("dec_q_784", 784, 256, 256, 3),
+                                ("dec_val_4f", 20400, 256, 256, 1), ("dec_val_4f_t3", 20400, 256, 256, 3)):
+        x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda")
+        ms = time_ms(lambda: ops.linear(x, w, b, out=out, tile=tile), iters=20, warm=5)
+        tf = 2.0 * M * N * K / ms / 1e9
+        res.append(dict(case=name, M=M, N=N, K=K, tile=tile, ms=ms, TFLOPs=tf, frac_f32_mfma_peak=tf / 157.3))
+        print(json.dumps(res[-1]))
+    # backbone-style convs (NHWC implicit GEMM), 30 frames at 384x640
+    for name, NI, H, W, Cin, Cout, k, s, p in (("res2_3x3", 30, 96, 160, 64, 64, 3, 1, 1), ("res3_3x3", 30, 48, 80, 128, 128, 3, 1, 1),
+                                               ("res4_3x3", 30, 24, 40, 256, 256, 3, 1, 1), ("res5_3x3", 30, 12, 20, 512, 512, 3, 1, 1),
+                                               ("res4_1x1", 30, 24, 40, 1024, 256, 1, 1, 0)):
+        x = torch.randn(NI, H, W, Cin, device="cuda"); w = torch.randn(Cout, k, k, Cin, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
+        ms = time_ms(lambda: ops.conv2d_nhwc(x, w, b, s, p, act="relu"), iters=20, warm=5)
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        tf = 2.0 * NI * OH * OW * Cout * Cin * k * k / ms / 1e9
+        res.append(dict(case=name, ms=ms, TFLOPs=tf, frac_f32_mfma_peak=tf / 157.3))
+        print(json.dumps(res[-1]))
+    return res
+
+
+if __name__ == "__main__" and a.what in ("gemm", "all"):
+    bench_gemm(a)
