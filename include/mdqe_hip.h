@@ -58,8 +58,21 @@ int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* shapes, con
                                   int B, int S, int M, int D, int G, int L, int Q, int P,
                                   float scale, float* out, void* stream);
 
+/* Fused module core (ops/modules/ms_deform_attn.py:141-170 / 198-235): consumes the projection GEMM's raw
+ * outputs.  value rows are ldv floats apart, batch b starts at row b*v_brows; offs row t=(b*Q+q) holds
+ * M*L*P*2 floats, logits row t holds M*L*P.  mode 0 (encoder): loc = ref_xy + off/8.  mode 1 (decoder):
+ * loc = ref_xy + (grid*0.5*wh + clamp(off, +-8*wh))/8 with ref = (cx,cy,w,h) and grid [M,L,P,2] (device).
+ * ref row = b*ref_bstride + q*ref_dim (ref_bstride 0 broadcasts one table over the batch).
+ * Level tables (HOST int[G*L]): H, W, start row.  out row t, ldout floats apart; out = scale * sum_g(...). */
+int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const float* offs, long ldo,
+                        const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
+                        int mode, const float* grid, const int* lvH_host, const int* lvW_host,
+                        const int* lvStart_host, int B, int M, int D, int G, int L, int Q, int P, float scale,
+                        float* out, long ldout, void* stream);
+
 /* ---- fp32 NT GEMM with fused epilogue (v_mfma_f32_32x32x2_f32, exact fp32) ----------------------
  * C[m,n] = mask( act(sum_k A[m*lda+k] * W[n*K+k] + bias[n]) + residual[(res_mod? m%res_mod : m)*ldr + n] )
+ * (res_first != 0: the residual is added before the activation instead, as in a ResNet bottleneck)
  * Serves nn.Linear / 1x1 conv call sites of the path: value_proj/output_proj/sampling_offsets/
  * attention_weights (ops/modules/ms_deform_attn.py:136-171), FFNs (transformer_enc.py:106,
  * transformer_dec.py:356,406), MLP heads (models/misc.py:6-18), MHA projections
@@ -69,15 +82,15 @@ int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* shapes, con
  * (the masked_fill of ms_deform_attn.py:137-138).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64. */
 int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                      int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
-                     const unsigned char* rowmask, int mask_cols, int tile, void* stream);
+                     int res_first, const unsigned char* rowmask, int mask_cols, int tile, void* stream);
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
- * X [NI,H,W,Cin] (Cin % 32 == 0), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,
+ * X [NI,H,W,Cin] (Cin % 32 == 0; images x_img_stride floats apart, <=0: dense), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,
  * activation and residual (ResNet bottlenecks -- detectron2 build_resnet_backbone, call site
  * mdqe/mdqe.py:27,33; input_proj 3x3 s2 models/mdqe.py:40-43; MaskHead 3x3 segmentation.py:42-57). */
-int mdqe_conv2d_nhwc_f32(const float* X, const float* Wt, const float* bias, float* Y, long ldy,
+int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                          int NI, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                         int act, const float* residual, long ldr, int tile, void* stream);
+                         int act, const float* residual, long ldr, int res_first, int tile, void* stream);
 
 /* ---- LayerNorm over the last dim: y = LN(x + res) * gamma + beta (res may be NULL) -----------------
  * nn.LayerNorm call sites transformer_enc.py:103-108,136; transformer_dec.py:345-358,394-408,466,492. */
@@ -87,7 +100,8 @@ int mdqe_layernorm_f32(const float* x, const float* res, const float* gamma, con
 /* ---- GroupNorm on NHWC [NI, HW, C] (+ fused activation); workspace >= mdqe_groupnorm_workspace_bytes --
  * nn.GroupNorm call sites models/mdqe.py:36,42; segmentation.py:21-26,104-105,112. */
 long mdqe_groupnorm_workspace_bytes(int NI, int G);
-int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, float* y, long ldy, int NI, int HW, int C, int G,
+int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, long x_img_stride, float* y, long ldy, long y_img_stride,
+                            int NI, int HW, int C, int G,
                             const float* gamma, const float* beta, float eps, int act, void* workspace, void* stream);
 
 /* ---- stem: (x-mean)/std (mdqe/mdqe.py:473-484) + zero pad to /32 (ImageList.from_tensors, mdqe.py:318)

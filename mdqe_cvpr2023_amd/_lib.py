@@ -13,10 +13,11 @@ i, f, p, l = c_int, c_float, c_void_p, c_long
 SIGNATURES = {
     "mdqe_msda_forward_f32": [p, p, p, p, p, i, i, i, i, i, i, i, p, p],
     "mdqe_msda_forward_grouped_f32": [p, p, p, p, p, i, i, i, i, i, i, i, i, f, p, p],
-    "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, p, i, i, p],
-    "mdqe_conv2d_nhwc_f32": [p, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, p],
+    "mdqe_msda_fused_f32": [p, l, l, p, l, p, l, p, l, i, i, p, p, p, p, i, i, i, i, i, i, i, f, p, l, p],
+    "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, i, p, i, i, p],
+    "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p],
     "mdqe_layernorm_f32": [p, p, p, p, p, l, i, f, p],
-    "mdqe_groupnorm_nhwc_f32": [p, l, p, l, i, i, i, i, p, p, f, i, p, p],
+    "mdqe_groupnorm_nhwc_f32": [p, l, l, p, l, l, i, i, i, i, p, p, f, i, p, p],
     "mdqe_stem_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],
     "mdqe_maxpool3x3s2_nhwc_f32": [p, p, i, i, i, i, p],
     "mdqe_upsample_nearest_add_nhwc_f32": [p, p, p, i, i, i, i, i, i, p],

@@ -30,6 +30,8 @@ struct GemmParams {
   const float* bias;        // [N] or null
   const float* residual;    // [res_rows, ldr] or null, added after activation
   long ldr; int res_mod;    // row index = res_mod > 0 ? m % res_mod : m
+  int res_first;            // 1: add residual BEFORE the activation (ResNet bottleneck), 0: after
+  long img_stride;          // conv mode: floats between consecutive images of X
   const unsigned char* rowmask; int mask_cols;   // C[m, n < mask_cols] = 0 where rowmask[m] != 0
   int act; int act_cols;    // activation on columns < act_cols (act_cols <= 0: all)
   unsigned a_bytes, w_bytes;
@@ -83,7 +85,7 @@ gemm_nt_f32_kernel(const GemmParams p) {
       if (p.conv) {
         const int ow = m % p.OW; const int t = m / p.OW; const int oh = t % p.OH; const int img = t / p.OH;
         ih0[j] = oh * p.stride - p.pad; iw0[j] = ow * p.stride - p.pad;
-        rowoff[j] = (unsigned)((((long)img * p.H + ih0[j]) * p.Wd + iw0[j]) * p.Cin * 4);   // may wrap; fixed below
+        rowoff[j] = (unsigned)(((long)img * p.img_stride + ((long)ih0[j] * p.Wd + iw0[j]) * p.Cin) * 4);   // may wrap; fixed below
       } else {
         rowoff[j] = (unsigned)((long)m * p.lda * 4);
       }
@@ -182,11 +184,14 @@ gemm_nt_f32_kernel(const GemmParams p) {
         const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (nok && m < p.M) {
           float v = acc[i][j][r] + bv;
-          if (do_act) v = mdqe_act(v, p.act);
+          float rv = 0.f;
           if (p.residual != nullptr) {
             const long rr = p.res_mod > 0 ? (m % p.res_mod) : m;
-            v += p.residual[rr * p.ldr + n];
+            rv = p.residual[rr * p.ldr + n];
           }
+          if (p.res_first) v += rv;
+          if (do_act) v = mdqe_act(v, p.act);
+          if (!p.res_first) v += rv;
           if (p.rowmask != nullptr && n < p.mask_cols && p.rowmask[m]) v = 0.f;
           p.C[(long)m * p.ldc + n] = v;
         }
@@ -227,7 +232,7 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
 
 extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                                 int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
-                                const unsigned char* rowmask, int mask_cols, int tile, void* stream) {
+                                int res_first, const unsigned char* rowmask, int mask_cols, int tile, void* stream) {
   MDQE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N);
   if (M == 0) return MDQE_OK;
   MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
@@ -236,15 +241,15 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
   MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
   GemmParams p = {};
   p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
-  p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = res_mod; p.rowmask = rowmask; p.mask_cols = mask_cols;
+  p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = res_mod; p.res_first = res_first; p.rowmask = rowmask; p.mask_cols = mask_cols;
   p.act = act; p.act_cols = act_cols; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
   mdqe_clear_error();
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }
 
-extern "C" int mdqe_conv2d_nhwc_f32(const float* X, const float* Wt, const float* bias, float* Y, long ldy,
+extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                                     int NI, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                    int act, const float* residual, long ldr, int tile, void* stream) {
+                                    int act, const float* residual, long ldr, int res_first, int tile, void* stream) {
   MDQE_REQUIRE(NI >= 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MDQE_REQUIRE(Cin % 32 == 0);
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
@@ -252,12 +257,14 @@ extern "C" int mdqe_conv2d_nhwc_f32(const float* X, const float* Wt, const float
   if (NI == 0) return MDQE_OK;
   MDQE_CHECK_PTR(X); MDQE_CHECK_PTR(Wt); MDQE_CHECK_PTR(Y);
   MDQE_REQUIRE((((uintptr_t)X | (uintptr_t)Wt) & 15) == 0);
-  const long ab = (long)NI * H * Wd * Cin * 4, wb = (long)Cout * KH * KW * Cin * 4;
+  if (x_img_stride <= 0) x_img_stride = (long)H * Wd * Cin;
+  MDQE_REQUIRE(x_img_stride % 4 == 0 && x_img_stride >= (long)H * Wd * Cin);
+  const long ab = ((long)(NI - 1) * x_img_stride + (long)H * Wd * Cin) * 4, wb = (long)Cout * KH * KW * Cin * 4;
   MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L && (long)NI * OH * OW < 0x7FFFFFFFL);
   GemmParams p = {};
   p.A = X; p.W = Wt; p.C = Y; p.M = NI * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.lda = 0; p.ldc = ldy;
   p.conv = 1; p.H = H; p.Wd = Wd; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
-  p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = 0; p.rowmask = nullptr; p.mask_cols = 0;
+  p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = 0; p.res_first = res_first; p.img_stride = x_img_stride; p.rowmask = nullptr; p.mask_cols = 0;
   p.act = act; p.act_cols = 0; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
   mdqe_clear_error();
   return dispatch_gemm(p, tile, (hipStream_t)stream);

@@ -80,7 +80,7 @@ extern "C" int mdqe_layernorm_f32(const float* x, const float* res, const float*
 #define GN_MAX_CHUNKS 64
 
 __global__ void __launch_bounds__(256)
-gn_partial_kernel(const float* __restrict__ x, long ldx, int HW, int C, int G, int nchunks, double* __restrict__ part) {
+gn_partial_kernel(const float* __restrict__ x, long ldx, long xis, int HW, int C, int G, int nchunks, double* __restrict__ part) {
   __shared__ float sh_s[1024], sh_q[1024];      // [rsub][channel] partial sums of the block's threads
   __shared__ double ch_s[1024], ch_q[1024];     // per channel
   const int img = blockIdx.y, chunk = blockIdx.x;
@@ -91,7 +91,7 @@ gn_partial_kernel(const float* __restrict__ x, long ldx, int HW, int C, int G, i
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (rsub < tpr) {
-    const float* base = x + (long)img * HW * ldx + col * 4;
+    const float* base = x + (long)img * xis + col * 4;
     for (int p = p0 + rsub; p < p1; p += tpr) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)p * ldx);
 #pragma unroll
@@ -117,7 +117,7 @@ gn_partial_kernel(const float* __restrict__ x, long ldx, int HW, int C, int G, i
 }
 
 __global__ void __launch_bounds__(256)
-gn_apply_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, int HW, int C, int G, int nchunks,
+gn_apply_kernel(const float* __restrict__ x, long ldx, long xis, float* __restrict__ y, long ldy, long yis, int HW, int C, int G, int nchunks,
                 const double* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
                 float eps, int act) {
   __shared__ float s_mean[64], s_rstd[64];
@@ -141,7 +141,7 @@ gn_apply_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, lo
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int col = (int)(i % c4n);
     const long p = i / c4n;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)img * HW + p) * ldx + col * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)img * xis + p * ldx + col * 4);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col * 4);
     const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col * 4);
     f32x4 o;
@@ -150,17 +150,21 @@ gn_apply_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, lo
       const int gi = (col * 4 + k) / cpg;
       o[k] = mdqe_act((v[k] - s_mean[gi]) * s_rstd[gi] * g[k] + b[k], act);
     }
-    *reinterpret_cast<f32x4*>(y + ((long)img * HW + p) * ldy + col * 4) = o;
+    *reinterpret_cast<f32x4*>(y + (long)img * yis + p * ldy + col * 4) = o;
   }
 }
 
 extern "C" long mdqe_groupnorm_workspace_bytes(int NI, int G) { return (long)NI * GN_MAX_CHUNKS * G * 2 * sizeof(double); }
 
-extern "C" int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, float* y, long ldy, int NI, int HW, int C, int G,
+extern "C" int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, long x_img_stride, float* y, long ldy, long y_img_stride,
+                                       int NI, int HW, int C, int G,
                                        const float* gamma, const float* beta, float eps, int act, void* workspace,
                                        void* stream) {
   MDQE_REQUIRE(NI >= 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0 && C % 4 == 0 && C <= 1024);
   MDQE_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0);
+  if (x_img_stride <= 0) x_img_stride = (long)HW * ldx;
+  if (y_img_stride <= 0) y_img_stride = (long)HW * ldy;
+  MDQE_REQUIRE(x_img_stride % 4 == 0 && y_img_stride % 4 == 0);
   if (NI == 0) return MDQE_OK;
   MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(y); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta); MDQE_CHECK_PTR(workspace);
   mdqe_clear_error();
@@ -168,12 +172,12 @@ extern "C" int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, float* y, long 
   int nchunks = (HW + 255) / 256;
   if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
   if (nchunks < 1) nchunks = 1;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, NI), dim3(256), 0, st, x, ldx, HW, C, G, nchunks, (double*)workspace);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, NI), dim3(256), 0, st, x, ldx, x_img_stride, HW, C, G, nchunks, (double*)workspace);
   int rc = mdqe_launch_status();
   if (rc) return rc;
   long blocks = ((long)HW * (C / 4) + 255) / 256;
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, NI), dim3(256), 0, st, x, ldx, y, ldy, HW, C, G, nchunks,
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, NI), dim3(256), 0, st, x, ldx, x_img_stride, y, ldy, y_img_stride, HW, C, G, nchunks,
                      (const double*)workspace, gamma, beta, eps, act);
   return mdqe_launch_status();
 }

@@ -1,0 +1,537 @@
+"""Execution engine of the MDQE eval path on one MI355X.
+
+MI355X-first organisation (not the reference's module graph):
+  * activations are channels-last everywhere (tokens [frames, N, C]; images NHWC) so every dense
+    op is one NT GEMM / implicit-GEMM on the matrix cores with a fused epilogue;
+  * per-frame work (backbone -> input_proj -> encoder -> mask head -> query-init features ->
+    decoder value projections) runs ONCE per frame in large batches and is cached; the reference
+    recomputes a 30-frame window for every clip (mdqe/mdqe.py:302,314);
+  * input-independent tensors (padding masks, sine position embedding, W*pos tables, reference
+    points) are built once per resolution;
+  * per-clip work = query association + 6 decoder layers + heads + dynamic mask product.
+
+Each method cites the reference code whose arithmetic it reproduces.  Arithmetic on O(N*C) data
+runs in libmdqe_hip.so (ops.*); `torch.*` calls below act on <=196-row index/score tensors
+(host-side control the reference also does in Python) unless tagged INTERIM-TORCH, which marks
+device-side torch math still to be replaced by HIP kernels (tracked in DESIGN.md).
+"""
+import math
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .config import MDQEConfig
+from .params import ALIASES, RESNET_BLOCKS, msda_dir_grid
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing
+# ------------------------------------------------------------------------------------------------
+def _fold_bn(sd, p, eps=1e-5):
+    """FrozenBatchNorm (detectron2): y = x*scale + shift folded into the conv: returns (w*scale, shift)."""
+    scale = sd[p + ".norm.weight"] * (sd[p + ".norm.running_var"] + eps).rsqrt()
+    shift = sd[p + ".norm.bias"] - sd[p + ".norm.running_mean"] * scale
+    return sd[p + ".weight"] * scale.view(-1, 1, 1, 1), shift
+
+
+def _krsc(w):
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+class Packed:
+    """Device-resident weights in kernel layouts, built from a reference-named state dict."""
+
+    def __init__(self, sd, cfg: MDQEConfig, device):
+        self.cfg = cfg
+        dev = torch.device(device)
+        sd = {k: v.detach().float().cpu() for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
+        for k in list(sd):                       # aliased duplicates of the reference checkpoint
+            for a, b in ALIASES.items():
+                if k.startswith(a) and (b + k[len(a):]) not in sd:
+                    sd[b + k[len(a):]] = sd[k]
+        up = lambda t: t.contiguous().to(dev)
+        C, nh = cfg.hidden_dim, cfg.nheads
+        self.dev = dev
+
+        # ---- backbone (a4) -----------------------------------------------------------------------
+        self.bb = None
+        if cfg.backbone in RESNET_BLOCKS:
+            bp = "detr.backbone.0.backbone"
+            bb = NS()
+            w, b = _fold_bn(sd, bp + ".stem.conv1")
+            wp = torch.zeros(64, 160)
+            wp[:, :147] = _krsc(w).reshape(64, 147)
+            bb.stem_w, bb.stem_b = up(wp), up(b)
+            bb.stages = []
+            for si, nb in enumerate(RESNET_BLOCKS[cfg.backbone]):
+                blocks = []
+                for bi in range(nb):
+                    q = f"{bp}.res{si + 2}.{bi}"
+                    blk = NS(stride=2 if (bi == 0 and si > 0) else 1, shortcut=None)
+                    if (q + ".shortcut.weight") in sd:
+                        w, b = _fold_bn(sd, q + ".shortcut")
+                        blk.shortcut = (up(_krsc(w)), up(b))
+                    for cn in ("conv1", "conv2", "conv3"):
+                        w, b = _fold_bn(sd, f"{q}.{cn}")
+                        setattr(blk, cn, (up(_krsc(w)), up(b)))
+                    blocks.append(blk)
+                bb.stages.append(blocks)
+            self.bb = bb
+
+        # ---- input_proj (a6) ---------------------------------------------------------------------
+        self.inproj = []
+        for l in range(cfg.n_levels):
+            w = sd[f"detr.input_proj.{l}.0.weight"]
+            self.inproj.append(NS(w=up(_krsc(w)), k=w.shape[-1], b=up(sd[f"detr.input_proj.{l}.0.bias"]),
+                                  g=up(sd[f"detr.input_proj.{l}.1.weight"]), beta=up(sd[f"detr.input_proj.{l}.1.bias"])))
+
+        # ---- encoder (a7, a8) --------------------------------------------------------------------
+        e = "detr.transformer_enc"
+        self.level_embed = sd[e + ".level_embed"]                      # CPU: used to build the pos tables
+        self.enc = []
+        for i in range(cfg.enc_layers):
+            q = f"{e}.encoder.layers.{i}"
+            a = q + ".self_attn"
+            wcat = torch.cat([sd[a + ".value_proj.weight"], sd[a + ".sampling_offsets.weight"],
+                              sd[a + ".attention_weights.weight"]], 0)
+            bcat = torch.cat([sd[a + ".value_proj.bias"], sd[a + ".sampling_offsets.bias"], sd[a + ".attention_weights.bias"]])
+            wq = torch.cat([sd[a + ".sampling_offsets.weight"], sd[a + ".attention_weights.weight"]], 0)
+            self.enc.append(NS(wcat=up(wcat), bcat=up(bcat), wq=up(wq),
+                               wo=up(sd[a + ".output_proj.weight"]), bo=up(sd[a + ".output_proj.bias"]),
+                               n1=(up(sd[q + ".norm1.weight"]), up(sd[q + ".norm1.bias"])),
+                               w1=up(sd[q + ".linear1.weight"]), b1=up(sd[q + ".linear1.bias"]),
+                               w2=up(sd[q + ".linear2.weight"]), b2=up(sd[q + ".linear2.bias"]),
+                               n2=(up(sd[q + ".norm2.weight"]), up(sd[q + ".norm2.bias"]))))
+        self.enc_norm = (up(sd[e + ".encoder.norm.weight"]), up(sd[e + ".encoder.norm.bias"]))
+
+        # ---- mask head (a10) ---------------------------------------------------------------------
+        h = "detr.transformer_dec.mask_head"
+        mh = NS()
+        for i in (1, 2, 3):
+            setattr(mh, f"lay{i}", (up(_krsc(sd[f"{h}.lay{i}.weight"])), up(sd[f"{h}.lay{i}.bias"])))
+            setattr(mh, f"gn{i}", (up(sd[f"{h}.gn{i}.weight"]), up(sd[f"{h}.gn{i}.bias"])))
+        for i in (1, 2):
+            setattr(mh, f"ad{i}", (up(_krsc(sd[f"{h}.adapter{i}.weight"])), up(sd[f"{h}.adapter{i}.bias"])))
+        for name in ("out_lay1", "out_lay2"):
+            dw = sd[f"{h}.{name}.depthwise.weight"]
+            setattr(mh, name, NS(dw=up(dw.view(dw.shape[0], 25).t()), db=up(sd[f"{h}.{name}.depthwise.bias"]),
+                                 pw=up(sd[f"{h}.{name}.pointwise.weight"].flatten(1)), pb=up(sd[f"{h}.{name}.pointwise.bias"]),
+                                 g=up(sd[f"{h}.{name}.gn.weight"]), beta=up(sd[f"{h}.{name}.gn.bias"])))
+        mh.tw, mh.tb = up(sd[h + ".out_uplay.weight"].flatten()), up(sd[h + ".out_uplay.bias"])
+        self.mh = mh
+
+        # ---- decoder (a11-a14) -------------------------------------------------------------------
+        d = "detr.transformer_dec"
+        mlp = lambda name, n=3: [(up(sd[f"{d}.{name}.layers.{i}.weight"]), up(sd[f"{d}.{name}.layers.{i}.bias"])) for i in range(n)]
+        self.rpn_cls, self.cls_embed, self.track_embed = mlp("rpn_cls_embed"), mlp("cls_embed"), mlp("track_embed")
+        self.mask_embed, self.bbox_embed = mlp("mask_embed"), mlp("bbox_embed")
+        self.dec_norm = (up(sd[d + ".decoder_norm.weight"]), up(sd[d + ".decoder_norm.bias"]))
+        w = torch.zeros(C, 4)
+        w[:, :2] = sd[d + ".point2pos_proj.weight"]                     # boxes[..., :2] @ W^T == boxes @ [W|0]^T
+        self.p2p = (up(w), up(sd[d + ".point2pos_proj.bias"]))
+        self.dec = []
+        vw, vb = [], []
+        for i in range(cfg.dec_layers):
+            q = f"{d}.decoder.layers.{i}"
+            L = NS()
+            for tag, mod in (("sa", "self_attn"), ("sai", "self_attn_inst")):
+                Wi, bi = sd[f"{q}.{mod}.in_proj_weight"], sd[f"{q}.{mod}.in_proj_bias"]
+                setattr(L, tag, NS(wqk=up(Wi[:2 * C]), bqk=up(bi[:2 * C]), wv=up(Wi[2 * C:]), bv=up(bi[2 * C:]),
+                                   wo=up(sd[f"{q}.{mod}.out_proj.weight"]), bo=up(sd[f"{q}.{mod}.out_proj.bias"])))
+            for tag, mod in (("ca", "cross_attn"), ("ta", "temp_attn_inst")):
+                if not (q + f".{mod}.value_proj.weight") in sd:
+                    setattr(L, tag, None)
+                    continue
+                wq = torch.cat([sd[f"{q}.{mod}.sampling_grid_offsets.weight"], sd[f"{q}.{mod}.attention_weights.weight"]], 0)
+                bq = torch.cat([sd[f"{q}.{mod}.sampling_grid_offsets.bias"], sd[f"{q}.{mod}.attention_weights.bias"]])
+                setattr(L, tag, NS(wq=up(wq), bq=up(bq), n_off=sd[f"{q}.{mod}.sampling_grid_offsets.weight"].shape[0],
+                                   wo=up(sd[f"{q}.{mod}.output_proj.weight"]), bo=up(sd[f"{q}.{mod}.output_proj.bias"])))
+                vw.append(sd[f"{q}.{mod}.value_proj.weight"])
+                vb.append(sd[f"{q}.{mod}.value_proj.bias"])
+            for nm in ("norm1", "norm2", "norm3", "norm1_inst", "norm2_inst", "norm3_inst"):
+                setattr(L, nm, (up(sd[f"{q}.{nm}.weight"]), up(sd[f"{q}.{nm}.bias"])))
+            for nm in ("linear1", "linear2", "linear1_inst", "linear2_inst", "time_weights"):
+                setattr(L, nm, (up(sd[f"{q}.{nm}.weight"]), up(sd[f"{q}.{nm}.bias"])))
+            self.dec.append(L)
+        self.dec_vw, self.dec_vb = up(torch.cat(vw, 0)), up(torch.cat(vb))   # all decoder value_proj's stacked
+        self.n_val = len(vw)
+        self.grid_sp = up(msda_dir_grid(nh, cfg.n_levels, cfg.dec_points))
+        self.grid_tp = up(msda_dir_grid(nh, cfg.n_frames, cfg.dec_points))
+        nb = cfg.n_bins
+        ii, jj = torch.meshgrid(torch.arange(nb), torch.arange(nb), indexing="ij")
+        ind = torch.stack([jj, ii], -1).view(-1, 2)
+        self.relpos = (ind[:, None] - ind[None]).abs().to(dev)          # transformer_dec.py:61-64
+
+
+# ------------------------------------------------------------------------------------------------
+# per-resolution constants
+# ------------------------------------------------------------------------------------------------
+def _pos_sine(mask, npf, temperature=10000.0):
+    """PositionEmbeddingSine (mdqe/models/position_encoding.py:28-48) on CPU; mask [H,W] bool -> [H*W, 2*npf]."""
+    nm = ~mask[None]
+    y = nm.cumsum(1, dtype=torch.float32)
+    x = nm.cumsum(2, dtype=torch.float32)
+    y = y / (y[:, -1:, :] + 1e-6) * (2 * math.pi)
+    x = x / (x[:, :, -1:] + 1e-6) * (2 * math.pi)
+    d = torch.arange(npf, dtype=torch.float32)
+    d = temperature ** (2 * torch.div(d, 2, rounding_mode="trunc") / npf)
+    px, py = x[..., None] / d, y[..., None] / d
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), 4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), 4).flatten(3)
+    return torch.cat((py, px), 3)[0].reshape(-1, 2 * npf)
+
+
+class Geometry:
+    """Everything that depends only on the (h, w) of the frames (a2, a3, a5 and the encoder's
+    reference points): padded size, level shapes, padding masks, position tables."""
+
+    def __init__(self, P: Packed, h, w):
+        cfg, dev = P.cfg, P.dev
+        d = cfg.size_divisibility
+        self.h, self.w = h, w
+        self.Hp, self.Wp = (h + d - 1) // d * d, (w + d - 1) // d * d
+        shapes, masks = [], []
+        for s in cfg.backbone_strides:                                   # MaskedBackbone.mask_out_padding, mdqe/mdqe.py:44-57
+            H, W = self.Hp // s, self.Wp // s
+            m = torch.ones(H, W, dtype=torch.bool)
+            m[: int(np.ceil(float(h) / s)), : int(np.ceil(float(w) / s))] = False
+            shapes.append((H, W))
+            masks.append(m)
+        for l in range(len(shapes), cfg.n_levels):                       # extra 3x3/s2 levels, models/mdqe.py:88-93
+            H, W = (shapes[-1][0] + 2 - 3) // 2 + 1, (shapes[-1][1] + 2 - 3) // 2 + 1
+            m = F.interpolate(masks[len(cfg.backbone_strides) - 1][None, None].float(), size=(H, W)).to(torch.bool)[0, 0]
+            shapes.append((H, W))
+            masks.append(m)
+        self.shapes = shapes
+        self.hw = [a * b for a, b in shapes]
+        self.starts = [0] + list(np.cumsum(self.hw)[:-1])
+        self.N = int(sum(self.hw))
+        self.mask_flat = torch.cat([m.flatten() for m in masks]).to(dev)             # [N] bool
+        self.any_pad = bool(self.mask_flat.any())
+        npf = cfg.hidden_dim // 2
+        pos = torch.cat([_pos_sine(m, npf) + P.level_embed[l].view(1, -1) for l, m in enumerate(masks)], 0)   # [N,C]
+        ref = torch.cat([self._ref_points(H, W) for H, W in shapes], 0)              # transformer_enc.py:48-49
+        self.ref = ref.contiguous().to(dev)
+        pos_d = pos.contiguous().to(dev)
+        nq = P.enc[0].wq.shape[0] if P.enc else 0
+        C = cfg.hidden_dim
+        self.pos_tables = []
+        for lyr in P.enc:                                                # (pos+lvl) @ [Woff;Wattn]^T, constant per resolution
+            t = torch.zeros(self.N, C + nq, device=dev)
+            ops.linear(pos_d, lyr.wq, None, out=t[:, C:], ldc=C + nq)
+            self.pos_tables.append(t)
+        self._masks_rep = {}
+
+    @staticmethod
+    def _ref_points(H, W):
+        """make_reference_points, mdqe/models/misc.py:21-29."""
+        ry, rx = torch.meshgrid(torch.linspace(0.5, H - 0.5, H), torch.linspace(0.5, W - 0.5, W), indexing="ij")
+        return torch.stack((rx.reshape(-1) / max(W, 1), ry.reshape(-1) / max(H, 1)), -1)
+
+    def rowmask(self, n):
+        """uint8 [n*N] padding mask for n frames (None when nothing is padded)."""
+        if not self.any_pad:
+            return None
+        if n not in self._masks_rep:
+            self._masks_rep[n] = self.mask_flat.view(torch.uint8).repeat(n).contiguous()
+        return self._masks_rep[n]
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """mdqe/util/misc.py:478-482."""
+    x = x.clamp(0, 1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def box_cxcywh_to_xyxy(b):
+    cx, cy, w, h = b.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+
+
+def box_xyxy_to_cxcywh(b):
+    x0, y0, x1, y1 = b.unbind(-1)
+    return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], -1)
+
+
+class Engine:
+    def __init__(self, cfg: MDQEConfig, state_dict, device="cuda", backbone_fn=None):
+        self.cfg = cfg
+        self.P = Packed(state_dict, cfg, device)
+        self.dev = self.P.dev
+        self.backbone_fn = backbone_fn           # optional callable(frames [NI,3,h,w], geo) -> list of NHWC feats
+        self._geo = {}
+
+    def geometry(self, h, w) -> Geometry:
+        k = (h, w)
+        if k not in self._geo:
+            self._geo[k] = Geometry(self.P, h, w)
+        return self._geo[k]
+
+    # ---- a1, a2, a4: normalise + pad + ResNet ------------------------------------------------------
+    def backbone(self, frames, geo):
+        """frames [NI,3,h,w] uint8/fp32 CUDA -> [res3,res4,res5] NHWC.  ResNet-50 as built by detectron2
+        (STRIDE_IN_1X1 False, FrozenBN folded; configs/R50_coco.yaml:7-10)."""
+        if self.backbone_fn is not None:
+            return self.backbone_fn(frames, geo)
+        bb, cfg = self.P.bb, self.cfg
+        NI = frames.shape[0]
+        col = ops.stem_im2col(frames, geo.Hp, geo.Wp, cfg.pixel_mean, cfg.pixel_std)
+        x = ops.linear(col, bb.stem_w, bb.stem_b, act="relu").view(NI, geo.Hp // 2, geo.Wp // 2, 64)
+        del col
+        x = ops.maxpool3x3s2(x)
+        outs = []
+        for si, blocks in enumerate(bb.stages):
+            for blk in blocks:
+                s = blk.stride
+                sc = x if blk.shortcut is None else self._conv(x, blk.shortcut, 1, s, 0, None)
+                y = self._conv(x, blk.conv1, 1, 1, 0, "relu")
+                y = self._conv(y, blk.conv2, 3, s, 1, "relu")
+                x = self._conv(y, blk.conv3, 1, 1, 0, "relu", residual=sc)
+            if si >= 1:
+                outs.append(x)
+        return outs
+
+    @staticmethod
+    def _conv(x, wb, k, stride, pad, act, residual=None):
+        w, b = wb
+        if k == 1 and stride == 1 and x.is_contiguous():
+            NI, H, W, Cin = x.shape
+            r = residual.view(-1, residual.shape[-1]) if residual is not None else None
+            return ops.linear(x.view(-1, Cin), w.view(w.shape[0], Cin), b, act=act, residual=r, res_first=True).view(NI, H, W, -1)
+        return ops.conv2d_nhwc(x, w, b, stride, pad, act=act, residual=residual, res_first=True)
+
+    # ---- a6, a7, a8: input_proj + deformable encoder ----------------------------------------------
+    def encode(self, feats, geo):
+        """models/mdqe.py:79-105 + transformer_enc.py:30-59,100-110,121-136 -> tokens [NI, N, C]."""
+        P, cfg = self.P, self.cfg
+        NI, C, N = feats[0].shape[0], cfg.hidden_dim, geo.N
+        x = torch.empty(NI, N, C, device=self.dev)
+        src = None
+        for l in range(cfg.n_levels):
+            ip = P.inproj[l]
+            if l < len(feats):
+                f = feats[l]
+                y = ops.linear(f.reshape(-1, f.shape[-1]), ip.w.view(C, -1), ip.b)
+            else:
+                src = feats[-1] if l == len(feats) else src
+                y = ops.conv2d_nhwc(src, ip.w, ip.b, 2, 1)
+                src = None                      # deeper extra levels would chain on the normalised output
+            s0, hw = geo.starts[l], geo.hw[l]
+            ops.groupnorm_nhwc(y.view(NI, hw, C), 32, ip.g, ip.beta, out=x[:, s0:s0 + hw])
+        M, nh = NI * N, cfg.nheads
+        D = C // nh
+        LP = cfg.n_levels * cfg.enc_points
+        levels = ([s[0] for s in geo.shapes], [s[1] for s in geo.shapes], geo.starts)
+        rowmask = geo.rowmask(NI)
+        x2 = x.view(M, C)
+        nq = 3 * nh * LP
+        proj = torch.empty(M, C + nq, device=self.dev)
+        attn = torch.empty(M, C, device=self.dev)
+        hid = torch.empty(M, cfg.d_ffn, device=self.dev)
+        y = torch.empty(M, C, device=self.dev)
+        for li, lyr in enumerate(P.enc):
+            # value | offsets | logits in ONE GEMM; (pos+lvl)@W comes from the per-resolution table
+            ops.linear(x2, lyr.wcat, lyr.bcat, residual=geo.pos_tables[li], res_mod=N, rowmask=rowmask, mask_cols=C, out=proj)
+            ops.msda_fused(proj[:, :C], proj[:, C:C + 2 * nh * LP], proj[:, C + 2 * nh * LP:], geo.ref, levels, NI, N, nh, D,
+                           cfg.n_levels, cfg.enc_points, mode=0, v_brows=N, out=attn)
+            ops.linear(attn, lyr.wo, lyr.bo, residual=x2, out=y)
+            ops.layernorm(y, *lyr.n1, out=x2)
+            ops.linear(x2, lyr.w1, lyr.b1, act="gelu", out=hid)
+            ops.linear(hid, lyr.w2, lyr.b2, residual=x2, out=y)
+            ops.layernorm(y, *lyr.n2, out=x2)
+        return ops.layernorm(x2, *P.enc_norm).view(NI, N, C)
+
+    # ---- a10: mask-feature head -------------------------------------------------------------------
+    def mask_features(self, enc, geo):
+        """models/mdqe.py:107-117 + segmentation.py:42-63 -> [NI, Hm, Wm, M] (channels-last)."""
+        mh, cfg = self.P.mh, self.cfg
+        NI, N, C = enc.shape
+        lv = [enc[:, geo.starts[l]:geo.starts[l] + geo.hw[l]].view(NI, geo.shapes[l][0], geo.shapes[l][1], C) for l in range(3)]
+        x = ops.conv2d_nhwc(lv[2], *mh.lay1, 1, 1)
+        x = ops.groupnorm_nhwc(x, 8, *mh.gn1, act="gelu", out=x).view(x.shape)
+        for i, f in ((2, lv[1]), (3, lv[0])):
+            cur = ops.conv2d_nhwc(f, *getattr(mh, f"ad{i - 1}"), 1, 0)
+            x = ops.upsample_nearest_add(cur, x, out=cur)
+            x = ops.conv2d_nhwc(x, *getattr(mh, f"lay{i}"), 1, 1)
+            x = ops.groupnorm_nhwc(x, 8, *getattr(mh, f"gn{i}"), act="gelu", out=x).view(x.shape)
+        o1, o2 = mh.out_lay1, mh.out_lay2
+        y = ops.dwconv5x5(x, o1.dw, o1.db)
+        y = ops.linear(y.view(-1, C), o1.pw, o1.pb).view(x.shape)
+        y = ops.groupnorm_nhwc(y, 32, o1.g, o1.beta, act="relu", out=y).view(x.shape)
+        z = ops.dwconv5x5(y, o2.dw, o2.db, up2=True, tw=mh.tw, tb=mh.tb)
+        Md = o2.pw.shape[0]
+        z2 = ops.linear(z.view(-1, C), o2.pw, o2.pb).view(NI, z.shape[1], z.shape[2], Md)
+        return ops.groupnorm_nhwc(z2, 32 if Md % 32 == 0 else 24, o2.g, o2.beta, act="relu", out=z2).view(z2.shape)
+
+    # ---- a11 (per-frame part): grid-guided query selection + content sampling ---------------------
+    def _mlp(self, x, layers, last_act=None):
+        n = len(layers)
+        for i, (w, b) in enumerate(layers):
+            x = ops.linear(x, w, b, act="gelu" if i < n - 1 else last_act)
+        return x
+
+    def frame_queries(self, enc, geo):
+        """transformer_dec.py:81-109,156-182 (everything before inter-frame association is per frame)."""
+        cfg = self.cfg
+        NI, N, C = enc.shape
+        H, W = geo.shapes[0]
+        nb = cfg.n_bins
+        conf = self._mlp(enc[:, :H * W].reshape(-1, C), self.P.rpn_cls).view(NI, H, W, -1)
+        # INTERIM-TORCH: score map resize + per-cell argmax + grid_sample (small maps, to become one HIP kernel)
+        s = conf.sigmoid().max(-1)[0].unsqueeze(1)
+        H_up, W_up = (2 * H // nb + 1) * nb, (2 * W // nb + 1) * nb
+        s = F.interpolate(s, size=(H_up, W_up), mode="bilinear")
+        r, t = H_up // nb, W_up // nb
+        sel = s.view(NI, nb, r, nb, t).permute(0, 1, 3, 2, 4).reshape(NI, nb * nb, r * t).argmax(-1)
+        gy = torch.arange(nb, device=self.dev).view(1, nb, 1).expand(NI, nb, nb).reshape(NI, -1)
+        gx = torch.arange(nb, device=self.dev).view(1, 1, nb).expand(NI, nb, nb).reshape(NI, -1)
+        idx = (gy * r + torch.div(sel, t, rounding_mode="floor")) * W_up + gx * t + sel % t
+        coords = torch.stack([torch.fmod(idx, W_up) / W_up, (idx / W_up) / H_up], -1)      # true division, :105-106
+        grid = 2 * coords.view(NI, nb, nb, 2) - 1
+        acc = None
+        for l, (Hl, Wl) in enumerate(geo.shapes):
+            f = enc[:, geo.starts[l]:geo.starts[l] + Hl * Wl].transpose(1, 2).reshape(NI, C, Hl, Wl)
+            g = F.grid_sample(f, grid, mode="bilinear", padding_mode="border", align_corners=False)
+            acc = g if acc is None else acc + g
+        content = (acc / len(geo.shapes)).flatten(2).transpose(1, 2).contiguous()           # [NI,Q,C]
+        emb = self._mlp(content.view(-1, C), self.P.track_embed).view(NI, nb * nb, -1)
+        return coords, content, emb
+
+    def dec_values(self, enc, geo):
+        """All decoder value_proj's (cross_attn + temp_attn_inst of every layer) for each frame, once:
+        value = masked_fill(Linear(x)) (ms_deform_attn.py:136-139,193-196) -> [NI, N, n_val*C]."""
+        NI, N, C = enc.shape
+        return ops.linear(enc.view(-1, C), self.P.dec_vw, self.P.dec_vb, rowmask=geo.rowmask(NI),
+                          mask_cols=self.P.dec_vw.shape[0]).view(NI, N, -1)
+
+    # ---- a11 (association) + a12-a14: decoder over one clip ---------------------------------------
+    def _mha(self, sa, qk_in, v_in, nh):
+        """nn.MultiheadAttention, q = k = x+pos, v = x, eval (transformer_dec.py:348-353,397-402)."""
+        B, Q, C = qk_in.shape
+        qk = ops.linear(qk_in.reshape(-1, C), sa.wqk, sa.bqk).view(B, Q, 2, nh, C // nh)
+        v = ops.linear(v_in.reshape(-1, C), sa.wv, sa.bv).view(B, Q, nh, C // nh)
+        # INTERIM-TORCH: 196x196 attention core (to become one fused HIP kernel)
+        q, k = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)
+        a = torch.softmax((q / math.sqrt(C // nh)) @ k.transpose(-1, -2), -1)
+        o = (a @ v.transpose(1, 2)).transpose(1, 2).reshape(B * Q, C)
+        return o, sa
+
+    def _clip_box(self, boxes, t0, t1):
+        """Circumscribed clip box, transformer_dec.py:473-480."""
+        b = box_cxcywh_to_xyxy(boxes.transpose(0, 1)[None][:, :, t0:t1]).clamp(0, 1)
+        b = torch.cat([b[..., :2].min(-2)[0], b[..., 2:].max(-2)[0]], -1)
+        return box_xyxy_to_cxcywh(b)[0].contiguous()                                      # [Q,4]
+
+    def decode_clip(self, coords, content, emb, values, geo):
+        """coords [T,Q,2], content [T,Q,C], emb [T,Q,E], values [T,N,n_val*C] (contiguous frames of one clip)."""
+        P, cfg = self.P, self.cfg
+        T, Q, C = content.shape
+        nh, N = cfg.nheads, geo.N
+        D, Tc = C // nh, cfg.n_frames
+        ct = int((T - 1) / 2)
+        # inter-frame query association (transformer_dec.py:111-145), eval window = w/2
+        if T > 1:
+            sim = torch.einsum("tqc,kc->tqk", emb, emb[ct])
+            wdw = cfg.window_inter_frame_asso / 2
+            itv = (torch.arange(T, device=self.dev) - ct).abs().view(T, 1, 1)
+            m = (P.relpos[None].float() > (wdw * itv)[..., None]).any(-1)
+            idx = sim.masked_fill(m, float("-inf")).softmax(-2).argmax(-2)                  # [T,K]
+            ar = torch.arange(T, device=self.dev)[:, None]
+            content, coords = content[ar, idx], coords[ar, idx]
+        x = content.reshape(T * Q, C).contiguous()
+        ref = torch.cat([coords, torch.full_like(coords, 0.1)], -1).reshape(T * Q, 4)
+        x_inst = x.view(T, Q, C)[ct].contiguous()                                           # [Q,C]
+        bbox = lambda z: self._mlp(ops.layernorm(z, *P.dec_norm), P.bbox_embed)
+        boxes = (bbox(x) + inverse_sigmoid(ref)).sigmoid().contiguous()
+        x_pos = ops.linear(boxes, *P.p2p)
+        t0, t1 = max(ct - int((Tc - 1) / 2), 0), ct + Tc
+        ibox = self._clip_box(boxes.view(T, Q, 4), t0, t1)
+        ipos = ops.linear(ibox, *P.p2p)
+        itv = max(int(T / Tc), 1)
+        ts = max(ct - int((Tc - 1) / 2) * itv, 0)
+        tca = list(range(ts, T, itv))[:Tc]
+        tca = tca + [tca[-1]] * (Tc - len(tca))                                             # repeat last frame (:382-386)
+        lv_sp = ([s[0] for s in geo.shapes], [s[1] for s in geo.shapes], geo.starts)
+        lv_tp = ([s[0] for s in geo.shapes for _ in range(Tc)], [s[1] for s in geo.shapes for _ in range(Tc)],
+                 [f * N + geo.starts[g] for g in range(len(geo.shapes)) for f in tca])
+        LP = cfg.n_levels * cfg.dec_points
+        TP = Tc * cfg.dec_points
+        vals2 = values.view(T * N, -1)
+        vi = 0
+        for L in P.dec:
+            # ---- box level: CA -> SA -> FFN (transformer_dec.py:415-422)
+            pr = ops.linear(x + x_pos, L.ca.wq, L.ca.bq)
+            a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * LP], pr[:, 2 * nh * LP:], boxes.view(T, Q, 4), lv_sp,
+                               T, Q, nh, D, cfg.n_levels, cfg.dec_points, mode=1, grid=P.grid_sp, v_brows=N)
+            vi += 1
+            x = ops.layernorm(ops.linear(a, L.ca.wo, L.ca.bo, residual=x), *L.norm2)
+            sx = x
+            o, sa = self._mha(L.sa, (x + x_pos).view(T, Q, C), x.view(T, Q, C), nh)
+            x = ops.layernorm(ops.linear(o, sa.wo, sa.bo, residual=x), *L.norm1)
+            hdn = ops.linear(x, *L.linear1, act="gelu")
+            x = ops.layernorm(ops.linear(hdn, *L.linear2, residual=x), *L.norm3)
+            # ---- instance level (transformer_dec.py:361-409)
+            tw = ops.linear(x, *L.time_weights).view(T, Q, 1)
+            fused = (torch.softmax(tw, 0) * sx.view(T, Q, C)).sum(0)                         # [Q,C]
+            xi2 = fused
+            if L.ta is not None:
+                pr = ops.linear(fused + ipos, L.ta.wq, L.ta.bq)
+                a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * TP], pr[:, 2 * nh * TP:], ibox.view(1, Q, 4), lv_tp,
+                                   1, Q, nh, D, Tc, cfg.dec_points, mode=1, grid=P.grid_tp, groups=len(geo.shapes),
+                                   scale=1.0 / len(geo.shapes), v_brows=T * N)
+                vi += 1
+                xi2 = ops.linear(a, L.ta.wo, L.ta.bo)
+            x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=xi2.contiguous())
+            o, sa = self._mha(L.sai, (x_inst + ipos).view(1, Q, C), x_inst.view(1, Q, C), nh)
+            x_inst = ops.layernorm(ops.linear(o, sa.wo, sa.bo, residual=x_inst), *L.norm1_inst)
+            hdn = ops.linear(x_inst, *L.linear1_inst, act="gelu")
+            x_inst = ops.layernorm(ops.linear(hdn, *L.linear2_inst, residual=x_inst), *L.norm3_inst)
+            # ---- iterative box refinement (transformer_dec.py:492-503)
+            boxes = (bbox(x) + inverse_sigmoid(boxes)).sigmoid().contiguous()
+            x_pos = ops.linear(boxes, *P.p2p)
+            ibox = self._clip_box(boxes.view(T, Q, 4), t0, t1)
+            ipos = ops.linear(ibox, *P.p2p)
+        n = ops.layernorm(x_inst, *P.dec_norm)
+        return {"cls": self._mlp(n, P.cls_embed, "sigmoid"), "mask_coeff": self._mlp(n, P.mask_embed, "tanh"),
+                "query_embed": x_inst}
+
+    # ---- a15: inference_clip (mdqe/mdqe.py:368-428) ------------------------------------------------
+    def inference_clip(self, out, mask_feats):
+        """mask_feats [T,Hm,Wm,M] channels-last (contiguous).  Returns dict like the reference's Instances."""
+        cfg = self.cfg
+        cls, coef, emb = out["cls"], out["mask_coeff"], out["query_embed"]
+        thr = cfg.apply_cls_thres
+        ss, si = cls.max(-1)[0].sort(descending=True)
+        valid = si[ss >= min(thr, float(ss[0]))]
+        if valid.numel() > 1:
+            e = F.normalize(emb[valid], dim=-1)
+            ms = torch.triu(e @ e.t(), diagonal=1).max(0)[0]
+            valid = valid[ms < 0.99][:10 * cfg.detections_per_image]
+        cls, coef, emb = cls[valid], coef[valid].contiguous(), emb[valid]
+        T, Hm, Wm, Md = mask_feats.shape
+        # dynamic mask product einsum('qm,mthw->qthw') (:384) as an NT GEMM: rows = instances, "weights" = pixels
+        mp = ops.linear(coef, mask_feats.view(-1, Md)).view(-1, T, Hm, Wm)
+        # INTERIM-TORCH below: reductions over the mask logits (to be fused into the mask kernel)
+        nb = mp.gt(0.).flatten(1).sum(1) > 0
+        cls, mp, emb = cls[nb], mp[nb], emb[nb]
+        if cls.numel() > 0:
+            mn = mp[:, ::2] if mp.shape[1] >= 5 else mp
+            soft = F.interpolate(mn, scale_factor=0.5).flatten(1).sigmoid()
+            hard = soft.gt(0.5).float()
+            num = soft @ hard.t()
+            den = soft.sum(-1)[:, None] + hard.sum(-1)[None] - num
+            mi = torch.triu(num / (den + 1), diagonal=1).max(0)[0]
+            cls = cls * (1 - mi[:, None])
+            k = mi < 0.5
+            cls, mp, emb = cls[k], mp[k], emb[k]
+        soft = mp.sigmoid().flatten(1)
+        hard = soft.gt(0.5).float()
+        cls = cls * ((soft * hard).sum(1) / (hard.sum(1) + 1e-6))[:, None]
+        sc, lab = cls.max(-1)
+        order = sc.sort(descending=True)[1]
+        n = max(int((sc > thr).sum()), 1)
+        t = order[:n]
+        return {"scores": sc[t], "pred_classes": lab[t], "cls_probs": cls[t], "pred_masks": mp[t], "query_embeds": emb[t]}

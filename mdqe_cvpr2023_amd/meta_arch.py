@@ -1,0 +1,189 @@
+"""MDQE meta-architecture: the drop-in for the reference's `MDQE` (mdqe/mdqe.py:60-471) on the
+eval-only VIS path.
+
+    model = MDQE(cfg)                      # cfg: the reference's CfgNode, or an MDQEConfig
+    model.load_state_dict(ckpt["model"])   # reference checkpoint names (prefix `detr.`)
+    out = model([{"image": [uint8 [3,h,w], ...], "height": H, "width": W}])
+    # -> {"image_size", "pred_scores", "pred_labels", "pred_masks": [BoolTensor[L,H,W] (CPU)]}
+
+Same call contract and output dict as MDQE.forward -> inference_vis -> inference_video.  When
+detectron2 is importable the class is registered in its META_ARCH_REGISTRY under the name "MDQE".
+Training and the COCO single-image branch are out of scope and raise.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import MDQEConfig, from_d2_cfg
+from .engine import Engine
+from .params import ALIASES, full_manifest, random_state
+from .tracking import Clips, OverTracker
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, nn.Module())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+def aligned_bilinear(t, factor):
+    """mdqe/util/misc.py:485-507.  INTERIM-TORCH (HBM-bound upsample; to be fused with sigmoid/crop/threshold)."""
+    if factor == 1:
+        return t
+    h, w = t.shape[-2:]
+    t = F.pad(t, pad=(0, 1, 0, 1), mode="replicate")
+    oh, ow = factor * h + 1, factor * w + 1
+    t = F.interpolate(t, size=(oh, ow), mode="bilinear", align_corners=True)
+    t = F.pad(t, pad=(factor // 2, 0, factor // 2, 0), mode="replicate")
+    return t[:, :, :oh - 1, :ow - 1]
+
+
+class MDQE(nn.Module):
+    def __init__(self, cfg, state_dict=None, backbone_fn=None, seed=0):
+        super().__init__()
+        self.cfg = cfg if isinstance(cfg, MDQEConfig) else from_d2_cfg(cfg)
+        self.device = torch.device(self.cfg.device)
+        self._backbone_fn = backbone_fn
+        self._engine = None
+        sd = state_dict if state_dict is not None else random_state(self.cfg, seed)
+        man = full_manifest(self.cfg)
+        for name, shape in man.items():
+            t = sd[name] if name in sd else torch.zeros(shape)
+            _register(self, name, t.detach().clone().float(), buffer=name.endswith(("running_mean", "running_var")))
+        self._extra = {k: v for k, v in sd.items() if k not in man}      # e.g. custom-backbone weights
+        self.frame_batch = self.cfg.n_frames_window_test
+        self.stage_times = None
+
+    # ---- checkpoint contract ---------------------------------------------------------------------
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # accept (and drop) the reference checkpoint's aliased / non-eval keys
+        for k in list(state_dict):
+            kk = k[len(prefix):]
+            if any(kk.startswith(a) for a in ALIASES) or kk.endswith((".sampling_offsets", "lvl_spatial_scales",
+                                                                      "query_relpos_grid", "num_batches_tracked")) \
+                    or kk.startswith("criterion."):
+                if not (kk.endswith(".sampling_offsets.weight") or kk.endswith(".sampling_offsets.bias")):
+                    state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        self._engine = None
+
+    def train(self, mode=True):
+        if mode:
+            raise RuntimeError("mdqe_cvpr2023_amd.MDQE implements the eval-only path (SURVEY.md §8); training is out of scope")
+        return super().train(False)
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            sd = OrderedDict((k, v) for k, v in self.state_dict().items())
+            sd.update(self._extra)
+            self._engine = Engine(self.cfg, sd, self.device, backbone_fn=self._backbone_fn)
+        return self._engine
+
+    # ---- forward (mdqe/mdqe.py:194-242) ------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        if len(batched_inputs) != 1:
+            raise RuntimeError("MDQE eval takes exactly one video per call (mdqe/mdqe.py:292)")
+        with torch.autocast(device_type="cuda", enabled=False):           # neutralise ambient autocast
+            return self.inference_vis(batched_inputs)
+
+    def _frame_cache(self, frames, geo):
+        """Per-frame stages a1-a11 for a batch of frames: everything a clip needs, computed once."""
+        eng = self.engine
+        feats = eng.backbone(frames, geo)
+        enc = eng.encode(feats, geo)
+        del feats
+        mf = eng.mask_features(enc, geo)
+        coords, content, emb = eng.frame_queries(enc, geo)
+        vals = eng.dec_values(enc, geo)
+        return {"mf": mf, "coords": coords, "content": content, "emb": emb, "vals": vals}
+
+    def inference_vis(self, batched_inputs, trace=None):
+        """mdqe/mdqe.py:291-366 with the compute-once schedule (same clips, same flush points)."""
+        cfg, eng = self.cfg, self.engine
+        video = batched_inputs[0]
+        imgs = video["image"]
+        L = len(imgs)
+        h, w = int(imgs[0].shape[-2]), int(imgs[0].shape[-1])
+        ori_h, ori_w = video.get("height", h), video.get("width", w)
+        geo = eng.geometry(h, w)
+        stack = imgs if torch.is_tensor(imgs) else torch.stack(list(imgs))
+        if stack.dtype not in (torch.uint8, torch.float32):
+            stack = stack.float()
+        frames_dev = stack.to(self.device, non_blocking=True).contiguous()
+        T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
+        merge_dev = torch.device("cpu") if cfg.merge_on_cpu else self.device
+
+        cache, base, nxt = None, 0, 0            # cache covers frames [base, base + len)
+        saved, last, tracker = 0, False, None
+        cls_clips, mask_clips = [], []
+        for start in range(0, L, stride):
+            end = start + T
+            if end > L:
+                last, end = True, L
+            while nxt < end:                     # extend the frame cache up to the clip's last frame
+                c1 = min(L, nxt + self.frame_batch)
+                new = self._frame_cache(frames_dev[nxt:c1], geo)
+                if cache is None:
+                    cache, base = new, nxt
+                else:
+                    keep = start - base           # frames before `start` are never needed again
+                    cache = {k: torch.cat([v[keep:], new[k]], 0) for k, v in cache.items()}
+                    base = start
+                nxt = c1
+            a, b = start - base, end - base
+            out = eng.decode_clip(cache["coords"][a:b], cache["content"][a:b], cache["emb"][a:b], cache["vals"][a:b], geo)
+            res = eng.inference_clip(out, cache["mf"][a:b])
+            if trace is not None:
+                trace.append({k: v.clone() for k, v in res.items()})
+            if merge_dev.type == "cpu":
+                res = {k: v.cpu() for k, v in res.items()}
+            if tracker is None:
+                tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
+                                      cache["mf"].shape[1:3], merge_dev, cfg.apply_cls_thres)
+            tracker.update(Clips(range(start, end), res))
+            if last or (start + stride >= win * (saved + 1)):
+                c, m = tracker.get_result(is_last_clip=last)
+                m = aligned_bilinear(m, cfg.match_stride).sigmoid()[..., :h, :w]
+                cls_clips.append(c)
+                mask_clips.append(m)
+                saved += 1
+            if last:
+                break
+        return self.inference_video((ori_h, ori_w), cls_clips, mask_clips)
+
+    def inference_video(self, image_size, cls_clips, mask_clips):
+        """mdqe/mdqe.py:430-471."""
+        K = self.cfg.num_classes
+        total = cls_clips[-1].shape[0]
+        cc = torch.stack([torch.cat([c, c.new_zeros(total - c.shape[0], c.shape[1])]) for c in cls_clips])
+        out_cls = (0.75 * cc.mean(0) + 0.25 * cc.max(0)[0]).flatten().cpu()
+        k = max(int(out_cls.gt(0.05).sum()), 10)
+        sc, ti = out_cls.topk(k, sorted=False)
+        labels = (ti % K).tolist()
+        inst = torch.div(ti, K, rounding_mode="floor").tolist()
+        masks, done = [], {}
+        for i in inst:
+            if i not in done:
+                vid = torch.cat([m[i] if i < m.shape[0] else torch.zeros_like(m[0]) for m in mask_clips], 0)
+                r = F.interpolate(vid.unsqueeze(0), size=tuple(image_size), mode="nearest").squeeze(0) > 0.5
+                done[i] = r.cpu()
+            masks.append(done[i])
+        return {"image_size": tuple(image_size), "pred_scores": sc.tolist(), "pred_labels": labels, "pred_masks": masks}
+
+
+try:                                              # drop-in registration when detectron2 is present
+    from detectron2.modeling import META_ARCH_REGISTRY
+    META_ARCH_REGISTRY.register(MDQE)
+except Exception:                                 # detectron2 absent in this image: d2-free entry only
+    pass

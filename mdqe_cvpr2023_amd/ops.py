@@ -30,7 +30,7 @@ def _chk(t, name, dtype=torch.float32):
 
 
 def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=None, mask_cols=0, act_cols=0,
-           out=None, ldc=None, tile=0):
+           out=None, ldc=None, tile=0, res_first=False):
     """out[..., n] = epilogue(x[..., :] @ weight[n, :]).  x may be a 2-D row-strided view (last dim contiguous)."""
     K = x.shape[-1]
     N = weight.shape[0]
@@ -54,16 +54,20 @@ def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=Non
     if residual is not None:
         ldr = residual.stride(0) if residual.dim() == 2 else residual.shape[-1]
     check(lib.mdqe_gemm_nt_f32(ptr(x2), lda, ptr(weight), ptr(bias), ptr(out), ldc_, M, N, K, ACT[act], act_cols,
-                               ptr(residual), ldr, res_mod, ptr(rowmask), mask_cols, tile, cur_stream()), "gemm_nt_f32")
+                               ptr(residual), ldr, res_mod, int(res_first), ptr(rowmask), mask_cols, tile, cur_stream()), "gemm_nt_f32")
     if x.dim() != 2 and ldc is None and out.dim() == 2 and out.shape == (M, N):
         return out.view(*x.shape[:-1], N)
     return out
 
 
-def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None, out=None, tile=0):
-    """x [NI,H,W,Cin]; w_packed [Cout,KH,KW,Cin]; returns [NI,OH,OW,Cout]."""
-    _chk(x, "x"); _chk(w_packed, "w"); _chk(bias, "bias"); _chk(residual, "residual")
+def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None, out=None, tile=0, res_first=False):
+    """x [NI,H,W,Cin] (dense, or a view whose images are x.stride(0) apart with dense pixels);
+    w_packed [Cout,KH,KW,Cin]; returns [NI,OH,OW,Cout]."""
+    _chk(w_packed, "w"); _chk(bias, "bias"); _chk(residual, "residual")
     NI, H, W, Cin = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and x.stride(3) == 1 and x.stride(2) == Cin and x.stride(1) == W * Cin):
+        raise RuntimeError("conv2d_nhwc: x must be CUDA fp32 NHWC with dense pixels")
+    xis = x.stride(0) if NI > 1 else 0
     Cout, KH, KW, _ = w_packed.shape
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
@@ -71,8 +75,8 @@ def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None
         out = torch.empty((NI, OH, OW, Cout), dtype=torch.float32, device=x.device)
     ldy = out.stride(-2)
     ldr = residual.stride(-2) if residual is not None else 0
-    check(lib.mdqe_conv2d_nhwc_f32(ptr(x), ptr(w_packed), ptr(bias), ptr(out), ldy, NI, H, W, Cin, Cout, KH, KW, stride,
-                                   pad, ACT[act], ptr(residual), ldr, tile, cur_stream()), "conv2d_nhwc_f32")
+    check(lib.mdqe_conv2d_nhwc_f32(ptr(x), xis, ptr(w_packed), ptr(bias), ptr(out), ldy, NI, H, W, Cin, Cout, KH, KW, stride,
+                                   pad, ACT[act], ptr(residual), ldr, int(res_first), tile, cur_stream()), "conv2d_nhwc_f32")
     return out
 
 
@@ -87,13 +91,18 @@ def layernorm(x, gamma, beta, res=None, eps=1e-5, out=None):
 
 
 def groupnorm_nhwc(x, groups, gamma, beta, act=None, eps=1e-5, out=None):
-    """x [NI, ..., C] (NHWC, pixel stride = x.stride(-2)); in-place allowed (out=x)."""
-    NI, C = x.shape[0], x.shape[-1]
-    HW = x.numel() // (NI * C)
+    """x [NI, HW, C] (pixel stride x.stride(1), image stride x.stride(0)); `out` may be a strided view
+    (e.g. a level slice of the encoder token buffer) or x itself (in place)."""
+    if x.dim() == 4:
+        x = x.view(x.shape[0], -1, x.shape[-1])
+    NI, HW, C = x.shape
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty((NI, HW, C), dtype=torch.float32, device=x.device)
+    elif out.dim() == 4:
+        out = out.view(NI, HW, C)
     ws = _workspace(lib.mdqe_groupnorm_workspace_bytes(NI, groups), x.device)
-    check(lib.mdqe_groupnorm_nhwc_f32(ptr(x), x.stride(-2), ptr(out), out.stride(-2), NI, HW, C, groups, ptr(gamma),
+    check(lib.mdqe_groupnorm_nhwc_f32(ptr(x), x.stride(1), x.stride(0) if NI > 1 else 0, ptr(out), out.stride(1),
+                                      out.stride(0) if NI > 1 else 0, NI, HW, C, groups, ptr(gamma),
                                       ptr(beta), eps, ACT[act], ptr(ws), cur_stream()), "groupnorm_nhwc")
     return out
 
@@ -149,4 +158,29 @@ def msda(value, shapes_dev, starts_dev, loc, attn, groups=1, scale=1.0, out=None
         out = torch.empty((B, Q, M * D), dtype=torch.float32, device=value.device)
     check(lib.mdqe_msda_forward_grouped_f32(ptr(value), ptr(shapes_dev), ptr(starts_dev), ptr(loc), ptr(attn), B, S, M, D,
                                             groups, L, Q, P, scale, ptr(out), cur_stream()), "msda")
+    return out
+
+
+def msda_fused(value, offs, logits, ref, levels, B, Q, M, D, L, P, mode=0, grid=None, groups=1, scale=1.0,
+               v_brows=None, out=None):
+    """Fused MSDeformAttn core.  value/offs/logits: 2-D row-strided fp32 views (last dim contiguous):
+    value [B*v_brows, M*D], offs [B*Q, M*L*P*2], logits [B*Q, M*L*P].  ref: [Q,2|4] (broadcast) or [B,Q,2|4].
+    levels: (H list, W list, start-row list) of length groups*L."""
+    import ctypes
+    Hs, Ws, Ss = levels
+    n = groups * L
+    assert len(Hs) == n and len(Ws) == n and len(Ss) == n
+    if ref.dim() == 2:
+        ref_b, ref_dim = 0, ref.shape[-1]
+    else:
+        ref_b, ref_dim = ref.stride(0), ref.shape[-1]
+    _chk(ref, "ref")
+    if out is None:
+        out = torch.empty((B * Q, M * D), dtype=torch.float32, device=value.device)
+    arr = lambda v: (ctypes.c_int * n)(*[int(x) for x in v])
+    if v_brows is None:
+        v_brows = value.shape[0] // max(B, 1)
+    check(lib.mdqe_msda_fused_f32(ptr(value), value.stride(0), v_brows, ptr(offs), offs.stride(0), ptr(logits),
+                                  logits.stride(0), ptr(ref), ref_b, ref_dim, mode, ptr(grid), arr(Hs), arr(Ws), arr(Ss),
+                                  B, M, D, groups, L, Q, P, scale, ptr(out), out.stride(0), cur_stream()), "msda_fused")
     return out
