@@ -108,59 +108,88 @@ class MDQE(nn.Module):
         vals = eng.dec_values(enc, geo)
         return {"mf": mf, "coords": coords, "content": content, "emb": emb, "vals": vals}
 
-    def inference_vis(self, batched_inputs, trace=None):
-        """mdqe/mdqe.py:291-366 with the compute-once schedule (same clips, same flush points)."""
-        cfg, eng = self.cfg, self.engine
-        video = batched_inputs[0]
-        imgs = video["image"]
-        L = len(imgs)
-        h, w = int(imgs[0].shape[-2]), int(imgs[0].shape[-1])
-        ori_h, ori_w = video.get("height", h), video.get("width", w)
-        geo = eng.geometry(h, w)
-        stack = imgs if torch.is_tensor(imgs) else torch.stack(list(imgs))
-        if stack.dtype not in (torch.uint8, torch.float32):
-            stack = stack.float()
-        frames_dev = stack.to(self.device, non_blocking=True).contiguous()
-        T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
-        merge_dev = torch.device("cpu") if cfg.merge_on_cpu else self.device
-
-        cache, base, nxt = None, 0, 0            # cache covers frames [base, base + len)
-        saved, last, tracker = 0, False, None
-        cls_clips, mask_clips = [], []
+    @staticmethod
+    def clip_schedule(L, T, stride):
+        """Clip list of mdqe/mdqe.py:308-312: (start, end, is_last); the loop ends at the first clip that
+        reaches past the video (it is clamped and may be shorter than T)."""
+        clips = []
         for start in range(0, L, stride):
             end = start + T
-            if end > L:
-                last, end = True, L
-            while nxt < end:                     # extend the frame cache up to the clip's last frame
-                c1 = min(L, nxt + self.frame_batch)
+            last = end > L
+            clips.append((start, min(end, L), last))
+            if last:
+                break
+        return clips
+
+    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None):
+        """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
+        `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res)."""
+        eng = self.engine
+        h, w = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
+        geo = eng.geometry(h, w)
+        n_local = frames_dev.shape[0]
+        cache, base, nxt = None, 0, 0            # cache covers local frames [base, base + len)
+        for (start, end, last) in clips:
+            ls, le = start - frame_offset, end - frame_offset
+            while nxt < le:                      # extend the frame cache up to the clip's last frame
+                c1 = min(n_local, nxt + self.frame_batch)
                 new = self._frame_cache(frames_dev[nxt:c1], geo)
                 if cache is None:
                     cache, base = new, nxt
                 else:
-                    keep = start - base           # frames before `start` are never needed again
+                    keep = ls - base              # frames before the clip start are never needed again
                     cache = {k: torch.cat([v[keep:], new[k]], 0) for k, v in cache.items()}
-                    base = start
+                    base = ls
                 nxt = c1
-            a, b = start - base, end - base
+            a, b = ls - base, le - base
             out = eng.decode_clip(cache["coords"][a:b], cache["content"][a:b], cache["emb"][a:b], cache["vals"][a:b], geo)
             res = eng.inference_clip(out, cache["mf"][a:b])
             if trace is not None:
                 trace.append({k: v.clone() for k, v in res.items()})
+            yield start, end, last, res
+
+    def merge_clips(self, results, frame_hw, out_size, mask_hw):
+        """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""
+        cfg = self.cfg
+        T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
+        merge_dev = torch.device("cpu") if cfg.merge_on_cpu else self.device
+        saved, tracker = 0, None
+        cls_clips, mask_clips = [], []
+        for start, end, last, res in results:
             if merge_dev.type == "cpu":
                 res = {k: v.cpu() for k, v in res.items()}
             if tracker is None:
                 tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
-                                      cache["mf"].shape[1:3], merge_dev, cfg.apply_cls_thres)
+                                      mask_hw, merge_dev, cfg.apply_cls_thres)
             tracker.update(Clips(range(start, end), res))
             if last or (start + stride >= win * (saved + 1)):
                 c, m = tracker.get_result(is_last_clip=last)
-                m = aligned_bilinear(m, cfg.match_stride).sigmoid()[..., :h, :w]
+                m = aligned_bilinear(m, cfg.match_stride).sigmoid()[..., :frame_hw[0], :frame_hw[1]]
                 cls_clips.append(c)
                 mask_clips.append(m)
                 saved += 1
             if last:
                 break
-        return self.inference_video((ori_h, ori_w), cls_clips, mask_clips)
+        return self.inference_video(out_size, cls_clips, mask_clips)
+
+    def to_device_frames(self, imgs):
+        stack = imgs if torch.is_tensor(imgs) else torch.stack(list(imgs))
+        if stack.dtype not in (torch.uint8, torch.float32):
+            stack = stack.float()
+        return stack.to(self.device, non_blocking=True).contiguous()
+
+    def inference_vis(self, batched_inputs, trace=None):
+        """mdqe/mdqe.py:291-366 with the compute-once schedule (same clips, same flush points)."""
+        cfg = self.cfg
+        video = batched_inputs[0]
+        frames_dev = self.to_device_frames(video["image"])
+        L, h, w = frames_dev.shape[0], int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
+        out_size = (video.get("height", h), video.get("width", w))
+        geo = self.engine.geometry(h, w)
+        ms = cfg.match_stride
+        clips = self.clip_schedule(L, cfg.n_frames_test, cfg.clip_stride)
+        return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace), (h, w), out_size,
+                                (geo.Hp // ms, geo.Wp // ms))
 
     def inference_video(self, image_size, cls_clips, mask_clips):
         """mdqe/mdqe.py:430-471."""

@@ -1,0 +1,110 @@
+"""Multi-GPU: one long video sharded across ranks.
+
+Frames are independent through the per-frame stages and clips are independent through the decoder and
+inference_clip, so rank r owns the clips that START in its contiguous frame range and holds those
+frames plus a (T-1)-frame halo; there is no collective on that path.  The single exchange step is one
+variable-length all-gather (RCCL over xGMI; `gloo` in the CPU tests) of the per-clip tracker inputs,
+padded to the global maximum instance count; every rank then replays the tracker in global clip
+order, which is bit-identical to the single-GPU schedule.
+"""
+import torch
+
+FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
+
+
+def owned_range(L, world, rank):
+    """Frames whose clips this rank owns: [a, b)."""
+    per = (L + world - 1) // world
+    return min(L, rank * per), min(L, (rank + 1) * per)
+
+
+def frame_range(L, world, rank, T, stride=1):
+    """Frames this rank must hold: owned range + halo so every owned clip is complete."""
+    a, b = owned_range(L, world, rank)
+    return a, min(L, b + T - 1)
+
+
+def owned_clips(clips, L, world, rank):
+    a, b = owned_range(L, world, rank)
+    return [c for c in clips if a <= c[0] < b]
+
+
+def pack(results, T, device):
+    """list of (start,end,last,res) -> dict of padded tensors [n_clips, n_max, ...] + meta [n_clips,4]."""
+    n = len(results)
+    nmax = max([len(r[3]["scores"]) for r in results], default=0)
+    meta = torch.tensor([[s, e, int(l), len(r["scores"])] for s, e, l, r in results], dtype=torch.int64, device=device).view(n, 4)
+    out = {"meta": meta}
+    for f in FIELDS:
+        if n == 0:
+            out[f] = None
+            continue
+        proto = results[0][3][f]
+        shape = list(proto.shape[1:])
+        if f == "pred_masks":
+            shape[0] = T                                   # the short last clip is padded in time
+        buf = torch.zeros([n, nmax] + shape, dtype=proto.dtype, device=device)
+        for i, (_, _, _, r) in enumerate(results):
+            t = r[f]
+            if f == "pred_masks":
+                buf[i, :t.shape[0], :t.shape[1]] = t
+            else:
+                buf[i, :t.shape[0]] = t
+        out[f] = buf
+    return out, nmax
+
+
+def all_gather_clips(local, T, dist, world, device, proto_shapes):
+    """Variable-length all-gather: sizes first, then payloads padded to the global maxima."""
+    packed, nmax = pack(local, T, device)
+    sizes = torch.tensor([len(local), nmax], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    cmax = int(max(int(s[0]) for s in all_sizes))
+    gmax = int(max(int(s[1]) for s in all_sizes))
+    merged = []
+    gathered = {}
+    meta = torch.zeros(cmax, 4, dtype=torch.int64, device=device)
+    meta[:len(local)] = packed["meta"]
+    bufs = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(bufs, meta)
+    gathered["meta"] = bufs
+    for f in FIELDS:
+        shape, dtype = proto_shapes[f]
+        buf = torch.zeros([cmax, gmax] + list(shape), dtype=dtype, device=device)
+        if packed[f] is not None and packed[f].numel() > 0:
+            buf[:packed[f].shape[0], :packed[f].shape[1]] = packed[f]
+        outs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        gathered[f] = outs
+    for r in range(world):
+        nclips = int(all_sizes[r][0])
+        m = gathered["meta"][r].cpu()
+        for i in range(nclips):
+            s, e, l, n = [int(v) for v in m[i]]
+            res = {}
+            for f in FIELDS:
+                t = gathered[f][r][i, :n]
+                if f == "pred_masks":
+                    t = t[:, :e - s]
+                res[f] = t
+            merged.append((s, e, bool(l), res))
+    merged.sort(key=lambda c: c[0])
+    return merged
+
+
+def run_sharded(model, shard_frames, f0, L, rank, world, dist, out_size):
+    """shard_frames: device tensor of this rank's frames, first one is global frame f0."""
+    cfg = model.cfg
+    T = cfg.n_frames_test
+    h, w = int(shard_frames.shape[-2]), int(shard_frames.shape[-1])
+    geo = model.engine.geometry(h, w)
+    ms = cfg.match_stride
+    mask_hw = (geo.Hp // ms, geo.Wp // ms)
+    clips = model.clip_schedule(L, T, cfg.clip_stride)
+    mine = owned_clips(clips, L, world, rank)
+    local = list(model.iter_clip_results(shard_frames, mine, f0))
+    proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
+             "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((T,) + tuple(mask_hw), torch.float32)}
+    merged = all_gather_clips(local, T, dist, world, shard_frames.device, proto)
+    return model.merge_clips(iter(merged), (h, w), out_size, mask_hw)

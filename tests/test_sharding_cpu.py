@@ -1,0 +1,97 @@
+"""CPU, world_size 2 over gloo: sharded clip production + variable-length all-gather + tracker replay must
+equal the single-process schedule (the N>1 path of bench.py / SURVEY.md §8e)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from mdqe_cvpr2023_amd import sharding
+from mdqe_cvpr2023_amd.config import MDQEConfig
+from mdqe_cvpr2023_amd.tracking import Clips, OverTracker
+
+CFG = MDQEConfig(backbone="custom", n_frames_test=3, n_frames_window_test=4, num_classes=5, hidden_dim=32, n_max_inst=16,
+                 apply_cls_thres=0.1)
+HW = (6, 8)
+L = 13
+
+
+def clip_schedule(L, T, stride):
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    return MDQE.clip_schedule(L, T, stride)
+
+
+def fake_result(start, end):
+    """Deterministic per-clip 'inference_clip' output keyed by the clip start (3 persistent objects)."""
+    g = torch.Generator().manual_seed(1000 + start)
+    n = 2 + start % 2
+    base = torch.eye(CFG.hidden_dim)[:3] * 4
+    emb = base[:n] + 0.05 * torch.randn(n, CFG.hidden_dim, generator=g)
+    masks = torch.full((n, end - start) + HW, -3.0)
+    for i in range(n):
+        masks[i, :, i * 2:i * 2 + 2, :] = 3.0
+    cls = torch.rand(n, CFG.num_classes, generator=g) * 0.3
+    cls[torch.arange(n), torch.arange(n)] = 0.8
+    sc, lab = cls.max(-1)
+    return {"scores": sc, "pred_classes": lab, "cls_probs": cls, "query_embeds": emb, "pred_masks": masks}
+
+
+def replay(results):
+    trk = OverTracker(CFG.n_max_inst, CFG.n_frames_test, CFG.n_frames_window_test, 1, CFG.num_classes, 4, CFG.hidden_dim, HW,
+                      torch.device("cpu"), CFG.apply_cls_thres)
+    outs, saved = [], 0
+    for s, e, last, r in results:
+        trk.update(Clips(range(s, e), r))
+        if last or (s + 1 >= CFG.n_frames_window_test * (saved + 1)):
+            c, m = trk.get_result(last)
+            outs.append((c.clone(), m.clone()))
+            saved += 1
+    return outs
+
+
+def worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = CFG.n_frames_test
+    clips = clip_schedule(L, T, 1)
+    mine = sharding.owned_clips(clips, L, world, rank)
+    f0, f1 = sharding.frame_range(L, world, rank, T)
+    assert all(f0 <= s and e <= f1 for s, e, _ in mine)            # halo covers every owned clip
+    local = [(s, e, l, fake_result(s, e)) for s, e, l in mine]
+    proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((CFG.num_classes,), torch.float32),
+             "query_embeds": ((CFG.hidden_dim,), torch.float32), "pred_masks": ((T,) + HW, torch.float32)}
+    merged = sharding.all_gather_clips(local, T, dist, world, torch.device("cpu"), proto)
+    outs = replay(merged)
+    q.put((rank, [(s, e, l) for s, e, l, _ in merged], outs))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_equals_single_process():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    clips = clip_schedule(L, CFG.n_frames_test, 1)
+    ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clips])
+    for rank, order, outs in got:
+        assert order == clips
+        assert len(outs) == len(ref)
+        for (c, m), (cr, mr) in zip(outs, ref):
+            assert torch.equal(c, cr) and torch.equal(m, mr)
+
+
+def test_ranges_cover_all_clips_once():
+    for L_, world in ((13, 2), (120, 8), (7, 4), (4, 8), (240, 3)):
+        clips = clip_schedule(L_, 4, 1)
+        seen = []
+        for r in range(world):
+            seen += sharding.owned_clips(clips, L_, world, r)
+        assert sorted(seen) == clips
