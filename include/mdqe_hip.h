@@ -59,12 +59,13 @@ int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* shapes, con
                                   float scale, float* out, void* stream);
 
 /* Fused module core (ops/modules/ms_deform_attn.py:141-170 / 198-235): consumes the projection GEMM's raw
- * outputs.  value rows are ldv floats apart, batch b starts at row b*v_brows; offs row t=(b*Q+q) holds
+ * outputs.  value rows are ldv floats apart, batch b starts at row (vidx ? vidx[b] : b)*v_brows (vidx: device
+ * int32[B], lets a batch of overlapping clips address one per-frame value cache); offs row t=(b*Q+q) holds
  * M*L*P*2 floats, logits row t holds M*L*P.  mode 0 (encoder): loc = ref_xy + off/8.  mode 1 (decoder):
  * loc = ref_xy + (grid*0.5*wh + clamp(off, +-8*wh))/8 with ref = (cx,cy,w,h) and grid [M,L,P,2] (device).
  * ref row = b*ref_bstride + q*ref_dim (ref_bstride 0 broadcasts one table over the batch).
  * Level tables (HOST int[G*L]): H, W, start row.  out row t, ldout floats apart; out = scale * sum_g(...). */
-int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const float* offs, long ldo,
+int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* vidx, const float* offs, long ldo,
                         const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
                         int mode, const float* grid, const int* lvH_host, const int* lvW_host,
                         const int* lvStart_host, int B, int M, int D, int G, int L, int Q, int P, float scale,

@@ -17,7 +17,7 @@ struct MsdaLevels { int H[16]; int W[16]; int start[16]; };
 
 template <int L, int P>
 __global__ void __launch_bounds__(256)
-msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows,
+msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows, const int* __restrict__ vidx,
                   const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                   const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode,
                   const float* __restrict__ grid, MsdaLevels lv,
@@ -60,7 +60,8 @@ msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows,
     if (mode == 1) { bw = rp[2]; bh = rp[3]; }
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* vb = value + (long)b * v_brows * ldv + m * D + cv * 4;
+    const long brow = vidx != nullptr ? (long)vidx[b] * v_brows : (long)b * v_brows;
+    const float* vb = value + brow * ldv + m * D + cv * 4;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
@@ -104,7 +105,7 @@ msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows,
   }
 }
 
-extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const float* offs, long ldo,
+extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* vidx, const float* offs, long ldo,
                                    const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
                                    int mode, const float* grid, const int* lvH_host, const int* lvW_host,
                                    const int* lvStart_host, int B, int M, int D, int G, int L, int Q, int P, float scale,
@@ -125,7 +126,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
   if (nb > 256L * 64) nb = 256L * 64;
   hipStream_t st = (hipStream_t)stream;
   mdqe_clear_error();
-#define LAUNCH(LL, PP) hipLaunchKernelGGL((msda_fused_kernel<LL, PP>), dim3((unsigned)nb), dim3(256), 0, st, value, ldv, v_brows, \
+#define LAUNCH(LL, PP) hipLaunchKernelGGL((msda_fused_kernel<LL, PP>), dim3((unsigned)nb), dim3(256), 0, st, value, ldv, v_brows, vidx, \
     offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, D, G, Q, scale, out, ldout, total)
   if (L == 4 && P == 4) LAUNCH(4, 4);
   else if (L == 3 && P == 4) LAUNCH(3, 4);

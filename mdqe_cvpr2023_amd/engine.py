@@ -419,36 +419,50 @@ class Engine:
         o = (a @ v.transpose(1, 2)).transpose(1, 2).reshape(B * Q, C)
         return o, sa
 
-    def _clip_box(self, boxes, t0, t1):
-        """Circumscribed clip box, transformer_dec.py:473-480."""
-        b = box_cxcywh_to_xyxy(boxes.transpose(0, 1)[None][:, :, t0:t1]).clamp(0, 1)
+    @staticmethod
+    def _clip_box(boxes, t0, t1):
+        """Circumscribed clip box, transformer_dec.py:473-480.  boxes [B,T,Q,4] -> [B*Q,4]."""
+        b = box_cxcywh_to_xyxy(boxes.transpose(1, 2)[:, :, t0:t1]).clamp(0, 1)
         b = torch.cat([b[..., :2].min(-2)[0], b[..., 2:].max(-2)[0]], -1)
-        return box_xyxy_to_cxcywh(b)[0].contiguous()                                      # [Q,4]
+        return box_xyxy_to_cxcywh(b).reshape(-1, 4).contiguous()
 
     def decode_clip(self, coords, content, emb, values, geo):
-        """coords [T,Q,2], content [T,Q,C], emb [T,Q,E], values [T,N,n_val*C] (contiguous frames of one clip)."""
+        """One clip: coords [T,Q,2], content [T,Q,C], emb [T,Q,E], values [T,N,n_val*C] (contiguous frames)."""
+        T = content.shape[0]
+        out = self.decode_clips({"coords": coords, "content": content, "emb": emb, "vals": values}, [0], T, geo)
+        return {k: v[0] for k, v in out.items()}
+
+    def decode_clips(self, cache, starts, T, geo):
+        """Decoder for a BATCH of clips that all have T frames (clips are independent through a11-a14).
+        cache: per-frame tensors of one chunk (coords/content/emb/vals, leading dim = frames); starts: first frame
+        (index into the cache) of each clip.  Returns cls [B,Q,K], mask_coeff [B,Q,M], query_embed [B,Q,C]."""
         P, cfg = self.P, self.cfg
-        T, Q, C = content.shape
+        Bc = len(starts)
+        fidx = torch.tensor([[a + t for t in range(T)] for a in starts], device=self.dev)      # [Bc,T]
+        coords, content, emb = cache["coords"][fidx], cache["content"][fidx], cache["emb"][fidx]
+        vals = cache["vals"]
+        Q, C = content.shape[2], content.shape[3]
         nh, N = cfg.nheads, geo.N
         D, Tc = C // nh, cfg.n_frames
         ct = int((T - 1) / 2)
         # inter-frame query association (transformer_dec.py:111-145), eval window = w/2
         if T > 1:
-            sim = torch.einsum("tqc,kc->tqk", emb, emb[ct])
+            sim = torch.einsum("btqc,bkc->btqk", emb, emb[:, ct])
             wdw = cfg.window_inter_frame_asso / 2
             itv = (torch.arange(T, device=self.dev) - ct).abs().view(T, 1, 1)
-            m = (P.relpos[None].float() > (wdw * itv)[..., None]).any(-1)
-            idx = sim.masked_fill(m, float("-inf")).softmax(-2).argmax(-2)                  # [T,K]
-            ar = torch.arange(T, device=self.dev)[:, None]
-            content, coords = content[ar, idx], coords[ar, idx]
-        x = content.reshape(T * Q, C).contiguous()
-        ref = torch.cat([coords, torch.full_like(coords, 0.1)], -1).reshape(T * Q, 4)
-        x_inst = x.view(T, Q, C)[ct].contiguous()                                           # [Q,C]
+            m = (P.relpos[None].float() > (wdw * itv)[..., None]).any(-1)                       # [T,Q,K]
+            idx = sim.masked_fill(m[None], float("-inf")).softmax(-2).argmax(-2)                # [Bc,T,K]
+            content = torch.gather(content, 2, idx[..., None].expand(-1, -1, -1, C))
+            coords = torch.gather(coords, 2, idx[..., None].expand(-1, -1, -1, 2))
+        BT = Bc * T
+        x = content.reshape(BT * Q, C).contiguous()
+        ref = torch.cat([coords, torch.full_like(coords, 0.1)], -1).reshape(BT * Q, 4)
+        x_inst = content[:, ct].reshape(Bc * Q, C).contiguous()
         bbox = lambda z: self._mlp(ops.layernorm(z, *P.dec_norm), P.bbox_embed)
         boxes = (bbox(x) + inverse_sigmoid(ref)).sigmoid().contiguous()
         x_pos = ops.linear(boxes, *P.p2p)
         t0, t1 = max(ct - int((Tc - 1) / 2), 0), ct + Tc
-        ibox = self._clip_box(boxes.view(T, Q, 4), t0, t1)
+        ibox = self._clip_box(boxes.view(Bc, T, Q, 4), t0, t1)
         ipos = ops.linear(ibox, *P.p2p)
         itv = max(int(T / Tc), 1)
         ts = max(ct - int((Tc - 1) / 2) * itv, 0)
@@ -459,79 +473,125 @@ class Engine:
                  [f * N + geo.starts[g] for g in range(len(geo.shapes)) for f in tca])
         LP = cfg.n_levels * cfg.dec_points
         TP = Tc * cfg.dec_points
-        vals2 = values.view(T * N, -1)
+        vals2 = vals.view(-1, vals.shape[-1])
+        vidx_sp = fidx.reshape(-1).to(torch.int32).contiguous()                             # value block of (clip, frame)
+        vidx_tp = fidx[:, 0].to(torch.int32).contiguous()                                   # first frame of each clip
         vi = 0
         for L in P.dec:
             # ---- box level: CA -> SA -> FFN (transformer_dec.py:415-422)
             pr = ops.linear(x + x_pos, L.ca.wq, L.ca.bq)
-            a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * LP], pr[:, 2 * nh * LP:], boxes.view(T, Q, 4), lv_sp,
-                               T, Q, nh, D, cfg.n_levels, cfg.dec_points, mode=1, grid=P.grid_sp, v_brows=N)
+            a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * LP], pr[:, 2 * nh * LP:], boxes.view(BT, Q, 4), lv_sp,
+                               BT, Q, nh, D, cfg.n_levels, cfg.dec_points, mode=1, grid=P.grid_sp, v_brows=N, vidx=vidx_sp)
             vi += 1
             x = ops.layernorm(ops.linear(a, L.ca.wo, L.ca.bo, residual=x), *L.norm2)
             sx = x
-            o, sa = self._mha(L.sa, (x + x_pos).view(T, Q, C), x.view(T, Q, C), nh)
+            o, sa = self._mha(L.sa, (x + x_pos).view(BT, Q, C), x.view(BT, Q, C), nh)
             x = ops.layernorm(ops.linear(o, sa.wo, sa.bo, residual=x), *L.norm1)
             hdn = ops.linear(x, *L.linear1, act="gelu")
             x = ops.layernorm(ops.linear(hdn, *L.linear2, residual=x), *L.norm3)
             # ---- instance level (transformer_dec.py:361-409)
-            tw = ops.linear(x, *L.time_weights).view(T, Q, 1)
-            fused = (torch.softmax(tw, 0) * sx.view(T, Q, C)).sum(0)                         # [Q,C]
+            tw = ops.linear(x, *L.time_weights).view(Bc, T, Q, 1)
+            fused = (torch.softmax(tw, 1) * sx.view(Bc, T, Q, C)).sum(1).reshape(Bc * Q, C)
             xi2 = fused
             if L.ta is not None:
                 pr = ops.linear(fused + ipos, L.ta.wq, L.ta.bq)
-                a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * TP], pr[:, 2 * nh * TP:], ibox.view(1, Q, 4), lv_tp,
-                                   1, Q, nh, D, Tc, cfg.dec_points, mode=1, grid=P.grid_tp, groups=len(geo.shapes),
-                                   scale=1.0 / len(geo.shapes), v_brows=T * N)
+                a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * TP], pr[:, 2 * nh * TP:], ibox.view(Bc, Q, 4), lv_tp,
+                                   Bc, Q, nh, D, Tc, cfg.dec_points, mode=1, grid=P.grid_tp, groups=len(geo.shapes),
+                                   scale=1.0 / len(geo.shapes), v_brows=N, vidx=vidx_tp)
                 vi += 1
                 xi2 = ops.linear(a, L.ta.wo, L.ta.bo)
             x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=xi2.contiguous())
-            o, sa = self._mha(L.sai, (x_inst + ipos).view(1, Q, C), x_inst.view(1, Q, C), nh)
+            o, sa = self._mha(L.sai, (x_inst + ipos).view(Bc, Q, C), x_inst.view(Bc, Q, C), nh)
             x_inst = ops.layernorm(ops.linear(o, sa.wo, sa.bo, residual=x_inst), *L.norm1_inst)
             hdn = ops.linear(x_inst, *L.linear1_inst, act="gelu")
             x_inst = ops.layernorm(ops.linear(hdn, *L.linear2_inst, residual=x_inst), *L.norm3_inst)
             # ---- iterative box refinement (transformer_dec.py:492-503)
             boxes = (bbox(x) + inverse_sigmoid(boxes)).sigmoid().contiguous()
             x_pos = ops.linear(boxes, *P.p2p)
-            ibox = self._clip_box(boxes.view(T, Q, 4), t0, t1)
+            ibox = self._clip_box(boxes.view(Bc, T, Q, 4), t0, t1)
             ipos = ops.linear(ibox, *P.p2p)
         n = ops.layernorm(x_inst, *P.dec_norm)
-        return {"cls": self._mlp(n, P.cls_embed, "sigmoid"), "mask_coeff": self._mlp(n, P.mask_embed, "tanh"),
-                "query_embed": x_inst}
+        return {"cls": self._mlp(n, P.cls_embed, "sigmoid").view(Bc, Q, -1),
+                "mask_coeff": self._mlp(n, P.mask_embed, "tanh").view(Bc, Q, -1),
+                "query_embed": x_inst.view(Bc, Q, C)}
 
-    # ---- a15: inference_clip (mdqe/mdqe.py:368-428) ------------------------------------------------
+    # ---- a15: inference_clip (mdqe/mdqe.py:368-428), batched over clips ---------------------------
     def inference_clip(self, out, mask_feats):
-        """mask_feats [T,Hm,Wm,M] channels-last (contiguous).  Returns dict like the reference's Instances."""
+        """Single clip: out tensors [Q,*]; mask_feats [T,Hm,Wm,M]."""
+        return self.inference_clips({k: v[None] for k, v in out.items()}, [mask_feats])[0]
+
+    def inference_clips(self, outs, mask_feats):
+        """outs: cls [B,Q,K], mask_coeff [B,Q,M], query_embed [B,Q,C]; mask_feats: list of B tensors [T,Hm,Wm,M]
+        (channels-last views of the frame cache).  Same decisions as the reference, computed for the whole batch
+        with masks instead of data-dependent shapes; 2 host syncs per batch."""
         cfg = self.cfg
-        cls, coef, emb = out["cls"], out["mask_coeff"], out["query_embed"]
+        cls, coef, emb = outs["cls"], outs["mask_coeff"], outs["query_embed"]
+        B, Q, K = cls.shape
         thr = cfg.apply_cls_thres
-        ss, si = cls.max(-1)[0].sort(descending=True)
-        valid = si[ss >= min(thr, float(ss[0]))]
-        if valid.numel() > 1:
-            e = F.normalize(emb[valid], dim=-1)
-            ms = torch.triu(e @ e.t(), diagonal=1).max(0)[0]
-            valid = valid[ms < 0.99][:10 * cfg.detections_per_image]
-        cls, coef, emb = cls[valid], coef[valid].contiguous(), emb[valid]
-        T, Hm, Wm, Md = mask_feats.shape
-        # dynamic mask product einsum('qm,mthw->qthw') (:384) as an NT GEMM: rows = instances, "weights" = pixels
-        mp = ops.linear(coef, mask_feats.view(-1, Md)).view(-1, T, Hm, Wm)
-        # INTERIM-TORCH below: reductions over the mask logits (to be fused into the mask kernel)
-        nb = mp.gt(0.).flatten(1).sum(1) > 0
-        cls, mp, emb = cls[nb], mp[nb], emb[nb]
-        if cls.numel() > 0:
-            mn = mp[:, ::2] if mp.shape[1] >= 5 else mp
-            soft = F.interpolate(mn, scale_factor=0.5).flatten(1).sigmoid()
-            hard = soft.gt(0.5).float()
-            num = soft @ hard.t()
-            den = soft.sum(-1)[:, None] + hard.sum(-1)[None] - num
-            mi = torch.triu(num / (den + 1), diagonal=1).max(0)[0]
-            cls = cls * (1 - mi[:, None])
-            k = mi < 0.5
-            cls, mp, emb = cls[k], mp[k], emb[k]
-        soft = mp.sigmoid().flatten(1)
+        # -- score sort + threshold + near-duplicate embedding removal (:373-379)
+        ss, si = cls.max(-1)[0].sort(descending=True, dim=1)
+        keep = ss >= torch.clamp(ss[:, :1], max=thr)
+        e = F.normalize(torch.gather(emb, 1, si[..., None].expand(-1, -1, emb.shape[-1])), dim=-1)
+        sim = torch.bmm(e, e.transpose(1, 2)) * keep[:, :, None]           # rows of dropped queries do not count
+        ms = torch.triu(sim, diagonal=1).max(1)[0]
+        multi = keep.sum(1, keepdim=True) > 1                              # the reference skips this step for <=1 query
+        keep = keep & ((ms < 0.99) | ~multi)
+        keep = keep & (keep.cumsum(1) <= 10 * cfg.detections_per_image)
+        nz = keep.nonzero()                                                # host sync 1: [n_total, 2] (clip, sorted rank)
+        bi, ri = nz[:, 0], nz[:, 1]
+        qi = si[bi, ri]
+        n_tot = int(nz.shape[0])
+        counts = torch.bincount(bi, minlength=B).tolist()
+        cls_k, emb_k = cls[bi, qi], emb[bi, qi]
+        coef_k = coef[bi, qi].contiguous()
+        T, Hm, Wm, Md = mask_feats[0].shape
+        # -- dynamic mask product einsum('qm,mthw->qthw') (:384): NT GEMM per clip, rows = instances, "weights" = pixels
+        mp = torch.empty(n_tot, T, Hm, Wm, device=self.dev)
+        o = 0
+        for b in range(B):
+            if counts[b]:
+                ops.linear(coef_k[o:o + counts[b]], mask_feats[b].reshape(-1, Md), out=mp[o:o + counts[b]].view(counts[b], -1))
+            o += counts[b]
+        # INTERIM-TORCH below: per-row reductions over the mask logits (to be fused into the mask kernel)
+        flat = mp.view(n_tot, -1)
+        pos = flat > 0
+        nonblank = pos.any(1)                                              # (:387)
+        mn = mp[:, ::2] if T >= 5 else mp                                  # (:394-396) nearest x0.5 = even pixels
+        half = mn[:, :, 0:2 * (Hm // 2):2, 0:2 * (Wm // 2):2].reshape(n_tot, -1)
+        soft_h = half.sigmoid()
+        hard_h = soft_h.gt(0.5).float()
+        sh, hh = soft_h.sum(1), hard_h.sum(1)
+        soft = flat.sigmoid()
         hard = soft.gt(0.5).float()
-        cls = cls * ((soft * hard).sum(1) / (hard.sum(1) + 1e-6))[:, None]
-        sc, lab = cls.max(-1)
-        order = sc.sort(descending=True)[1]
-        n = max(int((sc > thr).sum()), 1)
-        t = order[:n]
-        return {"scores": sc[t], "pred_classes": lab[t], "cls_probs": cls[t], "pred_masks": mp[t], "query_embeds": emb[t]}
+        quality = (soft * hard).sum(1) / (hard.sum(1) + 1e-6)              # (:411-413)
+        # -- soft-IoU NMS inside each clip (:398-408), rows in score order, blank rows excluded
+        mi = torch.zeros(n_tot, device=self.dev)
+        o = 0
+        for b in range(B):
+            n = counts[b]
+            if n > 1:
+                nbk = nonblank[o:o + n].float()
+                num = ops.linear((soft_h[o:o + n] * nbk[:, None]).contiguous(), hard_h[o:o + n].contiguous())
+                den = sh[o:o + n, None] + hh[None, o:o + n] - num
+                iou = torch.triu(num / (den + 1), diagonal=1) * nbk[:, None]
+                mi[o:o + n] = iou.max(0)[0]
+            o += n
+        cls_k = cls_k * (1 - mi[:, None])
+        alive = nonblank & (mi < 0.5)
+        cls_k = cls_k * quality[:, None]
+        sc, lab = cls_k.max(-1)
+        # -- final per-clip top-k: max(#(score>thr),1) best alive rows (:416-419)
+        neg = torch.where(alive, sc, torch.full_like(sc, -1.0))
+        host = torch.stack([neg, (alive & (sc > thr)).float()], 1).cpu()   # host sync 2
+        results, o = [], 0
+        for b in range(B):
+            n = counts[b]
+            sneg, above = host[o:o + n, 0], host[o:o + n, 1]
+            n_alive = int((sneg >= 0).sum())
+            order = torch.argsort(sneg, descending=True, stable=True)
+            k = min(max(int(above.sum()), 1), n_alive)
+            t = (order[:k] + o).to(self.dev)
+            results.append({"scores": sc[t], "pred_classes": lab[t], "cls_probs": cls_k[t], "pred_masks": mp[t],
+                            "query_embeds": emb_k[t]})
+            o += n
+        return results

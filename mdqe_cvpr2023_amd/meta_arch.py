@@ -129,8 +129,9 @@ class MDQE(nn.Module):
         geo = eng.geometry(h, w)
         n_local = frames_dev.shape[0]
         cache, base, nxt = None, 0, 0            # cache covers local frames [base, base + len)
-        for (start, end, last) in clips:
-            ls, le = start - frame_offset, end - frame_offset
+        i = 0
+        while i < len(clips):
+            ls, le = clips[i][0] - frame_offset, clips[i][1] - frame_offset
             while nxt < le:                      # extend the frame cache up to the clip's last frame
                 c1 = min(n_local, nxt + self.frame_batch)
                 new = self._frame_cache(frames_dev[nxt:c1], geo)
@@ -141,12 +142,20 @@ class MDQE(nn.Module):
                     cache = {k: torch.cat([v[keep:], new[k]], 0) for k, v in cache.items()}
                     base = ls
                 nxt = c1
-            a, b = ls - base, le - base
-            out = eng.decode_clip(cache["coords"][a:b], cache["content"][a:b], cache["emb"][a:b], cache["vals"][a:b], geo)
-            res = eng.inference_clip(out, cache["mf"][a:b])
-            if trace is not None:
-                trace.append({k: v.clone() for k, v in res.items()})
-            yield start, end, last, res
+            # every further clip of the same length whose frames are already cached joins the batch:
+            # clips are independent through the decoder, so they run as ONE pass (M = clips*T*Q rows)
+            T = le - ls
+            j = i
+            while j < len(clips) and clips[j][1] - frame_offset <= nxt and clips[j][1] - clips[j][0] == T:
+                j += 1
+            group = clips[i:j]
+            outs = eng.decode_clips(cache, [c[0] - frame_offset - base for c in group], T, geo)
+            ress = eng.inference_clips(outs, [cache["mf"][c[0] - frame_offset - base:c[1] - frame_offset - base] for c in group])
+            for (start, end, last), res in zip(group, ress):
+                if trace is not None:
+                    trace.append({k: v.clone() for k, v in res.items()})
+                yield start, end, last, res
+            i = j
 
     def merge_clips(self, results, frame_hw, out_size, mask_hw):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""

@@ -162,7 +162,7 @@ def msda(value, shapes_dev, starts_dev, loc, attn, groups=1, scale=1.0, out=None
 
 
 def msda_fused(value, offs, logits, ref, levels, B, Q, M, D, L, P, mode=0, grid=None, groups=1, scale=1.0,
-               v_brows=None, out=None):
+               v_brows=None, out=None, vidx=None):
     """Fused MSDeformAttn core.  value/offs/logits: 2-D row-strided fp32 views (last dim contiguous):
     value [B*v_brows, M*D], offs [B*Q, M*L*P*2], logits [B*Q, M*L*P].  ref: [Q,2|4] (broadcast) or [B,Q,2|4].
     levels: (H list, W list, start-row list) of length groups*L."""
@@ -180,7 +180,9 @@ def msda_fused(value, offs, logits, ref, levels, B, Q, M, D, L, P, mode=0, grid=
     arr = lambda v: (ctypes.c_int * n)(*[int(x) for x in v])
     if v_brows is None:
         v_brows = value.shape[0] // max(B, 1)
-    check(lib.mdqe_msda_fused_f32(ptr(value), value.stride(0), v_brows, ptr(offs), offs.stride(0), ptr(logits),
+    if vidx is not None and (vidx.dtype != torch.int32 or not vidx.is_cuda or vidx.numel() != B):
+        raise RuntimeError("msda_fused: vidx must be a CUDA int32 tensor with B entries")
+    check(lib.mdqe_msda_fused_f32(ptr(value), value.stride(0), v_brows, ptr(vidx), ptr(offs), offs.stride(0), ptr(logits),
                                   logits.stride(0), ptr(ref), ref_b, ref_dim, mode, ptr(grid), arr(Hs), arr(Ws), arr(Ss),
                                   B, M, D, groups, L, Q, P, scale, ptr(out), out.stride(0), cur_stream()), "msda_fused")
     return out

@@ -1,10 +1,14 @@
-"""Cross-clip tracker: same decisions as the reference's OverTracker
-(mdqe/tracking/OverTracker.py:10-242), state kept on the device.
+"""Cross-clip tracker: the decisions of the reference's OverTracker
+(mdqe/tracking/OverTracker.py:10-242) on a leaner state.
 
-The memory bank [clips, instances, frames, h, w] is allocated once and re-zeroed per window; the
-Hungarian assignment stays on the host (n <= 120) exactly like the reference (scipy, :159).
-INTERIM-TORCH: the soft-IoU / averaging reductions use torch device ops; they are HBM-bound
-reductions scheduled to become HIP kernels."""
+Reference state: saved_logits [clips, instances, frames, h, w] (8 GB at R50_ovis_360, re-zeroed per
+window) that is only ever consumed through sum-over-clips.  Here: a running per-(instance, frame)
+SUM of logits + a count (250 MB), per-clip class/embedding/presence tables (tiny), and the
+host-side bookkeeping (untracked counters, frame sets) on the host.  One device->host transfer per
+update (the Hungarian assignment runs on the host with scipy exactly like the reference, :159).
+Works on CUDA (HIP GEMM for the hard-mask intersections) and on CPU tensors (gloo tests).
+"""
+import numpy as np
 import torch
 from scipy.optimize import linear_sum_assignment
 
@@ -18,6 +22,14 @@ def ctt_similarity(saved, inp):
     if Ns == 1 and Ni == 1:
         return 0.5 * (d2t + t2d)
     return (Ws * d2t + Wi * t2d) / max(Ws + Wi, 1)
+
+
+def _nt(a, b):
+    """a @ b.T for 0/1 fp32 matrices."""
+    if a.is_cuda:
+        from . import ops
+        return ops.linear(a.contiguous(), b.contiguous())
+    return a @ b.t()
 
 
 class Clips:
@@ -49,15 +61,16 @@ class OverTracker:
         self.saved_idx = set()
         self.start_frame = 0
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)
-        self.logits = z(self.num_clips, self.max_inst, self.mem_len, *self.size)
-        self.valid = z(self.num_clips, self.max_inst, self.mem_len, dt=torch.bool)
+        self.sum_logits = z(self.max_inst, self.mem_len, *self.size)       # sum over clips of saved logits
+        self.cnt = z(self.max_inst, self.mem_len)                          # number of clips that wrote (inst, frame)
+        self.clip_valid = z(self.num_clips, self.max_inst, dt=torch.bool)  # instance present in clip slot
         self.cls = z(self.num_clips, self.max_inst, self.K)
         self.embeds = z(self.num_clips, self.max_inst, self.E)
         self._init_memory(True)
         self.n_long = 15 // clip_stride
         self.n_short = max(num_frames, 5) // clip_stride
         self.w_mem = torch.exp(torch.arange(self.n_long, device=device) * 0.25)
-        self.untracked = z(self.max_inst)
+        self.untracked = np.zeros(self.max_inst, dtype=np.float64)         # host-side counters (:45, :77-78)
         self.embed_mem = z(self.max_inst, self.E)
 
     def _init_memory(self, first=False):
@@ -65,36 +78,45 @@ class OverTracker:
         self.start_frame = 0 if first else self.start_frame + self.win
         self.saved_idx.difference_update(range(self.start_frame))
         if not first:
-            self.logits.zero_(); self.valid.zero_(); self.cls.zero_(); self.embeds.zero_()
+            self.sum_logits.zero_(); self.cnt.zero_(); self.clip_valid.zero_(); self.cls.zero_(); self.embeds.zero_()
         self.frame_idx = range(self.start_frame, self.start_frame + self.mem_len)
 
     def _update_memory(self, n_clip, r_idx, c_idx, clip):
+        """OverTracker.py:65-90."""
+        if n_clip >= self.num_clips or (len(r_idx) and max(r_idx) >= self.max_inst):
+            raise IndexError("tracker memory exceeded (MAX_NUM_INSTANCES / clip slots), as the reference would")
         fi = clip.frame_idx
         s0 = max(min(fi) - self.start_frame, 0)
         s1 = max(fi) - self.start_frame
         a, b = fi.index(self.frame_idx[s0]), fi.index(self.frame_idx[s1])
-        self.logits[n_clip, r_idx, s0:s1 + 1] = clip.mask_logits[c_idx, a:b + 1].float()
-        self.valid[n_clip, r_idx, s0:s1 + 1] = True
-        self.cls[n_clip, r_idx] = clip.cls_probs[c_idx]
-        self.embeds[n_clip, r_idx] = clip.query_embeds[c_idx].float()
+        r = torch.as_tensor(r_idx, dtype=torch.long, device=self.device)
+        c = torch.as_tensor(c_idx, dtype=torch.long, device=self.device)
+        if len(r_idx):
+            self.sum_logits[r, s0:s1 + 1] += clip.mask_logits[c, a:b + 1].float()
+            self.cnt[r, s0:s1 + 1] += 1
+            self.clip_valid[n_clip, r] = True
+            self.cls[n_clip, r] = clip.cls_probs[c]
+            self.embeds[n_clip, r] = clip.query_embeds[c].float()
         self.untracked += 1
         self.untracked[r_idx] = 0
+        if not len(r_idx):
+            return
         if n_clip > 0:
             st = max(n_clip - 2, 0)
-            qm = self.embeds[st:n_clip + 1][:, r_idx]
+            qm = self.embeds[st:n_clip + 1][:, r]
             w = self.w_mem[:qm.shape[0]].reshape(-1, 1, 1)
             vm = (qm != 0).any(-1)[..., None]
-            self.embed_mem[r_idx] = (qm * w).sum(0) / (vm * w).sum(0).clamp(min=1)
+            self.embed_mem[r] = (qm * w).sum(0) / (vm * w).sum(0).clamp(min=1)
         else:
-            self.embed_mem[r_idx] = clip.query_embeds[c_idx].float()
+            self.embed_mem[r] = clip.query_embeds[c].float()
 
     @staticmethod
-    def _siou(saved, inp):
-        """hard-mask IoU over overlapping frames, OverTracker.py:92-113 (same arithmetic, GEMM form:
-        |A & B| = A.B^T on 0/1 rows, |A | B| = |A| + |B| - |A & B|)."""
-        i = inp.flatten(1).gt(0.5).float()
-        s = saved.flatten(1).gt(0.5).float()
-        inter = s @ i.t()
+    def _siou(saved_logits, inp_logits):
+        """hard-mask IoU over the overlapping frames (OverTracker.py:92-113): sigmoid(x) > 0.5 <=> x > 0;
+        |A & B| as an NT GEMM of 0/1 rows (exact in fp32), |A | B| = |A| + |B| - |A & B|."""
+        i = inp_logits.flatten(1).gt(0).float()
+        s = saved_logits.flatten(1).gt(0).float()
+        inter = _nt(s, i)
         si, ii = s.sum(1), i.sum(1)
         v = (si[:, None] > 0) & (ii[None] > 0)
         union = si[:, None] + ii[None] - inter
@@ -102,52 +124,53 @@ class OverTracker:
 
     def update(self, clip: Clips):
         n_in = clip.num_instance
-        siou = sm = None
         if self.num_inst == 0:
             mid = midx = list(range(n_in))
             self.num_inst += n_in
-            siou = torch.zeros(0, n_in, device=self.device)
-            sm = torch.zeros(0, n_in, device=self.device)
+            siou = sm = np.zeros((0, n_in))
+            sc = None
         else:
-            qm = self.embed_mem[:self.num_inst]
-            lo = (self.untracked[:self.num_inst] < self.n_long).nonzero().reshape(-1)
-            sh = (self.untracked[:self.num_inst] < self.n_short).nonzero().reshape(-1)
-            sm = torch.zeros(self.num_inst, n_in, device=self.device)
-            sm[lo] = ctt_similarity(qm[lo], clip.query_embeds)
-            sm[sh] = 0.5 * (sm[sh] + ctt_similarity(qm[sh], clip.query_embeds))
+            ni = self.num_inst
+            qm = self.embed_mem[:ni]
+            lo = np.nonzero(self.untracked[:ni] < self.n_long)[0].tolist()
+            sh = np.nonzero(self.untracked[:ni] < self.n_short)[0].tolist()
+            sm_d = torch.zeros(ni, n_in, device=self.device)
+            if lo:
+                sm_d[lo] = ctt_similarity(qm[lo], clip.query_embeds)
+            if sh:
+                sm_d[sh] = 0.5 * (sm_d[sh] + ctt_similarity(qm[sh], clip.query_embeds))
             ii, si_ = [], []
             for o, f in enumerate(clip.frame_idx):
                 if f in self.saved_idx and f >= self.start_frame:
                     ii.append(o)
                     si_.append(self.frame_idx.index(f))
-            siou = torch.zeros(self.num_inst, n_in, device=self.device)
-            if len(si_) > 0:
-                im = clip.mask_logits[:, ii].float()
-                s = self.logits[:self.num_clip, :self.num_inst][:, :, si_]
-                sv = self.valid[:self.num_clip, :self.num_inst].any(-1)
-                s = s.sum(0) / sv.sum(0).clamp(min=1).reshape(-1, 1, 1, 1)
-                siou = self._siou(s.sigmoid(), im.sigmoid())
+            siou_d = torch.zeros(ni, n_in, device=self.device)
+            if len(si_) > 0 and n_in > 0:
+                contiguous = si_ == list(range(si_[0], si_[-1] + 1)) and ii == list(range(ii[0], ii[-1] + 1))
+                im = (clip.mask_logits[:, ii[0]:ii[-1] + 1] if contiguous else clip.mask_logits[:, ii]).float()
+                n_present = self.clip_valid[:self.num_clip, :ni].sum(0).clamp(min=1).reshape(-1, 1, 1, 1)
+                s = (self.sum_logits[:ni, si_[0]:si_[-1] + 1] if contiguous else self.sum_logits[:ni][:, si_]) / n_present
+                siou_d = self._siou(s, im)
+            host = torch.cat([siou_d, sm_d, clip.scores.reshape(1, -1).float()], 0).cpu().numpy()   # the one host sync
+            siou, sm, sc = host[:ni].copy(), host[ni:2 * ni].copy(), host[2 * ni]
             scores = siou + sm
             above = scores > 0.6
-            scores = scores * above.float()
-            r, c = linear_sum_assignment(scores.cpu().numpy(), maximize=True)       # host sync, as the reference (:159)
-            above_c = above.cpu().numpy()
+            scores = scores * above
+            r, c = linear_sum_assignment(scores, maximize=True)
             mid, midx = [], []
             for ri, ci in zip(r, c):
-                if not above_c[ri, ci]:
+                if not above[ri, ci]:
                     continue
                 midx.append(int(ci))
                 mid.append(int(ri))
-            if mid:
-                siou[mid, midx] = -1
-                sm[mid, midx] = 0
+                siou[ri, ci] = -1
+                sm[ri, ci] = 0
+        if sc is None:
+            sc = clip.scores.float().cpu().numpy() if n_in else np.zeros(0)
         un = [i for i in range(n_in) if i not in midx]
         rep = []
-        if un and siou.shape[0] > 0:
-            ms = siou[:, un].max(0)[0].cpu()
-            mc = sm[:, un].max(0)[0].cpu()
-            rep = [i for j, i in enumerate(un) if ms[j] > 0.4 or mc[j] > 0.6]
-        sc = clip.scores.cpu()
+        if siou.shape[0] > 0:
+            rep = [i for i in un if siou[:, i].max() > 0.4 or sm[:, i].max() > 0.6]
         un = [i for i in range(n_in) if i not in midx + rep and sc[i] > 2 * self.thr]
         new = list(range(self.num_inst, self.num_inst + len(un)))
         mid, midx = list(mid) + new, list(midx) + un
@@ -157,26 +180,27 @@ class OverTracker:
         self.num_inst += len(new)
 
     def get_result(self, is_last_clip=False):
-        lg = self.logits[:self.num_clip, :self.num_inst]
-        va = self.valid[:self.num_clip, :self.num_inst]
-        cl = self.cls[:self.num_clip, :self.num_inst]
-        qe = self.embeds[:self.num_clip, :self.num_inst]
-        lg = lg.sum(0) / va.sum(0).clamp(min=1)[..., None, None]
+        """OverTracker.py:195-225."""
+        n = self.num_inst
+        lg = self.sum_logits[:n] / self.cnt[:n].clamp(min=1)[..., None, None]
         nv = max(self.saved_idx) - self.start_frame + 1
         ln = self.win if not is_last_clip else int(nv)
         out_m = lg[:, :ln]
-        vc = va.any(-1)[..., None]
+        vc = self.clip_valid[:self.num_clip, :n][..., None]
+        cl = self.cls[:self.num_clip, :n]
+        qe = self.embeds[:self.num_clip, :n]
         out_c = (cl * vc).sum(0) / vc.sum(0).clamp(min=1)
         nc = min(max(3, (self.T - 1) // self.stride), self.num_clip)
         qw = vc[-nc:] * self.w_mem[:nc].reshape(-1, 1, 1)
         oq = (qe[-nc:] * qw).sum(0) / qw.sum(0).clamp(min=1)
         if not is_last_clip:
-            n = self.num_inst
-            carry_v = va[:, :n, self.win:].any(0)
-            carry_l = lg[:n, self.win:].clone()
+            carry_l = lg[:, self.win:]                       # lg is a fresh tensor, safe across the re-zeroing
+            carry_v = (self.cnt[:n, self.win:] > 0)
             self._init_memory(False)
-            self.logits[0, :n, :self.mem_len - self.win] = carry_l
-            self.valid[0, :n, :self.mem_len - self.win] = carry_v
+            k = self.mem_len - self.win
+            self.sum_logits[:n, :k] = carry_l * carry_v[..., None, None]
+            self.cnt[:n, :k] = carry_v.float()
+            self.clip_valid[0, :n] = carry_v.any(-1)
             self.cls[0, :n] = out_c
             self.embeds[0, :n] = oq
         return out_c, out_m

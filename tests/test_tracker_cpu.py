@@ -1,0 +1,33 @@
+"""CPU: the product tracker (running-sum state) against the reference OverTracker's recorded behaviour."""
+import torch
+
+from _golden import Fixture, maxdiff
+from mdqe_cvpr2023_amd.tracking import Clips, OverTracker
+
+
+def test_tracker_matches_reference_sequence():
+    fx = Fixture("tracker_seq")
+    trk = OverTracker(fx.i("MAXI"), fx.i("T"), fx.i("WIN"), 1, fx.i("K"), 4, fx.i("E"), tuple(int(v) for v in fx.z["HW"]),
+                      torch.device("cpu"), fx.f("THR"))
+    saved, n = 0, fx.i("n_clips")
+    for i in range(n):
+        clip = {k: fx.t(f"clip{i}::{k}") for k in ("scores", "pred_classes", "cls_probs", "pred_masks", "query_embeds")}
+        fi = fx.t(f"clip{i}::frame_idx").tolist()
+        trk.update(Clips(fi, clip))
+        assert trk.num_inst == fx.i(f"clip{i}::num_inst_after")
+        last = i == n - 1
+        if last or (fi[0] + 1 >= fx.i("WIN") * (saved + 1)):
+            c, m = trk.get_result(last)
+            assert maxdiff(c, fx.t(f"win{saved}::cls")) < 1e-6
+            assert m.shape == fx.t(f"win{saved}::masks").shape and maxdiff(m, fx.t(f"win{saved}::masks")) < 1e-5
+            saved += 1
+    assert saved == fx.i("n_windows")
+
+
+def test_clip_schedule_matches_reference_loop():
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    # mdqe/mdqe.py:308-312,363: clips until the first one that reaches past the video (clamped)
+    assert MDQE.clip_schedule(9, 3, 1) == [(s, min(s + 3, 9), s + 3 > 9) for s in range(8)]
+    assert MDQE.clip_schedule(4, 4, 1) == [(0, 4, False), (1, 4, True)]
+    assert MDQE.clip_schedule(3, 4, 1) == [(0, 3, True)]
+    assert MDQE.clip_schedule(10, 4, 2)[-1] == (8, 10, True)
