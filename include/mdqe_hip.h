@@ -124,6 +124,17 @@ int mdqe_upsample_nearest_add_nhwc_f32(const float* a, const float* b, float* y,
 int mdqe_dwconv5x5_nhwc_f32(const float* x, const float* wt, const float* bias, float* y, int NI, int H, int W, int C,
                             int up2, const float* tw, const float* tb, void* stream);
 
+/* ---- tracker, device half (mdqe/tracking/OverTracker.py) ------------------------------------------
+ * siou: out3[i,j,:] = (|A_i & B_j|, |A_i|, |B_j|) with A_i = saved[i*saved_stride + k] > 0, B_j = inp[j*inp_stride + k] > 0,
+ * k < n (the overlapping frames of both are contiguous); feeds OverTracker._get_siou (:92-113).
+ * accumulate: sum[r[k]*sum_stride + e] += src[c[k]*src_stride + e] (e < n), cnt[r[k]*cnt_stride + f] += 1 (f < nf);
+ * r/c are HOST int arrays (count <= 128)  (OverTracker._update_memory :65-76). */
+int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
+                      int n_in, long n, float* out3, void* stream);
+int mdqe_trk_accumulate_f32(float* sum, long sum_stride, float* cnt, long cnt_stride, const float* src,
+                            long src_stride, long n, int nf, const int* r_host, const int* c_host, int count,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -583,15 +583,24 @@ class Engine:
         # -- final per-clip top-k: max(#(score>thr),1) best alive rows (:416-419)
         neg = torch.where(alive, sc, torch.full_like(sc, -1.0))
         host = torch.stack([neg, (alive & (sc > thr)).float()], 1).cpu()   # host sync 2
-        results, o = [], 0
+        sels, o = [], 0
         for b in range(B):
             n = counts[b]
             sneg, above = host[o:o + n, 0], host[o:o + n, 1]
             n_alive = int((sneg >= 0).sum())
             order = torch.argsort(sneg, descending=True, stable=True)
             k = min(max(int(above.sum()), 1), n_alive)
-            t = (order[:k] + o).to(self.dev)
-            results.append({"scores": sc[t], "pred_classes": lab[t], "cls_probs": cls_k[t], "pred_masks": mp[t],
-                            "query_embeds": emb_k[t]})
+            sels.append(order[:k] + o)
             o += n
+        sel_all = torch.cat(sels).to(self.dev)
+        small = torch.cat([sc[:, None], cls_k, emb_k], 1)[sel_all].cpu().numpy()   # host sync 3: per-instance vectors for the tracker
+        results, o = [], 0
+        for b in range(B):
+            k = len(sels[b])
+            t = sel_all[o:o + k]
+            hs = small[o:o + k]
+            results.append({"scores": sc[t], "pred_classes": lab[t], "cls_probs": cls_k[t], "pred_masks": mp[t],
+                            "query_embeds": emb_k[t],
+                            "host": {"scores": hs[:, 0], "cls_probs": hs[:, 1:1 + K], "query_embeds": hs[:, 1 + K:]}})
+            o += k
         return results

@@ -153,7 +153,7 @@ class MDQE(nn.Module):
             ress = eng.inference_clips(outs, [cache["mf"][c[0] - frame_offset - base:c[1] - frame_offset - base] for c in group])
             for (start, end, last), res in zip(group, ress):
                 if trace is not None:
-                    trace.append({k: v.clone() for k, v in res.items()})
+                    trace.append({k: v.clone() for k, v in res.items() if torch.is_tensor(v)})
                 yield start, end, last, res
             i = j
 
@@ -161,12 +161,12 @@ class MDQE(nn.Module):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""
         cfg = self.cfg
         T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
-        merge_dev = torch.device("cpu") if cfg.merge_on_cpu else self.device
+        # MODEL.MDQE.MERGE_ON_CPU exists in the reference to fit 16-40 GB GPUs (mdqe/mdqe.py:185-186,354-355); with
+        # 288 GB of HBM the merge always stays on the device (results are identical either way).
+        merge_dev = self.device
         saved, tracker = 0, None
         cls_clips, mask_clips = [], []
         for start, end, last, res in results:
-            if merge_dev.type == "cpu":
-                res = {k: v.cpu() for k, v in res.items()}
             if tracker is None:
                 tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
                                       mask_hw, merge_dev, cfg.apply_cls_thres)

@@ -30,6 +30,10 @@ def stage_breakdown(model, frames_dev, chunk=30, n_clips=8):
     coords, content, emb = q
     dec, out["decode_clip"] = _t(lambda: eng.decode_clip(coords[:T], content[:T], emb[:T], vals[:T], geo), n_clips)
     res, out["inference_clip"] = _t(lambda: eng.inference_clip(dec, mf[:T]), n_clips)
+    nb = fr.shape[0] - T + 1
+    cache = {"coords": coords, "content": content, "emb": emb, "vals": vals}
+    decs, out[f"decode_clips_x{nb}"] = _t(lambda: eng.decode_clips(cache, list(range(nb)), T, geo), 2)
+    _, out[f"inference_clips_x{nb}"] = _t(lambda: eng.inference_clips(decs, [mf[i:i + T] for i in range(nb)]), 2)
     ms = cfg.match_stride
     trk, out["tracker_alloc"] = _t(lambda: OverTracker(cfg.n_max_inst, T, cfg.n_frames_window_test, cfg.clip_stride, cfg.num_classes,
                                                        cfg.mask_dim, cfg.hidden_dim, (geo.Hp // ms, geo.Wp // ms), model.device,

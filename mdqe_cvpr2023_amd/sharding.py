@@ -80,14 +80,16 @@ def all_gather_clips(local, T, dist, world, device, proto_shapes):
     for r in range(world):
         nclips = int(all_sizes[r][0])
         m = gathered["meta"][r].cpu()
+        host = {f: gathered[f][r].cpu().numpy() for f in ("scores", "cls_probs", "query_embeds")}   # one copy per rank buffer
         for i in range(nclips):
             s, e, l, n = [int(v) for v in m[i]]
             res = {}
             for f in FIELDS:
                 t = gathered[f][r][i, :n]
                 if f == "pred_masks":
-                    t = t[:, :e - s]
+                    t = t[:, :e - s].contiguous()
                 res[f] = t
+            res["host"] = {f: host[f][i, :n] for f in host}
             merged.append((s, e, bool(l), res))
     merged.sort(key=lambda c: c[0])
     return merged
