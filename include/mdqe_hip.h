@@ -80,10 +80,13 @@ int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* v
  * (transformer_dec.py:350,399), input_proj 1x1 (models/mdqe.py:34-37), dynamic mask product
  * (mdqe/mdqe.py:384).  K % 4 == 0, lda % 4 == 0, A/W 16-B aligned.  act applies to columns
  * < act_cols (<=0: all); rowmask (u8, 1 = zero the row) applies to columns < mask_cols
- * (the masked_fill of ms_deform_attn.py:137-138).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64. */
+ * (the masked_fill of ms_deform_attn.py:137-138).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64.
+ * ksplit > 1: K is cut into ksplit chunks over blockIdx.y, partial tiles go to splitk_ws (>= ksplit*M*N floats)
+ * and a second pass sums them in fixed order and applies the epilogue (deterministic; for skinny large-K products). */
 int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                      int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
-                     int res_first, const unsigned char* rowmask, int mask_cols, int tile, void* stream);
+                     int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
+                     float* splitk_ws, void* stream);
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
  * X [NI,H,W,Cin] (Cin % 32 == 0; images x_img_stride floats apart, <=0: dense), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,
@@ -134,6 +137,13 @@ int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_saved, const 
 int mdqe_trk_accumulate_f32(float* sum, long sum_stride, float* cnt, long cnt_stride, const float* src,
                             long src_stride, long n, int nf, const int* r_host, const int* c_host, int count,
                             void* stream);
+
+/* ---- per-row statistics of dynamic mask logits (mdqe/mdqe.py:387-413) in one pass -------------------
+ * logits [n, T, H, W].  stats[r] = (any(x>0), sum sigmoid(x)[x>0], count[x>0], sum_half sigmoid(x), count_half[x>0]);
+ * half = every 2nd pixel in y and x (and every 2nd frame when t_step == 2), i.e. F.interpolate(scale_factor=0.5,
+ * nearest) of :394-396; soft_h / hard_h [n, Th*(H/2)*(W/2)] receive sigmoid(x) and [x>0] on that grid. */
+int mdqe_mask_row_stats_f32(const float* logits, int n, int T, int H, int W, int t_step, float* stats5,
+                            float* soft_h, float* hard_h, void* stream);
 
 #ifdef __cplusplus
 }

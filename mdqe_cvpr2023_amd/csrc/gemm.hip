@@ -35,6 +35,9 @@ struct GemmParams {
   const unsigned char* rowmask; int mask_cols;   // C[m, n < mask_cols] = 0 where rowmask[m] != 0
   int act; int act_cols;    // activation on columns < act_cols (act_cols <= 0: all)
   unsigned a_bytes, w_bytes;
+  int vec_ok;               // C/bias/residual are 16-B aligned with ld % 4 == 0: float4 epilogue
+  int ksplit, kchunk;       // split-K: blockIdx.y = split, K range [y*kchunk, (y+1)*kchunk); raw partials -> ws
+  float* ws;                // [ksplit][M][N] partial sums (deterministic two-pass reduction)
 };
 
 #define OOB_OFF 0xFFFFFFF0u
@@ -136,13 +139,16 @@ gemm_nt_f32_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
+  const int kbeg = p.ksplit > 1 ? blockIdx.y * p.kchunk : 0;
+  const int kend = p.ksplit > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+  const int kt0 = kbeg / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
   const int lr = lane & 31, lh = lane >> 5;
-  issue(0, 0);
+  issue(kt0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for step kt has landed
     __syncthreads();                                   // ... and everybody else's; all reads of the other buffer are done
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
     const float* sA = lds + (kt & 1) * (ROWS * BK);
     const float* sW = sA + BM * BK;
 #pragma unroll
@@ -170,51 +176,125 @@ gemm_nt_f32_kernel(const GemmParams p) {
     }
   }
 
-  // epilogue: acc[i][j][r] is C(row = (r&3) + 8*(r>>2) + 4*lh, col = lr) of the 32x32 sub-tile
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // acc[i][j][r] is C(row = (r&3) + 8*(r>>2) + 4*lh, col = lr) of a 32x32 sub-tile.  The tile is restaged
+  // through LDS (free after the K loop) so that every lane then owns 4 consecutive columns of a row:
+  // bias / residual / C move as 16-B lane accesses, 512 B contiguous per row across 32 lanes.
+  __syncthreads();                                   // every wave is done reading the last K-step
+  float* sC = lds;                                   // [BM][BN] floats (== 2 stage buffers when BM == BN)
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * (BN / WN) + j * 32 + lr;
-    const bool nok = n < p.N;
-    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
-    const bool do_act = p.act != MDQE_ACT_NONE && (p.act_cols <= 0 || n < p.act_cols);
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nok && m < p.M) {
-          float v = acc[i][j][r] + bv;
-          float rv = 0.f;
-          if (p.residual != nullptr) {
-            const long rr = p.res_mod > 0 ? (m % p.res_mod) : m;
-            rv = p.residual[rr * p.ldr + n];
-          }
-          if (p.res_first) v += rv;
-          if (do_act) v = mdqe_act(v, p.act);
-          if (!p.res_first) v += rv;
-          if (p.rowmask != nullptr && n < p.mask_cols && p.rowmask[m]) v = 0.f;
-          p.C[(long)m * p.ldc + n] = v;
-        }
+        const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = wn * (BN / WN) + j * 32 + lr;
+        sC[row * BN + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int C4 = BN / 4;                         // float4 per tile row
+  constexpr int NV = BM * C4 / (64 * NW);            // float4 per thread
+  if (p.ksplit > 1) {                                // raw partial tile -> workspace; epilogue runs in the reduce pass
+    float* w = p.ws + (long)blockIdx.y * p.M * p.N;
+    for (int it = 0; it < NV; ++it) {
+      const int idx = it * (64 * NW) + tid;
+      const int row = idx / C4, c4 = idx - row * C4;
+      const int m = m0 + row, n = n0 + c4 * 4;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) w[(long)m * p.N + n + e] = sC[row * BN + c4 * 4 + e];
+    }
+    return;
+  }
+  const bool vec = p.vec_ok;
+  int rr0 = 0;
+  if (p.residual != nullptr && p.res_mod > 0) rr0 = m0 % p.res_mod;
+#pragma unroll 4
+  for (int it = 0; it < NV; ++it) {
+    const int idx = it * (64 * NW) + tid;
+    const int row = idx / C4, c4 = idx - row * C4;
+    const int m = m0 + row, n = n0 + c4 * 4;
+    if (m >= p.M || n >= p.N) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * BN + c4 * 4);
+    const bool full = vec && (n + 3 < p.N);
+    long rrow = m;
+    if (p.res_mod > 0) { int t = rr0 + row; while (t >= p.res_mod) t -= p.res_mod; rrow = t; }
+    const bool masked = p.rowmask != nullptr && p.rowmask[m];
+    if (full) {
+      if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
+      if (p.res_first) v += rv;
+      if (p.act != MDQE_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (p.act_cols <= 0 || n + e < p.act_cols) v[e] = mdqe_act(v[e], p.act);
+      }
+      if (!p.res_first) v += rv;
+      if (masked) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.mask_cols) v[e] = 0.f;
+      }
+      *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) break;
+        float x = v[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f);
+        const float rv = p.residual != nullptr ? p.residual[rrow * p.ldr + n + e] : 0.f;
+        if (p.res_first) x += rv;
+        if (p.act != MDQE_ACT_NONE && (p.act_cols <= 0 || n + e < p.act_cols)) x = mdqe_act(x, p.act);
+        if (!p.res_first) x += rv;
+        if (masked && n + e < p.mask_cols) x = 0.f;
+        p.C[(long)m * p.ldc + n + e] = x;
       }
     }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gemm_splitk_reduce_kernel(const GemmParams p) {
+  const long total = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / p.N), n = (int)(i - (long)m * p.N);
+    float x = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) x += p.ws[(long)s * total + i];       // fixed order: deterministic
+    if (p.bias != nullptr) x += p.bias[n];
+    float rv = 0.f;
+    if (p.residual != nullptr) rv = p.residual[(long)(p.res_mod > 0 ? m % p.res_mod : m) * p.ldr + n];
+    if (p.res_first) x += rv;
+    if (p.act != MDQE_ACT_NONE && (p.act_cols <= 0 || n < p.act_cols)) x = mdqe_act(x, p.act);
+    if (!p.res_first) x += rv;
+    if (p.rowmask != nullptr && n < p.mask_cols && p.rowmask[m]) x = 0.f;
+    p.C[(long)m * p.ldc + n] = x;
   }
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmParams& p, hipStream_t st) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t smem = 2 * (BM + BN) * 32 * sizeof(float);
+  size_t smem = 2 * (BM + BN) * 32 * sizeof(float);
+  if (smem < (size_t)BM * BN * sizeof(float)) smem = (size_t)BM * BN * sizeof(float);   // epilogue restage
   auto kern = gemm_nt_f32_kernel<BM, BN, WM, WN>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(64 * WM * WN), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(64 * WM * WN), smem, st, p);
+  int rc = mdqe_launch_status();
+  if (rc || p.ksplit <= 1) return rc;
+  long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
   return mdqe_launch_status();
 }
 
 static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
+  p.vec_ok = ((((uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.residual) & 15) == 0) && (p.ldc % 4 == 0) &&
+             (p.residual == nullptr || p.ldr % 4 == 0);
   // tile: 0 = auto
   if (tile == 0) {
     const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -232,7 +312,8 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
 
 extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                                 int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
-                                int res_first, const unsigned char* rowmask, int mask_cols, int tile, void* stream) {
+                                int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
+                                float* splitk_ws, void* stream) {
   MDQE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N);
   if (M == 0) return MDQE_OK;
   MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
@@ -243,6 +324,13 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
   p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = res_mod; p.res_first = res_first; p.rowmask = rowmask; p.mask_cols = mask_cols;
   p.act = act; p.act_cols = act_cols; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+  p.ksplit = 1; p.kchunk = K; p.ws = nullptr;
+  if (ksplit > 1) {
+    MDQE_CHECK_PTR(splitk_ws);
+    int kc = (K + ksplit - 1) / ksplit; kc = (kc + 31) / 32 * 32;
+    const int ks = (K + kc - 1) / kc;
+    if (ks > 1) { p.ksplit = ks; p.kchunk = kc; p.ws = splitk_ws; }
+  }
   mdqe_clear_error();
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }
@@ -266,6 +354,7 @@ extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const flo
   p.conv = 1; p.H = H; p.Wd = Wd; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = 0; p.res_first = res_first; p.img_stride = x_img_stride; p.rowmask = nullptr; p.mask_cols = 0;
   p.act = act; p.act_cols = 0; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+  p.ksplit = 1; p.kchunk = p.K; p.ws = nullptr;
   mdqe_clear_error();
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }

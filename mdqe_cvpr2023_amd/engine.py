@@ -552,18 +552,11 @@ class Engine:
             if counts[b]:
                 ops.linear(coef_k[o:o + counts[b]], mask_feats[b].reshape(-1, Md), out=mp[o:o + counts[b]].view(counts[b], -1))
             o += counts[b]
-        # INTERIM-TORCH below: per-row reductions over the mask logits (to be fused into the mask kernel)
-        flat = mp.view(n_tot, -1)
-        pos = flat > 0
-        nonblank = pos.any(1)                                              # (:387)
-        mn = mp[:, ::2] if T >= 5 else mp                                  # (:394-396) nearest x0.5 = even pixels
-        half = mn[:, :, 0:2 * (Hm // 2):2, 0:2 * (Wm // 2):2].reshape(n_tot, -1)
-        soft_h = half.sigmoid()
-        hard_h = soft_h.gt(0.5).float()
-        sh, hh = soft_h.sum(1), hard_h.sum(1)
-        soft = flat.sigmoid()
-        hard = soft.gt(0.5).float()
-        quality = (soft * hard).sum(1) / (hard.sum(1) + 1e-6)              # (:411-413)
+        # one pass over the logits: blank test, mask-quality sums, half-resolution soft/hard maps + sums (:387-413)
+        stats, soft_h, hard_h = ops.mask_row_stats(mp)
+        nonblank = stats[:, 0] > 0
+        quality = stats[:, 1] / (stats[:, 2] + 1e-6)
+        sh, hh = stats[:, 3], stats[:, 4]
         # -- soft-IoU NMS inside each clip (:398-408), rows in score order, blank rows excluded
         mi = torch.zeros(n_tot, device=self.dev)
         o = 0
@@ -571,7 +564,7 @@ class Engine:
             n = counts[b]
             if n > 1:
                 nbk = nonblank[o:o + n].float()
-                num = ops.linear((soft_h[o:o + n] * nbk[:, None]).contiguous(), hard_h[o:o + n].contiguous())
+                num = ops.linear(soft_h[o:o + n], hard_h[o:o + n]) * nbk[:, None]      # split-K NT GEMM over the pixels
                 den = sh[o:o + n, None] + hh[None, o:o + n] - num
                 iou = torch.triu(num / (den + 1), diagonal=1) * nbk[:, None]
                 mi[o:o + n] = iou.max(0)[0]

@@ -30,7 +30,7 @@ def _chk(t, name, dtype=torch.float32):
 
 
 def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=None, mask_cols=0, act_cols=0,
-           out=None, ldc=None, tile=0, res_first=False):
+           out=None, ldc=None, tile=0, res_first=False, ksplit=0):
     """out[..., n] = epilogue(x[..., :] @ weight[n, :]).  x may be a 2-D row-strided view (last dim contiguous)."""
     K = x.shape[-1]
     N = weight.shape[0]
@@ -53,8 +53,14 @@ def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=Non
     ldr = 0
     if residual is not None:
         ldr = residual.stride(0) if residual.dim() == 2 else residual.shape[-1]
+    ws = None
+    if ksplit == 0 and K >= 2048 and ((M + 63) // 64) * ((N + 63) // 64) <= 64:
+        ksplit = min(64, K // 256)                      # skinny product: spread K over the CUs
+    if ksplit > 1:
+        ws = _workspace(ksplit * M * N * 4 + 64, x.device)
     check(lib.mdqe_gemm_nt_f32(ptr(x2), lda, ptr(weight), ptr(bias), ptr(out), ldc_, M, N, K, ACT[act], act_cols,
-                               ptr(residual), ldr, res_mod, int(res_first), ptr(rowmask), mask_cols, tile, cur_stream()), "gemm_nt_f32")
+                               ptr(residual), ldr, res_mod, int(res_first), ptr(rowmask), mask_cols, tile, ksplit, ptr(ws),
+                               cur_stream()), "gemm_nt_f32")
     if x.dim() != 2 and ldc is None and out.dim() == 2 and out.shape == (M, N):
         return out.view(*x.shape[:-1], N)
     return out
@@ -186,3 +192,18 @@ def msda_fused(value, offs, logits, ref, levels, B, Q, M, D, L, P, mode=0, grid=
                                   logits.stride(0), ptr(ref), ref_b, ref_dim, mode, ptr(grid), arr(Hs), arr(Ws), arr(Ss),
                                   B, M, D, groups, L, Q, P, scale, ptr(out), out.stride(0), cur_stream()), "msda_fused")
     return out
+
+
+def mask_row_stats(logits):
+    """logits [n,T,H,W] -> (stats [n,5], soft_h [n,Ph], hard_h [n,Ph]); see mdqe_mask_row_stats_f32."""
+    _chk(logits, "logits")
+    n, T, H, W = logits.shape
+    t_step = 2 if T >= 5 else 1
+    Th = (T + t_step - 1) // t_step
+    Ph = Th * (H // 2) * (W // 2)
+    stats = torch.empty(n, 5, device=logits.device)
+    soft_h = torch.empty(n, Ph, device=logits.device)
+    hard_h = torch.empty(n, Ph, device=logits.device)
+    check(lib.mdqe_mask_row_stats_f32(ptr(logits), n, T, H, W, t_step, ptr(stats), ptr(soft_h), ptr(hard_h), cur_stream()),
+          "mask_row_stats")
+    return stats, soft_h, hard_h

@@ -138,3 +138,27 @@ def test_stem_maxpool_upsample_dw():
     ref = F.conv2d(up, dw, db, padding=2, groups=C)
     out = ops.dwconv5x5(xg, wt, db.cuda(), up2=True, tw=tw.view(C).cuda(), tb=tb.cuda()).cpu().permute(0, 3, 1, 2)
     assert out.shape == ref.shape and rel(out, ref) < 1e-5
+
+
+def test_gemm_splitk_and_mask_stats():
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(150, 15360, generator=g); b = (torch.rand(150, 15360, generator=g) > 0.5).float()
+    ref = a @ b.t()
+    out = ops.linear(a.cuda(), b.cuda()).cpu()                    # auto split-K
+    assert rel(out, ref) < 2e-5
+    out = ops.linear(a.cuda()[:37], b.cuda()[:50], ksplit=7, act="relu", bias=torch.ones(50).cuda()).cpu()
+    assert rel(out, torch.relu(a[:37] @ b[:50].t() + 1)) < 2e-5
+    for T in (4, 5, 3):
+        x = torch.randn(7, T, 24, 40, generator=g) * 3
+        x[2] = -x[2].abs()                                        # a blank row
+        stats, sh, hh = ops.mask_row_stats(x.cuda())
+        mn = x[:, ::2] if T >= 5 else x
+        soft = F.interpolate(mn, scale_factor=0.5).flatten(1).sigmoid()
+        hard = soft.gt(0.5).float()
+        assert torch.equal(stats[:, 0].cpu() > 0, x.gt(0).flatten(1).any(1))
+        s_full = x.sigmoid().flatten(1); h_full = s_full.gt(0.5).float()
+        assert float((stats[:, 1].cpu() - (s_full * h_full).sum(1)).abs().max()) < 2e-2
+        assert torch.equal(stats[:, 2].cpu(), h_full.sum(1))
+        assert float((sh.cpu() - soft).abs().max()) < 1e-6 and torch.equal(hh.cpu(), hard)
+        assert float((stats[:, 3].cpu() - soft.sum(1)).abs().max()) < 2e-2 and torch.equal(stats[:, 4].cpu(), hard.sum(1))
