@@ -145,6 +145,29 @@ int mdqe_trk_accumulate_f32(float* sum, long sum_stride, float* cnt, long cnt_st
 int mdqe_mask_row_stats_f32(const float* logits, int n, int T, int H, int W, int t_step, float* stats5,
                             float* soft_h, float* hard_h, void* stream);
 
+/* ---- nn.MultiheadAttention core for short sequences (transformer_dec.py:348-353,397-402) --------------
+ * o[b,q,h,:] = softmax_k((q*D^-0.5).k) @ v ; qk rows hold q at col h*D and k at col C+h*D.  Q <= 256, D in {8,16,24,32}. */
+int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, long ldv, float* o, long ldo, int B, int Q,
+                       int C, int nh, void* stream);
+
+/* ---- grid-guided query selection (transformer_dec.py:81-109): conf [NI,H,W,K] -> coords [NI,nb*nb,2] (x,y);
+ * score_ws: NI*H*W floats. */
+int mdqe_query_select_f32(const float* conf, int NI, int H, int W, int K, int nb, float* score_ws, float* coords,
+                          void* stream);
+
+/* ---- query content (transformer_dec.py:171-179): mean over levels of border-mode bilinear grid_sample of the
+ * channels-last tokens [NI,N,C] at coords [NI,Qn,2]; level tables are HOST int[n_levels]. */
+int mdqe_sample_levels_mean_f32(const float* tokens, int NI, long N, int C, const float* coords, int Qn,
+                                const int* lvH_host, const int* lvW_host, const int* lvStart_host, int n_levels,
+                                float* out, void* stream);
+
+/* ---- final masks (mdqe/mdqe.py:357-358,458-462; util/misc.py:485-507) fused: x`factor` aligned-bilinear ->
+ * sigmoid -> crop [:h,:w] -> nearest resize to (Ho,Wo) -> > 0.5.  logits [*,Fw,Hm,Wm] (one tracker window);
+ * row k of out (uint8 [n_sel][out_inst_stride]) takes instance inst_idx_dev[k], frames written at f_off.. */
+int mdqe_final_masks_u8(const float* logits, int n_sel, const int* inst_idx_dev, int Fw, int Hm, int Wm, int factor,
+                        int h, int w, int Ho, int Wo, unsigned char* out, long out_inst_stride, int f_off,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,10 @@ SIGNATURES = {
     "mdqe_msda_fused_f32": [p, l, l, p, p, l, p, l, p, l, i, i, p, p, p, p, i, i, i, i, i, i, i, f, p, l, p],
     "mdqe_trk_siou_f32": [p, l, i, p, l, i, l, p, p],
     "mdqe_trk_accumulate_f32": [p, l, p, l, p, l, l, i, p, p, i, p],
+    "mdqe_mha_small_f32": [p, l, p, l, p, l, i, i, i, i, p],
+    "mdqe_query_select_f32": [p, i, i, i, i, i, p, p, p],
+    "mdqe_sample_levels_mean_f32": [p, i, l, i, p, i, p, p, p, i, p, p],
+    "mdqe_final_masks_u8": [p, i, p, i, i, i, i, i, i, i, i, p, l, i, p],
     "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, i, p, i, i, i, p, p],
     "mdqe_mask_row_stats_f32": [p, i, i, i, i, i, p, p, p, p],
     "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p],

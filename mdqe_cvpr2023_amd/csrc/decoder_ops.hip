@@ -1,0 +1,244 @@
+// Decoder-side kernels of the MDQE path for gfx950: small-sequence multi-head attention, grid-guided
+// query selection, multi-level content sampling, and the fused final-mask kernel.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// nn.MultiheadAttention core for short sequences (Q <= 256 tokens, head dim D <= 64, D % 4 == 0):
+//   o[b,q,h,:] = softmax_k( (q[b,q,h,:] * D^-0.5) . k[b,k,h,:] ) @ v[b,k,h,:]
+// (transformer_dec.py:348-353,397-402; torch scales q before the product).  One block per (batch, head):
+// K and V of the head live in LDS (2 x Q x D floats, 50 KB at Q=196, D=32), one thread per query row,
+// single-pass online softmax; every lane reads the same K/V row -> LDS broadcast reads.
+// qk: [B*Q, ldqk] with q at column h*D and k at column C + h*D; v: [B*Q, ldv]; o: [B*Q, ldo].
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256)
+mha_small_kernel(const float* __restrict__ qk, long ldqk, const float* __restrict__ v, long ldv, float* __restrict__ o,
+                 long ldo, int Q, int C, int nh) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sK = sm;
+  float* sV = sm + Q * D;
+  const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+  const long row0 = (long)b * Q;
+  for (int i = threadIdx.x; i < Q * (D / 4); i += blockDim.x) {
+    const int r = i / (D / 4), c4 = i % (D / 4);
+    *reinterpret_cast<f32x4*>(sK + r * D + c4 * 4) = *reinterpret_cast<const f32x4*>(qk + (row0 + r) * ldqk + C + h * D + c4 * 4);
+    *reinterpret_cast<f32x4*>(sV + r * D + c4 * 4) = *reinterpret_cast<const f32x4*>(v + (row0 + r) * ldv + h * D + c4 * 4);
+  }
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r >= Q) return;
+  const float scale = rsqrtf((float)D);
+  float q[D], acc[D];
+#pragma unroll
+  for (int c = 0; c < D; c += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(qk + (row0 + r) * ldqk + h * D + c);
+    q[c] = t[0] * scale; q[c + 1] = t[1] * scale; q[c + 2] = t[2] * scale; q[c + 3] = t[3] * scale;
+    acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < Q; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+      const f32x4 kk = *reinterpret_cast<const f32x4*>(sK + j * D + c);
+      s += q[c] * kk[0] + q[c + 1] * kk[1] + q[c + 2] * kk[2] + q[c + 3] * kk[3];
+    }
+    const float mn = fmaxf(m, s);
+    const float corr = expf(m - mn);
+    const float p = expf(s - mn);
+    l = l * corr + p;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + j * D + c);
+      acc[c] = acc[c] * corr + p * vv[0]; acc[c + 1] = acc[c + 1] * corr + p * vv[1];
+      acc[c + 2] = acc[c + 2] * corr + p * vv[2]; acc[c + 3] = acc[c + 3] * corr + p * vv[3];
+    }
+    m = mn;
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int c = 0; c < D; c += 4)
+    *reinterpret_cast<f32x4*>(o + (row0 + r) * ldo + h * D + c) = f32x4{acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv};
+}
+
+extern "C" int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, long ldv, float* o, long ldo, int B, int Q,
+                                  int C, int nh, void* stream) {
+  MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && nh > 0 && C % nh == 0 && ldqk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0);
+  const int D = C / nh;
+  MDQE_REQUIRE(D == 32 || D == 24 || D == 16 || D == 8);
+  if (B == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(qk); MDQE_CHECK_PTR(v); MDQE_CHECK_PTR(o);
+  mdqe_clear_error();
+  const size_t smem = (size_t)2 * Q * D * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define L(DD) do { (void)hipFuncSetAttribute((const void*)mha_small_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((mha_small_kernel<DD>), dim3(B * nh), dim3(256), smem, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh); } while (0)
+  if (D == 32) L(32); else if (D == 24) L(24); else if (D == 16) L(16); else L(8);
+#undef L
+  return mdqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grid-guided query selection (transformer_dec.py:81-109): s = max_k sigmoid(conf[img,y,x,k]);
+// bilinear resize (align_corners=False) to (H_up,W_up) = multiples of the nb x nb grid; per cell the FIRST
+// maximum wins; coords = (fmod(idx,W_up)/W_up, (idx/W_up)/H_up) with TRUE division (:105-106).
+// Pass 1 writes the score map; pass 2: one wave per (img, cell).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+score_max_kernel(const float* __restrict__ conf, long n, int K, float* __restrict__ score) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, conf[i * K + k]);
+    score[i] = 1.0f / (1.0f + expf(-m));                 // sigmoid is monotone: max(sigmoid) = sigmoid(max)
+  }
+}
+
+__global__ void __launch_bounds__(64)
+cell_argmax_kernel(const float* __restrict__ score, int H, int W, int H_up, int W_up, int nb, float* __restrict__ coords) {
+  const int cell = blockIdx.x % (nb * nb), img = blockIdx.x / (nb * nb);
+  const int cy = cell / nb, cx = cell % nb;
+  const int r = H_up / nb, t = W_up / nb;
+  const float sh = (float)H / (float)H_up, sw = (float)W / (float)W_up;
+  const float* s = score + (long)img * H * W;
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  for (int p = threadIdx.x; p < r * t; p += 64) {
+    const int oy = cy * r + p / t, ox = cx * t + p % t;
+    float fy = ((float)oy + 0.5f) * sh - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = ((float)ox + 0.5f) * sw - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0;
+    const float v = (1.f - ly) * ((1.f - lx) * s[y0 * W + x0] + lx * s[y0 * W + x1]) +
+                    ly * ((1.f - lx) * s[y1 * W + x0] + lx * s[y1 * W + x1]);
+    if (v > best || (v == best && p < bidx)) { best = v; bidx = p; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  }
+  if (threadIdx.x == 0) {
+    const int row = cy * r + bidx / t, col = cx * t + bidx % t;
+    const float idx = (float)(row * W_up + col);
+    float* c = coords + ((long)img * nb * nb + cell) * 2;
+    c[0] = fmodf(idx, (float)W_up) / (float)W_up;
+    c[1] = (idx / (float)W_up) / (float)H_up;
+  }
+}
+
+extern "C" int mdqe_query_select_f32(const float* conf, int NI, int H, int W, int K, int nb, float* score_ws, float* coords,
+                                     void* stream) {
+  MDQE_REQUIRE(NI >= 0 && H > 0 && W > 0 && K > 0 && nb > 0);
+  if (NI == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(conf); MDQE_CHECK_PTR(score_ws); MDQE_CHECK_PTR(coords);
+  mdqe_clear_error();
+  const int H_up = (2 * H / nb + 1) * nb, W_up = (2 * W / nb + 1) * nb;
+  const long n = (long)NI * H * W;
+  long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(score_max_kernel, dim3((unsigned)blocks), dim3(256), 0, st, conf, n, K, score_ws);
+  int rc = mdqe_launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(cell_argmax_kernel, dim3(NI * nb * nb), dim3(64), 0, st, score_ws, H, W, H_up, W_up, nb, coords);
+  return mdqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Content of the selected queries (transformer_dec.py:171-179): mean over levels of
+// grid_sample(level, 2*coord-1, bilinear, padding_mode=border, align_corners=False) on channels-last tokens
+// tokens [NI, N, C]; level l occupies rows start[l] .. start[l]+H_l*W_l.
+// ------------------------------------------------------------------------------------------------
+struct SampLevels { int H[8]; int W[8]; int start[8]; int n; };
+
+__global__ void __launch_bounds__(256)
+sample_levels_mean_kernel(const float* __restrict__ tok, long N, int C, const float* __restrict__ coords, int Qn, SampLevels lv,
+                          float* __restrict__ out, long total) {
+  const int c4n = C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const long t = i / c4n;                              // img*Qn + q
+    const long img = t / Qn;
+    const float cx = coords[t * 2], cy = coords[t * 2 + 1];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < lv.n; ++l) {
+      const int H = lv.H[l], W = lv.W[l];
+      float ix = ((2.f * cx - 1.f + 1.f) * W - 1.f) * 0.5f;      // grid_sampler unnormalize, align_corners=False
+      float iy = ((2.f * cy - 1.f + 1.f) * H - 1.f) * 0.5f;
+      ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));                // border: clip coordinates
+      iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+      const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+      const float lx = ix - x0, ly = iy - y0;
+      const float* base = tok + (img * N + lv.start[l]) * C + c4 * 4;
+      f32x4 v = (1.f - ly) * (1.f - lx) * *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x0) * C);
+      if (x0 + 1 < W) v += (1.f - ly) * lx * *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x0 + 1) * C);
+      if (y0 + 1 < H) v += ly * (1.f - lx) * *reinterpret_cast<const f32x4*>(base + ((long)(y0 + 1) * W + x0) * C);
+      if (x0 + 1 < W && y0 + 1 < H) v += ly * lx * *reinterpret_cast<const f32x4*>(base + ((long)(y0 + 1) * W + x0 + 1) * C);
+      acc += v;
+    }
+    *reinterpret_cast<f32x4*>(out + t * C + c4 * 4) = acc / (float)lv.n;
+  }
+}
+
+extern "C" int mdqe_sample_levels_mean_f32(const float* tokens, int NI, long N, int C, const float* coords, int Qn,
+                                           const int* lvH_host, const int* lvW_host, const int* lvStart_host, int n_levels,
+                                           float* out, void* stream) {
+  MDQE_REQUIRE(NI >= 0 && N > 0 && C > 0 && C % 4 == 0 && Qn > 0 && n_levels > 0 && n_levels <= 8);
+  if (NI == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(tokens); MDQE_CHECK_PTR(coords); MDQE_CHECK_PTR(out);
+  MDQE_CHECK_PTR(lvH_host); MDQE_CHECK_PTR(lvW_host); MDQE_CHECK_PTR(lvStart_host);
+  SampLevels lv;
+  lv.n = n_levels;
+  for (int i = 0; i < 8; ++i) { lv.H[i] = 1; lv.W[i] = 1; lv.start[i] = 0; }
+  for (int i = 0; i < n_levels; ++i) { lv.H[i] = lvH_host[i]; lv.W[i] = lvW_host[i]; lv.start[i] = lvStart_host[i]; }
+  mdqe_clear_error();
+  const long total = (long)NI * Qn * (C / 4);
+  long nb = (total + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(sample_levels_mean_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, tokens, N, C, coords, Qn, lv,
+                     out, total);
+  return mdqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final masks (mdqe/mdqe.py:357-358 + 458-462): out[i,f,Y,X] = sigmoid(aligned_bilinear_x4(logits)[sy,sx]) > 0.5 with
+// (sy,sx) = nearest source pixel of the crop [:h,:w] for an output of (Ho,Wo):  sy = min(floor(Y*h/Ho), h-1).
+// aligned_bilinear (util/misc.py:485-507) in closed form: pixel p reads source (max(p - f/2, 0))/f, clamped to the map.
+// logits [n, F, Hm, Wm] (mean logits of one tracker window); out uint8 [n, F_total, Ho, Wo] written at frame f_off.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+final_mask_kernel(const float* __restrict__ lg, int Fw, int Hm, int Wm, int factor, int h, int w, int Ho, int Wo,
+                  unsigned char* __restrict__ out, long out_inst_stride, int f_off, const int* __restrict__ inst_idx, long total) {
+  const float sy_scale = (float)h / (float)Ho, sx_scale = (float)w / (float)Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % Wo); long t = i / Wo;
+    const int Y = (int)(t % Ho); t /= Ho;
+    const int f = (int)(t % Fw); const int k = (int)(t / Fw);
+    const int sy = min((int)floorf(Y * sy_scale), h - 1), sx = min((int)floorf(X * sx_scale), w - 1);
+    const float fy = (float)max(sy - factor / 2, 0) / (float)factor, fx = (float)max(sx - factor / 2, 0) / (float)factor;
+    const int y0 = min((int)fy, Hm - 1), x0 = min((int)fx, Wm - 1);
+    const int y1 = min(y0 + 1, Hm - 1), x1 = min(x0 + 1, Wm - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float* m = lg + ((long)inst_idx[k] * Fw + f) * Hm * Wm;
+    const float top = m[y0 * Wm + x0] * (1.f - lx) + m[y0 * Wm + x1] * lx;
+    const float bot = m[y1 * Wm + x0] * (1.f - lx) + m[y1 * Wm + x1] * lx;
+    const float v = top * (1.f - ly) + bot * ly;
+    const float p = 1.0f / (1.0f + expf(-v));
+    out[(long)k * out_inst_stride + ((long)(f_off + f) * Ho + Y) * Wo + X] = p > 0.5f ? 1 : 0;
+  }
+}
+
+extern "C" int mdqe_final_masks_u8(const float* logits, int n_sel, const int* inst_idx_dev, int Fw, int Hm, int Wm, int factor,
+                                   int h, int w, int Ho, int Wo, unsigned char* out, long out_inst_stride, int f_off,
+                                   void* stream) {
+  MDQE_REQUIRE(n_sel >= 0 && Fw >= 0 && Hm > 0 && Wm > 0 && factor >= 1 && h > 0 && w > 0 && Ho > 0 && Wo > 0);
+  MDQE_REQUIRE(h <= Hm * factor && w <= Wm * factor);
+  if (n_sel == 0 || Fw == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(logits); MDQE_CHECK_PTR(inst_idx_dev); MDQE_CHECK_PTR(out);
+  mdqe_clear_error();
+  const long total = (long)n_sel * Fw * Ho * Wo;
+  long nb = (total + 255) / 256; if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(final_mask_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, logits, Fw, Hm, Wm, factor, h, w, Ho,
+                     Wo, out, out_inst_stride, f_off, inst_idx_dev, total);
+  return mdqe_launch_status();
+}

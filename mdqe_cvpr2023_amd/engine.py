@@ -380,23 +380,8 @@ class Engine:
         H, W = geo.shapes[0]
         nb = cfg.n_bins
         conf = self._mlp(enc[:, :H * W].reshape(-1, C), self.P.rpn_cls).view(NI, H, W, -1)
-        # INTERIM-TORCH: score map resize + per-cell argmax + grid_sample (small maps, to become one HIP kernel)
-        s = conf.sigmoid().max(-1)[0].unsqueeze(1)
-        H_up, W_up = (2 * H // nb + 1) * nb, (2 * W // nb + 1) * nb
-        s = F.interpolate(s, size=(H_up, W_up), mode="bilinear")
-        r, t = H_up // nb, W_up // nb
-        sel = s.view(NI, nb, r, nb, t).permute(0, 1, 3, 2, 4).reshape(NI, nb * nb, r * t).argmax(-1)
-        gy = torch.arange(nb, device=self.dev).view(1, nb, 1).expand(NI, nb, nb).reshape(NI, -1)
-        gx = torch.arange(nb, device=self.dev).view(1, 1, nb).expand(NI, nb, nb).reshape(NI, -1)
-        idx = (gy * r + torch.div(sel, t, rounding_mode="floor")) * W_up + gx * t + sel % t
-        coords = torch.stack([torch.fmod(idx, W_up) / W_up, (idx / W_up) / H_up], -1)      # true division, :105-106
-        grid = 2 * coords.view(NI, nb, nb, 2) - 1
-        acc = None
-        for l, (Hl, Wl) in enumerate(geo.shapes):
-            f = enc[:, geo.starts[l]:geo.starts[l] + Hl * Wl].transpose(1, 2).reshape(NI, C, Hl, Wl)
-            g = F.grid_sample(f, grid, mode="bilinear", padding_mode="border", align_corners=False)
-            acc = g if acc is None else acc + g
-        content = (acc / len(geo.shapes)).flatten(2).transpose(1, 2).contiguous()           # [NI,Q,C]
+        coords = ops.query_select(conf, nb)                      # sigmoid-max, bilinear resize, per-cell first argmax
+        content = ops.sample_levels_mean(enc, coords, geo.shapes, geo.starts)               # [NI,Q,C]
         emb = self._mlp(content.view(-1, C), self.P.track_embed).view(NI, nb * nb, -1)
         return coords, content, emb
 
@@ -411,13 +396,9 @@ class Engine:
     def _mha(self, sa, qk_in, v_in, nh):
         """nn.MultiheadAttention, q = k = x+pos, v = x, eval (transformer_dec.py:348-353,397-402)."""
         B, Q, C = qk_in.shape
-        qk = ops.linear(qk_in.reshape(-1, C), sa.wqk, sa.bqk).view(B, Q, 2, nh, C // nh)
-        v = ops.linear(v_in.reshape(-1, C), sa.wv, sa.bv).view(B, Q, nh, C // nh)
-        # INTERIM-TORCH: 196x196 attention core (to become one fused HIP kernel)
-        q, k = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)
-        a = torch.softmax((q / math.sqrt(C // nh)) @ k.transpose(-1, -2), -1)
-        o = (a @ v.transpose(1, 2)).transpose(1, 2).reshape(B * Q, C)
-        return o, sa
+        qk = ops.linear(qk_in.reshape(-1, C), sa.wqk, sa.bqk)
+        v = ops.linear(v_in.reshape(-1, C), sa.wv, sa.bv)
+        return ops.mha_small(qk, v, B, Q, C, nh), sa
 
     @staticmethod
     def _clip_box(boxes, t0, t1):

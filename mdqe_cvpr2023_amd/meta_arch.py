@@ -165,21 +165,21 @@ class MDQE(nn.Module):
         # 288 GB of HBM the merge always stays on the device (results are identical either way).
         merge_dev = self.device
         saved, tracker = 0, None
-        cls_clips, mask_clips = [], []
+        cls_clips, windows, f_off = [], [], 0
         for start, end, last, res in results:
             if tracker is None:
                 tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
                                       mask_hw, merge_dev, cfg.apply_cls_thres)
             tracker.update(Clips(range(start, end), res))
             if last or (start + stride >= win * (saved + 1)):
-                c, m = tracker.get_result(is_last_clip=last)
-                m = aligned_bilinear(m, cfg.match_stride).sigmoid()[..., :frame_hw[0], :frame_hw[1]]
+                c, m = tracker.get_result(is_last_clip=last)        # m: mean logits [n, F, Hm, Wm] of this window
                 cls_clips.append(c)
-                mask_clips.append(m)
+                windows.append((f_off, m.contiguous()))
+                f_off += m.shape[1]
                 saved += 1
             if last:
                 break
-        return self.inference_video(out_size, cls_clips, mask_clips)
+        return self.inference_video(out_size, cls_clips, windows, frame_hw, f_off)
 
     def to_device_frames(self, imgs):
         stack = imgs if torch.is_tensor(imgs) else torch.stack(list(imgs))
@@ -200,8 +200,11 @@ class MDQE(nn.Module):
         return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace), (h, w), out_size,
                                 (geo.Hp // ms, geo.Wp // ms))
 
-    def inference_video(self, image_size, cls_clips, mask_clips):
-        """mdqe/mdqe.py:430-471."""
+    def inference_video(self, image_size, cls_clips, windows, frame_hw, n_frames):
+        """mdqe/mdqe.py:430-471.  The x4 aligned-bilinear up-sampling, sigmoid, crop (:357-358), nearest resize to the
+        original size and the 0.5 threshold (:458-462) run as ONE kernel per window, only for the instances that
+        survive the top-k; windows in which an instance did not exist yet stay zero (:442)."""
+        from . import ops
         K = self.cfg.num_classes
         total = cls_clips[-1].shape[0]
         cc = torch.stack([torch.cat([c, c.new_zeros(total - c.shape[0], c.shape[1])]) for c in cls_clips])
@@ -210,14 +213,18 @@ class MDQE(nn.Module):
         sc, ti = out_cls.topk(k, sorted=False)
         labels = (ti % K).tolist()
         inst = torch.div(ti, K, rounding_mode="floor").tolist()
-        masks, done = [], {}
-        for i in inst:
-            if i not in done:
-                vid = torch.cat([m[i] if i < m.shape[0] else torch.zeros_like(m[0]) for m in mask_clips], 0)
-                r = F.interpolate(vid.unsqueeze(0), size=tuple(image_size), mode="nearest").squeeze(0) > 0.5
-                done[i] = r.cpu()
-            masks.append(done[i])
-        return {"image_size": tuple(image_size), "pred_scores": sc.tolist(), "pred_labels": labels, "pred_masks": masks}
+        sel = sorted(set(inst))
+        Ho, Wo = int(image_size[0]), int(image_size[1])
+        out = torch.zeros(len(sel), n_frames, Ho, Wo, dtype=torch.uint8, device=self.device)
+        sel_dev = torch.tensor(sel, dtype=torch.int32, device=self.device)
+        for f_off, m in windows:
+            cnt = sum(1 for i in sel if i < m.shape[0])       # sel is ascending: these are its first `cnt` entries
+            if cnt:
+                ops.final_masks(m, sel_dev[:cnt], self.cfg.match_stride, frame_hw[0], frame_hw[1], Ho, Wo, out, f_off)
+        host = out.cpu().view(torch.bool)
+        pos = {i: p for p, i in enumerate(sel)}
+        return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels,
+                "pred_masks": [host[pos[i]] for i in inst]}
 
 
 try:                                              # drop-in registration when detectron2 is present

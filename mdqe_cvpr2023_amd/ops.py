@@ -207,3 +207,45 @@ def mask_row_stats(logits):
     check(lib.mdqe_mask_row_stats_f32(ptr(logits), n, T, H, W, t_step, ptr(stats), ptr(soft_h), ptr(hard_h), cur_stream()),
           "mask_row_stats")
     return stats, soft_h, hard_h
+
+
+def mha_small(qk, v, B, Q, C, nh, out=None):
+    """qk [B*Q, 2C] (q | k), v [B*Q, C] -> [B*Q, C]."""
+    if out is None:
+        out = torch.empty((B * Q, C), dtype=torch.float32, device=v.device)
+    check(lib.mdqe_mha_small_f32(ptr(qk), qk.stride(0), ptr(v), v.stride(0), ptr(out), out.stride(0), B, Q, C, nh, cur_stream()),
+          "mha_small")
+    return out
+
+
+def query_select(conf, nb):
+    """conf [NI,H,W,K] -> coords [NI, nb*nb, 2]."""
+    _chk(conf, "conf")
+    NI, H, W, K = conf.shape
+    ws = torch.empty(NI * H * W, dtype=torch.float32, device=conf.device)
+    coords = torch.empty(NI, nb * nb, 2, dtype=torch.float32, device=conf.device)
+    check(lib.mdqe_query_select_f32(ptr(conf), NI, H, W, K, nb, ptr(ws), ptr(coords), cur_stream()), "query_select")
+    return coords
+
+
+def sample_levels_mean(tokens, coords, shapes, starts):
+    """tokens [NI,N,C], coords [NI,Q,2] -> [NI,Q,C]."""
+    import ctypes
+    _chk(tokens, "tokens"); _chk(coords, "coords")
+    NI, N, C = tokens.shape
+    Qn = coords.shape[1]
+    n = len(shapes)
+    arr = lambda v: (ctypes.c_int * n)(*[int(x) for x in v])
+    out = torch.empty(NI, Qn, C, dtype=torch.float32, device=tokens.device)
+    check(lib.mdqe_sample_levels_mean_f32(ptr(tokens), NI, N, C, ptr(coords), Qn, arr([s[0] for s in shapes]), arr([s[1] for s in shapes]),
+                                          arr(starts), n, ptr(out), cur_stream()), "sample_levels_mean")
+    return out
+
+
+def final_masks(logits, inst_idx, factor, h, w, Ho, Wo, out, f_off):
+    """logits [n,Fw,Hm,Wm]; inst_idx int32 CUDA [n_sel]; out uint8 [n_sel_total, L, Ho, Wo] (rows 0..n_sel-1 written)."""
+    _chk(logits, "logits")
+    n, Fw, Hm, Wm = logits.shape
+    check(lib.mdqe_final_masks_u8(ptr(logits), int(inst_idx.numel()), ptr(inst_idx), Fw, Hm, Wm, factor, h, w, Ho, Wo, ptr(out),
+                                  out.stride(0), f_off, cur_stream()), "final_masks")
+    return out

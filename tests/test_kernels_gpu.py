@@ -162,3 +162,60 @@ def test_gemm_splitk_and_mask_stats():
         assert torch.equal(stats[:, 2].cpu(), h_full.sum(1))
         assert float((sh.cpu() - soft).abs().max()) < 1e-6 and torch.equal(hh.cpu(), hard)
         assert float((stats[:, 3].cpu() - soft.sum(1)).abs().max()) < 2e-2 and torch.equal(stats[:, 4].cpu(), hard.sum(1))
+
+
+def test_mha_small():
+    from mdqe_cvpr2023_amd import ops
+    import math
+    g = torch.Generator().manual_seed(8)
+    for B, Q, C, nh in ((5, 196, 256, 8), (2, 16, 256, 8), (3, 196, 192, 8)):
+        qk = torch.randn(B * Q, 2 * C, generator=g) * 2
+        v = torch.randn(B * Q, C, generator=g)
+        d = C // nh
+        q = qk[:, :C].view(B, Q, nh, d).transpose(1, 2)
+        k = qk[:, C:].view(B, Q, nh, d).transpose(1, 2)
+        vv = v.view(B, Q, nh, d).transpose(1, 2)
+        ref = (torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), -1) @ vv).transpose(1, 2).reshape(B * Q, C)
+        out = ops.mha_small(qk.cuda(), v.cuda(), B, Q, C, nh).cpu()
+        assert float((out - ref).abs().max()) < 2e-5
+
+
+def test_query_select_and_sampling():
+    from mdqe_cvpr2023_amd import ops
+    import mdqe_oracle as O
+    g = torch.Generator().manual_seed(12)
+    for (H, W, nb) in ((48, 80, 14), (8, 12, 4), (60, 108, 14)):
+        conf = torch.randn(3, H, W, 7, generator=g) * 2
+        ref = O.grid_guided_query_selection(conf, nb)
+        out = ops.query_select(conf.cuda(), nb).cpu()
+        bad = (out - ref).abs().amax(-1) > 1e-6
+        assert bad.float().mean() < 0.01                        # argmax may flip only on near-ties
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    starts = [0, 240, 300, 315]
+    tok = torch.randn(2, 321, 64, generator=g)
+    coords = torch.rand(2, 16, 2, generator=g)
+    coords[0, 0] = torch.tensor([0.0, 0.0]); coords[0, 1] = torch.tensor([0.999, 0.999])
+    grid = 2 * coords.view(2, 4, 4, 2) - 1
+    acc = 0
+    for (Hl, Wl), st in zip(shapes, starts):
+        f = tok[:, st:st + Hl * Wl].transpose(1, 2).reshape(2, 64, Hl, Wl)
+        acc = acc + F.grid_sample(f, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    ref = (acc / 4).flatten(2).transpose(1, 2)
+    out = ops.sample_levels_mean(tok.cuda(), coords.cuda(), shapes, starts).cpu()
+    assert float((out - ref).abs().max()) < 1e-5
+
+
+def test_final_masks():
+    from mdqe_cvpr2023_amd import ops
+    import mdqe_oracle as O
+    g = torch.Generator().manual_seed(4)
+    lg = torch.randn(5, 3, 16, 24, generator=g) * 2
+    h, w, Ho, Wo = 60, 90, 120, 180
+    up = O.aligned_bilinear(lg, 4).sigmoid()[..., :h, :w]
+    sel = [0, 2, 3]
+    ref = torch.stack([F.interpolate(up[i].unsqueeze(0), size=(Ho, Wo), mode="nearest").squeeze(0) > 0.5 for i in sel])
+    out = torch.zeros(3, 5, Ho, Wo, dtype=torch.uint8).cuda()
+    ops.final_masks(lg.cuda(), torch.tensor(sel, dtype=torch.int32).cuda(), 4, h, w, Ho, Wo, out, 1)
+    got = out.cpu().bool()
+    assert (got[:, 1:4] != ref).float().mean() < 1e-4
+    assert not got[:, 0].any() and not got[:, 4].any()

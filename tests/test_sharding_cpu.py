@@ -49,7 +49,7 @@ def replay(results):
     return outs
 
 
-def worker(rank, world, port, q):
+def worker(rank, world, port, outdir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -64,21 +64,20 @@ def worker(rank, world, port, q):
              "query_embeds": ((CFG.hidden_dim,), torch.float32), "pred_masks": ((T,) + HW, torch.float32)}
     merged = sharding.all_gather_clips(local, T, dist, world, torch.device("cpu"), proto)
     outs = replay(merged)
-    q.put((rank, [(s, e, l) for s, e, l, _ in merged], outs))
+    torch.save((rank, [(s, e, l) for s, e, l, _ in merged], outs), os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_equals_single_process():
+def test_two_rank_sharding_equals_single_process(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=180)
         assert p.exitcode == 0
+    got = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(2)]
     clips = clip_schedule(L, CFG.n_frames_test, 1)
     ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clips])
     for rank, order, outs in got:
