@@ -35,18 +35,6 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
         m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
-def aligned_bilinear(t, factor):
-    """mdqe/util/misc.py:485-507.  INTERIM-TORCH (HBM-bound upsample; to be fused with sigmoid/crop/threshold)."""
-    if factor == 1:
-        return t
-    h, w = t.shape[-2:]
-    t = F.pad(t, pad=(0, 1, 0, 1), mode="replicate")
-    oh, ow = factor * h + 1, factor * w + 1
-    t = F.interpolate(t, size=(oh, ow), mode="bilinear", align_corners=True)
-    t = F.pad(t, pad=(factor // 2, 0, factor // 2, 0), mode="replicate")
-    return t[:, :, :oh - 1, :ow - 1]
-
-
 class MDQE(nn.Module):
     def __init__(self, cfg, state_dict=None, backbone_fn=None, seed=0):
         super().__init__()

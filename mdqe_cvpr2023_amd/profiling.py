@@ -44,7 +44,7 @@ def stage_breakdown(model, frames_dev, chunk=30, n_clips=8):
         t_up += dt
     out["tracker_update"] = t_up / n_clips
     (c, m), out["tracker_get_result"] = _t(lambda: trk.get_result(True))
-    from .meta_arch import aligned_bilinear
-    _, out["upsample_sigmoid"] = _t(lambda: aligned_bilinear(m, ms).sigmoid()[..., :h, :w])
+    cls_clips, windows = [c], [(0, m.contiguous())]
+    _, out["inference_video"] = _t(lambda: model.inference_video((h, w), cls_clips, windows, (h, w), m.shape[1]))
     out["n_inst_clip"] = int(len(res["scores"]))
     return out
