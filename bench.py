@@ -175,7 +175,12 @@ def main():
         if g:
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_kernel<128,128,2,2>", "achieved": g["tflops"],
                                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / F32_MFMA_PEAK_TFLOPS,
-                                "traffic": None, "launches": g["launches"], "avg_launch_us": g["avg_us"]}
+                                # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_gemm_ffn1_*.csv),
+                                # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, for the bench's largest
+                                # launch shape (encoder FFN1 of a 30-frame chunk); algorithmic bytes of that shape beside it
+                                "traffic": 2 * 104835.6 * 1024 + 612000.0 * 1024, "traffic_shape": "M=153000 N=1024 K=256",
+                                "traffic_algorithmic": 4.0 * (153000 * 256 + 1024 * 256 + 153000 * 1024),
+                                "launches": g["launches"], "avg_launch_us": g["avg_us"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])
         print(json.dumps(line))

@@ -52,6 +52,9 @@ def load_library(path=None):
         raise LibraryMissing(
             f"{path} not found: build it with `make -C mdqe_cvpr2023_amd/csrc` (or "
             f"`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU/PyTorch fallback.")
+    # torch must bring ITS HIP runtime (torch/lib/libamdhip64.so) into the process first: the streams and device
+    # pointers we are handed belong to that runtime, and a libmdqe_hip.so loaded earlier would bind to /opt/rocm's copy.
+    import torch  # noqa: F401
     h = ctypes.CDLL(path)
     h.mdqe_version.restype = c_int
     h.mdqe_strerror.restype = c_char_p

@@ -10,6 +10,7 @@ Same call contract and output dict as MDQE.forward -> inference_vis -> inference
 detectron2 is importable the class is registered in its META_ARCH_REGISTRY under the name "MDQE".
 Training and the COCO single-image branch are out of scope and raise.
 """
+import contextlib
 from collections import OrderedDict
 
 import torch
@@ -49,6 +50,7 @@ class MDQE(nn.Module):
             _register(self, name, t.detach().clone().float(), buffer=name.endswith(("running_mean", "running_var")))
         self._extra = {k: v for k, v in sd.items() if k not in man}      # e.g. custom-backbone weights
         self.frame_batch = self.cfg.n_frames_window_test
+        self._trk_stream = None
         self.stage_times = None
 
     # ---- checkpoint contract ---------------------------------------------------------------------
@@ -116,20 +118,28 @@ class MDQE(nn.Module):
         h, w = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
         geo = eng.geometry(h, w)
         n_local = frames_dev.shape[0]
-        cache, base, nxt = None, 0, 0            # cache covers local frames [base, base + len)
-        i = 0
-        while i < len(clips):
-            ls, le = clips[i][0] - frame_offset, clips[i][1] - frame_offset
-            while nxt < le:                      # extend the frame cache up to the clip's last frame
-                c1 = min(n_local, nxt + self.frame_batch)
-                new = self._frame_cache(frames_dev[nxt:c1], geo)
-                if cache is None:
-                    cache, base = new, nxt
+        st = {"cache": None, "base": 0, "nxt": 0}  # cache covers local frames [base, base + len)
+
+        def prepare(ci):
+            """Extend the frame cache up to the last frame of clip `ci` (async launches only)."""
+            ls, le = clips[ci][0] - frame_offset, clips[ci][1] - frame_offset
+            while st["nxt"] < le:
+                c1 = min(n_local, st["nxt"] + self.frame_batch)
+                new = self._frame_cache(frames_dev[st["nxt"]:c1], geo)
+                if st["cache"] is None:
+                    st["cache"], st["base"] = new, st["nxt"]
                 else:
-                    keep = ls - base              # frames before the clip start are never needed again
-                    cache = {k: torch.cat([v[keep:], new[k]], 0) for k, v in cache.items()}
-                    base = ls
-                nxt = c1
+                    keep = ls - st["base"]        # frames before the clip start are never needed again
+                    st["cache"] = {k: torch.cat([v[keep:], new[k]], 0) for k, v in st["cache"].items()}
+                    st["base"] = ls
+                st["nxt"] = c1
+
+        i = 0
+        if clips:
+            prepare(0)
+        while i < len(clips):
+            cache, base, nxt = st["cache"], st["base"], st["nxt"]
+            ls, le = clips[i][0] - frame_offset, clips[i][1] - frame_offset
             # every further clip of the same length whose frames are already cached joins the batch:
             # clips are independent through the decoder, so they run as ONE pass (M = clips*T*Q rows)
             T = le - ls
@@ -139,11 +149,16 @@ class MDQE(nn.Module):
             group = clips[i:j]
             outs = eng.decode_clips(cache, [c[0] - frame_offset - base for c in group], T, geo)
             ress = eng.inference_clips(outs, [cache["mf"][c[0] - frame_offset - base:c[1] - frame_offset - base] for c in group])
+            ready = torch.cuda.Event()
+            ready.record()                        # the clip results are complete once this event fires
+            i = j
+            if i < len(clips):
+                prepare(i)                        # prefetch: the next chunk's per-frame work is queued before the tracker runs
             for (start, end, last), res in zip(group, ress):
                 if trace is not None:
                     trace.append({k: v.clone() for k, v in res.items() if torch.is_tensor(v)})
+                res["ready"] = ready
                 yield start, end, last, res
-            i = j
 
     def merge_clips(self, results, frame_hw, out_size, mask_hw):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""
@@ -154,19 +169,38 @@ class MDQE(nn.Module):
         merge_dev = self.device
         saved, tracker = 0, None
         cls_clips, windows, f_off = [], [], 0
+        # The tracker runs on its own HIP stream: its small kernels and its per-clip host syncs then overlap with the
+        # next chunk's per-frame work that the producer has already queued on the main stream.
+        use_side = merge_dev.type == "cuda"
+        main = torch.cuda.current_stream(merge_dev) if use_side else None
+        if use_side and self._trk_stream is None:
+            self._trk_stream = torch.cuda.Stream(merge_dev)
+        side = self._trk_stream if use_side else None
         for start, end, last, res in results:
-            if tracker is None:
-                tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
-                                      mask_hw, merge_dev, cfg.apply_cls_thres)
-            tracker.update(Clips(range(start, end), res))
-            if last or (start + stride >= win * (saved + 1)):
-                c, m = tracker.get_result(is_last_clip=last)        # m: mean logits [n, F, Hm, Wm] of this window
-                cls_clips.append(c)
-                windows.append((f_off, m.contiguous()))
-                f_off += m.shape[1]
-                saved += 1
+            ctx = torch.cuda.stream(side) if use_side else contextlib.nullcontext()
+            with ctx:
+                if use_side:
+                    if res.get("ready") is not None:
+                        side.wait_event(res["ready"])
+                    else:
+                        side.wait_stream(main)
+                    res["pred_masks"].record_stream(side)
+                if tracker is None:
+                    tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
+                                          mask_hw, merge_dev, cfg.apply_cls_thres)
+                tracker.update(Clips(range(start, end), res))
+                if last or (start + stride >= win * (saved + 1)):
+                    c, m = tracker.get_result(is_last_clip=last)    # m: mean logits [n, F, Hm, Wm] of this window
+                    cls_clips.append(c)
+                    windows.append((f_off, m.contiguous()))
+                    f_off += m.shape[1]
+                    saved += 1
             if last:
                 break
+        if use_side:
+            main.wait_stream(side)
+            for _, m in windows:
+                m.record_stream(main)
         return self.inference_video(out_size, cls_clips, windows, frame_hw, f_off)
 
     def to_device_frames(self, imgs):
