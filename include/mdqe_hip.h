@@ -88,6 +88,11 @@ int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias
                      int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
                      float* splitk_ws, void* stream);
 
+/* GEMM arithmetic of the 128x128 tile (process-wide): 0 = exact fp32 MFMA (default), 1 = "f16x3": operands split
+ * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752). */
+int mdqe_set_gemm_precision(int mode);
+int mdqe_get_gemm_precision(void);
+
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
  * X [NI,H,W,Cin] (Cin % 32 == 0; images x_img_stride floats apart, <=0: dense), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,
  * activation and residual (ResNet bottlenecks -- detectron2 build_resnet_backbone, call site

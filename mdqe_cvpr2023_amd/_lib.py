@@ -20,6 +20,7 @@ SIGNATURES = {
     "mdqe_query_select_f32": [p, i, i, i, i, i, p, p, p],
     "mdqe_sample_levels_mean_f32": [p, i, l, i, p, i, p, p, p, i, p, p],
     "mdqe_final_masks_u8": [p, i, p, i, i, i, i, i, i, i, i, p, l, i, p],
+    "mdqe_set_gemm_precision": [i],
     "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, i, p, i, i, i, p, p],
     "mdqe_mask_row_stats_f32": [p, i, i, i, i, i, p, p, p, p],
     "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p],
@@ -59,6 +60,8 @@ def load_library(path=None):
     h.mdqe_version.restype = c_int
     h.mdqe_strerror.restype = c_char_p
     h.mdqe_strerror.argtypes = [c_int]
+    h.mdqe_get_gemm_precision.restype = c_int
+    h.mdqe_get_gemm_precision.argtypes = []
     h.mdqe_groupnorm_workspace_bytes.restype = c_long
     h.mdqe_groupnorm_workspace_bytes.argtypes = [c_int, c_int]
     for name, args in SIGNATURES.items():

@@ -20,27 +20,7 @@
 // lanes 0-31 carry k = 4c..4c+3 of their row, lanes 32-63 carry the next four.
 #include "common.h"
 
-struct GemmParams {
-  const float* A; const float* W; float* C;
-  int M, N, K;
-  long lda, ldc;
-  // conv mode (KH > 0): A is NHWC [NI, H, W_, Cin]
-  int conv; int H, Wd, Cin, OH, OW, KH, KW, stride, pad;
-  // epilogue
-  const float* bias;        // [N] or null
-  const float* residual;    // [res_rows, ldr] or null, added after activation
-  long ldr; int res_mod;    // row index = res_mod > 0 ? m % res_mod : m
-  int res_first;            // 1: add residual BEFORE the activation (ResNet bottleneck), 0: after
-  long img_stride;          // conv mode: floats between consecutive images of X
-  const unsigned char* rowmask; int mask_cols;   // C[m, n < mask_cols] = 0 where rowmask[m] != 0
-  int act; int act_cols;    // activation on columns < act_cols (act_cols <= 0: all)
-  unsigned a_bytes, w_bytes;
-  int vec_ok;               // C/bias/residual are 16-B aligned with ld % 4 == 0: float4 epilogue
-  int ksplit, kchunk;       // split-K: blockIdx.y = split, K range [y*kchunk, (y+1)*kchunk); raw partials -> ws
-  float* ws;                // [ksplit][M][N] partial sums (deterministic two-pass reduction)
-};
-
-#define OOB_OFF 0xFFFFFFF0u
+#include "gemm_params.h"
 
 template <int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN)
@@ -292,6 +272,14 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
   return mdqe_launch_status();
 }
 
+static int g_gemm_precision = 0;      // 0: exact fp32 MFMA; 1: f16x3 split on the 128x128 tile (gemm_f16x3.hip)
+extern "C" int mdqe_set_gemm_precision(int mode) {
+  if (mode != 0 && mode != 1) return MDQE_EINVAL;
+  g_gemm_precision = mode;
+  return MDQE_OK;
+}
+extern "C" int mdqe_get_gemm_precision(void) { return g_gemm_precision; }
+
 static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   p.vec_ok = ((((uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.residual) & 15) == 0) && (p.ldc % 4 == 0) &&
              (p.residual == nullptr || p.ldr % 4 == 0);
@@ -301,6 +289,13 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
     else if (b128 >= 192) tile = 1;
     else tile = 3;
+  }
+  if (tile == 1 && g_gemm_precision == 1) {
+    int rc = mdqe_launch_gemm_f16x3(p, st);
+    if (rc || p.ksplit <= 1) return rc;
+    long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
+    return mdqe_launch_status();
   }
   switch (tile) {
     case 1: return launch_gemm<128, 128, 2, 2>(p, st);

@@ -1,0 +1,26 @@
+// Shared parameter block of the GEMM kernels (gemm.hip, gemm_f16x3.hip).
+#pragma once
+struct GemmParams {
+  const float* A; const float* W; float* C;
+  int M, N, K;
+  long lda, ldc;
+  // conv mode (KH > 0): A is NHWC [NI, H, W_, Cin]
+  int conv; int H, Wd, Cin, OH, OW, KH, KW, stride, pad;
+  // epilogue
+  const float* bias;        // [N] or null
+  const float* residual;    // [res_rows, ldr] or null, added after activation
+  long ldr; int res_mod;    // row index = res_mod > 0 ? m % res_mod : m
+  int res_first;            // 1: add residual BEFORE the activation (ResNet bottleneck), 0: after
+  long img_stride;          // conv mode: floats between consecutive images of X
+  const unsigned char* rowmask; int mask_cols;   // C[m, n < mask_cols] = 0 where rowmask[m] != 0
+  int act; int act_cols;    // activation on columns < act_cols (act_cols <= 0: all)
+  unsigned a_bytes, w_bytes;
+  int vec_ok;               // C/bias/residual are 16-B aligned with ld % 4 == 0: float4 epilogue
+  int ksplit, kchunk;       // split-K: blockIdx.y = split, K range [y*kchunk, (y+1)*kchunk); raw partials -> ws
+  float* ws;                // [ksplit][M][N] partial sums (deterministic two-pass reduction)
+};
+
+#define OOB_OFF 0xFFFFFFF0u
+
+// defined in gemm_f16x3.hip
+int mdqe_launch_gemm_f16x3(const GemmParams& p, hipStream_t st);

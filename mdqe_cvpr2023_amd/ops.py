@@ -12,6 +12,15 @@ ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "tanh": 4}
 _ws = {}
 
 
+def set_gemm_precision(mode):
+    """'f32' (exact fp32 MFMA) or 'f16x3' (split-precision f16 MFMA, ~1e-6 rel. to fp32) for the large-tile GEMM/conv."""
+    check(lib.mdqe_set_gemm_precision({"f32": 0, "f16x3": 1}[mode]), "set_gemm_precision")
+
+
+def get_gemm_precision():
+    return {0: "f32", 1: "f16x3"}[lib.mdqe_get_gemm_precision()]
+
+
 def _workspace(nbytes, device):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     t = _ws.get(key)

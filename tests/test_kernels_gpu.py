@@ -219,3 +219,34 @@ def test_final_masks():
     got = out.cpu().bool()
     assert (got[:, 1:4] != ref).float().mean() < 1e-4
     assert not got[:, 0].any() and not got[:, 4].any()
+
+
+def test_gemm_f16x3_accuracy():
+    """Split-precision GEMM/conv (f16 hi + scaled f16 lo, 3 MFMAs, fp32 accumulate) vs an fp64 reference: the error
+    must be of the order of the fp32 MFMA kernel's own error (<= 4x), i.e. ~1e-6 relative."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(21)
+    try:
+        for (M, N, K) in ((20000, 640, 256), (20000, 256, 1024), (3000, 1024, 256)):
+            x = torch.randn(M, K, generator=g) * 3
+            x[::7] *= 1e-3                                     # small rows: exercises the scaled low part
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            b = torch.randn(N, generator=g)
+            ref = (x.double() @ w.double().t() + b.double())
+            ops.set_gemm_precision("f32")
+            e32 = float((ops.linear(x.cuda(), w.cuda(), b.cuda(), tile=1).cpu().double() - ref).abs().max() / ref.abs().max())
+            ops.set_gemm_precision("f16x3")
+            o3 = ops.linear(x.cuda(), w.cuda(), b.cuda(), tile=1).cpu().double()
+            e3 = float((o3 - ref).abs().max() / ref.abs().max())
+            assert e3 < max(4 * e32, 2e-6), (M, N, K, e32, e3)
+            # per-row relative error on the small-magnitude rows too
+            rows = slice(0, M, 7)
+            er = float((o3[rows] - ref[rows]).abs().max() / ref[rows].abs().max())
+            assert er < 5e-6, er
+        # implicit-GEMM conv in split precision
+        xi = torch.randn(2, 256, 24, 40, generator=g); wc = torch.randn(256, 256, 3, 3, generator=g) / 48; bc = torch.randn(256, generator=g)
+        ref = F.conv2d(xi.double(), wc.double(), bc.double(), 1, 1)
+        out = ops.conv2d_nhwc(xi.permute(0, 2, 3, 1).contiguous().cuda(), wc.permute(0, 2, 3, 1).contiguous().cuda(), bc.cuda(), 1, 1, tile=1)
+        assert float((out.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    finally:
+        ops.set_gemm_precision("f32")

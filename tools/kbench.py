@@ -88,3 +88,11 @@ def bench_gemm(args):
 
 if __name__ == "__main__" and a.what in ("gemm", "all"):
     bench_gemm(a)
+
+
+if __name__ == "__main__" and a.what in ("gemm", "all"):
+    from mdqe_cvpr2023_amd import ops as _ops
+    _ops.set_gemm_precision("f16x3")
+    print("--- f16x3 ---")
+    bench_gemm(a)
+    _ops.set_gemm_precision("f32")
