@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--frames", type=int, default=120, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print a per-stage time breakdown (extra untimed step)")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
+                    help="GEMM arithmetic of the headline number: exact fp32 MFMA (default) or split-precision f16x3")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 pass reported as `fast_mode`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,21 +142,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        sync()
-        meter.enabled = True
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        sync()
-        dt = time.perf_counter() - t0
-        meter.enabled = False
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from mdqe_cvpr2023_amd import ops
+
+    def timed(precision, meter_on):
+        ops.set_gemm_precision(precision)
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                step()
+            sync()
+            meter.enabled = meter_on
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                o = step()
+            sync()
+            d = time.perf_counter() - t0
+            meter.enabled = False
+        if dist is not None:
+            t = torch.tensor([d], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d, o
+
+    dt, out = timed(args.precision, True)
+    fast = None
+    if args.precision == "f32" and not args.no_fast_mode:
+        dt3, _ = timed("f16x3", False)
+        fast = {"gemm": "f16x3 split precision (fp32 in/out, 3 f16 MFMAs, ~1e-6 rel. to fp32; same parity tests)",
+                "value": L * args.steps / dt3, "unit": "frames/s", "ms_per_step": 1e3 * dt3 / args.steps}
+    ops.set_gemm_precision("f32")
 
     if args.stages and rank == 0:
         from mdqe_cvpr2023_amd import profiling
@@ -170,17 +186,21 @@ def main():
                                    "stride 1, 30-frame windows, random-init weights (zero-init trap removed)" % args.frames,
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
                        "instances_out": len(out["pred_scores"]),
+                       "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
                        "parallelism": "1 process/GPU; frame-range shards + RCCL all-gather of clip results" if world > 1 else "single GPU"},
         }
         if g:
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_kernel<128,128,2,2>", "achieved": g["tflops"],
-                                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                                "peak": F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3, "unit": "TFLOP/s",
+                                "frac": g["tflops"] / (F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3),
                                 # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_gemm_ffn1_*.csv),
                                 # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, for the bench's largest
                                 # launch shape (encoder FFN1 of a 30-frame chunk); algorithmic bytes of that shape beside it
                                 "traffic": 2 * 104835.6 * 1024 + 612000.0 * 1024, "traffic_shape": "M=153000 N=1024 K=256",
                                 "traffic_algorithmic": 4.0 * (153000 * 256 + 1024 * 256 + 153000 * 1024),
                                 "launches": g["launches"], "avg_launch_us": g["avg_us"]}
+        if fast:
+            line["fast_mode"] = fast
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])
         print(json.dumps(line))

@@ -272,7 +272,7 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
   return mdqe_launch_status();
 }
 
-static int g_gemm_precision = 0;      // 0: exact fp32 MFMA; 1: f16x3 split on the 128x128 tile (gemm_f16x3.hip)
+static int g_gemm_precision = 0;      // 0: exact fp32 MFMA; 1: f16x3 split on the 128-row tiles (gemm_f16x3.hip)
 extern "C" int mdqe_set_gemm_precision(int mode) {
   if (mode != 0 && mode != 1) return MDQE_EINVAL;
   g_gemm_precision = mode;
@@ -290,8 +290,8 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     else if (b128 >= 192) tile = 1;
     else tile = 3;
   }
-  if (tile == 1 && g_gemm_precision == 1) {
-    int rc = mdqe_launch_gemm_f16x3(p, st);
+  if ((tile == 1 || tile == 2) && g_gemm_precision == 1) {
+    int rc = mdqe_launch_gemm_f16x3(p, tile, st);
     if (rc || p.ksplit <= 1) return rc;
     long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);

@@ -241,10 +241,11 @@ gemm_nt_f16x3_kernel(const GemmParams p) {
   }
 }
 
-int mdqe_launch_gemm_f16x3(const GemmParams& p, hipStream_t st) {
-  constexpr int BM = 128, BN = 128;
+template <int BM, int BN>
+static int launch_f16x3(const GemmParams& p, hipStream_t st) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t smem = (size_t)BM * BN * sizeof(float);       // == 2 stages x 2 planes x 256 rows x 64 B
+  size_t smem = (size_t)2 * 2 * (BM + BN) * 32 * sizeof(_Float16);     // 2 stages x (hi, lo) planes
+  if (smem < (size_t)BM * BN * sizeof(float)) smem = (size_t)BM * BN * sizeof(float);
   auto kern = gemm_nt_f16x3_kernel<BM, BN, 2, 2>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -253,4 +254,8 @@ int mdqe_launch_gemm_f16x3(const GemmParams& p, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(256), smem, st, p);
   return mdqe_launch_status();
+}
+
+int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st) {
+  return tile == 2 ? launch_f16x3<128, 64>(p, st) : launch_f16x3<128, 128>(p, st);
 }

@@ -23,4 +23,4 @@ struct GemmParams {
 #define OOB_OFF 0xFFFFFFF0u
 
 // defined in gemm_f16x3.hip
-int mdqe_launch_gemm_f16x3(const GemmParams& p, hipStream_t st);
+int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st);

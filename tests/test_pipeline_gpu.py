@@ -11,6 +11,16 @@ from _golden import Fixture, maxdiff
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["f32", "f16x3"], autouse=True)
+def gemm_precision(request):
+    """Every pipeline parity test runs in both GEMM modes with the SAME tolerances: exact fp32 MFMA and the
+    split-precision f16x3 kernel."""
+    from mdqe_cvpr2023_amd import ops
+    ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision("f32")
+
+
 def small_cfg(**kw):
     from mdqe_cvpr2023_amd.config import MDQEConfig
     d = dict(backbone="custom", backbone_channels=(16, 24, 32), enc_layers=2, dec_layers=2, n_frames=3, num_classes=5,
