@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
                     help="GEMM arithmetic of the headline number: exact fp32 MFMA (default) or split-precision f16x3")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 pass reported as `fast_mode`")
+    ap.add_argument("--config", choices=["R50_ovis_360", "R50_ovis_720"], default="R50_ovis_360",
+                    help="R50_ovis_360 is BASELINE.json's metric config; R50_ovis_720 = 640x1138 frames (configs[2])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,12 +116,13 @@ def main():
 
     from mdqe_cvpr2023_amd import _lib
     _lib.load_library()                                   # loud if the HIP library is missing
-    from mdqe_cvpr2023_amd.config import R50_OVIS_360
+    from mdqe_cvpr2023_amd.config import PRESETS
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     from mdqe_cvpr2023_amd.params import random_state
     from mdqe_cvpr2023_amd import sharding
 
-    cfg = R50_OVIS_360
+    cfg = PRESETS[args.config]
+    fh, fw = (360, 640) if args.config == "R50_ovis_360" else (640, 1138)
     sd = random_state(cfg, seed=0)
     model = MDQE(cfg, state_dict=sd).eval()
     meter = GemmMeter()
@@ -127,15 +130,15 @@ def main():
 
     L = args.frames * world
     T = cfg.n_frames_test
-    video = synth_video(L, seed=0)                        # identical on all ranks; each keeps its shard (+halo) in HBM
+    video = synth_video(L, seed=0, h=fh, w=fw)            # identical on all ranks; each keeps its shard (+halo) in HBM
     f0, f1 = sharding.frame_range(L, world, rank, T, cfg.clip_stride)
     shard = video[f0:f1].cuda()
     torch.cuda.synchronize()
 
     def step():
         if world == 1:
-            return model([{"image": shard, "height": 360, "width": 640}])
-        return sharding.run_sharded(model, shard, f0, L, rank, world, dist, out_size=(360, 640))
+            return model([{"image": shard, "height": fh, "width": fw}])
+        return sharding.run_sharded(model, shard, f0, L, rank, world, dist, out_size=(fh, fw))
 
     def sync():
         if dist is not None:
@@ -179,11 +182,12 @@ def main():
     if rank == 0:
         g = meter.summary()
         line = {
-            "metric": "frames/sec (eval-only) R50 OVIS 360p 4-frame clip", "value": L * args.steps / dt, "unit": "frames/s",
+            "metric": "frames/sec (eval-only) R50 OVIS %s 4-frame clip" % ("360p" if args.config == "R50_ovis_360" else "640p"), "value": L * args.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "R50_ovis_360 eval-only: %d synthetic 360x640 uint8 frames per GPU per step, 4-frame clips "
-                                   "stride 1, 30-frame windows, random-init weights (zero-init trap removed)" % args.frames,
+            "config": {"workload": "%s eval-only: %d synthetic %dx%d uint8 frames per GPU per step, 4-frame clips stride 1, "
+                                   "%d-frame windows, random-init weights (zero-init trap removed)"
+                                   % (args.config, args.frames, fh, fw, cfg.n_frames_window_test),
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
                        "instances_out": len(out["pred_scores"]),
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",

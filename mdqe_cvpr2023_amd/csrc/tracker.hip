@@ -16,16 +16,20 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return r;
 }
 
-// out[i, j] = (inter, |saved_i|, |input_j|) over n contiguous floats per row pair.
+// out[i, j] += (inter, |saved_i|, |input_j|) over n contiguous floats per row pair.  The pixel range is cut into
+// gridDim.z chunks so that even a 1x1 pair fills the chip; partial counts are integers, so the float atomicAdd
+// accumulation is exact and order-independent (deterministic).  `out` is zeroed by the launcher.
 __global__ void __launch_bounds__(256)
 trk_siou_kernel(const float* __restrict__ saved, long saved_stride, const float* __restrict__ inp, long inp_stride,
                 long n, float* __restrict__ out, int n_in) {
   __shared__ float sh[4];
   const int i = blockIdx.y, j = blockIdx.x;
+  const long per = ((n / 4 + gridDim.z - 1) / gridDim.z) * 4;
+  const long k0 = (long)blockIdx.z * per, k1 = min(n, k0 + per);
   const float* a = saved + (long)i * saved_stride;
   const float* b = inp + (long)j * inp_stride;
   float ci = 0.f, ca = 0.f, cb = 0.f;
-  for (long k = (long)threadIdx.x * 4; k < n; k += 1024) {
+  for (long k = k0 + (long)threadIdx.x * 4; k < k1; k += 1024) {
     const f32x4 va = *reinterpret_cast<const f32x4*>(a + k);
     const f32x4 vb = *reinterpret_cast<const f32x4*>(b + k);
 #pragma unroll
@@ -37,7 +41,7 @@ trk_siou_kernel(const float* __restrict__ saved, long saved_stride, const float*
   ci = block_sum(ci, sh); ca = block_sum(ca, sh); cb = block_sum(cb, sh);
   if (threadIdx.x == 0) {
     float* o = out + ((long)i * n_in + j) * 3;
-    o[0] = ci; o[1] = ca; o[2] = cb;
+    atomicAdd(o, ci); atomicAdd(o + 1, ca); atomicAdd(o + 2, cb);
   }
 }
 
@@ -48,7 +52,12 @@ extern "C" int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_sa
   MDQE_CHECK_PTR(saved); MDQE_CHECK_PTR(inp); MDQE_CHECK_PTR(out3);
   MDQE_REQUIRE((((uintptr_t)saved | (uintptr_t)inp) & 15) == 0);
   mdqe_clear_error();
-  hipLaunchKernelGGL(trk_siou_kernel, dim3(n_in, n_saved), dim3(256), 0, (hipStream_t)stream, saved, saved_stride, inp,
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out3, 0, (size_t)n_saved * n_in * 3 * sizeof(float), st) != hipSuccess) return MDQE_ELAUNCH;
+  int chunks = 1;
+  const long pairs = (long)n_saved * n_in;
+  if (pairs < 512) { chunks = (int)(512 / pairs); const long maxc = (n / 4 + 1023) / 1024; if (chunks > maxc) chunks = (int)maxc; if (chunks < 1) chunks = 1; }
+  hipLaunchKernelGGL(trk_siou_kernel, dim3(n_in, n_saved, chunks), dim3(256), 0, st, saved, saved_stride, inp,
                      inp_stride, n, out3, n_in);
   return mdqe_launch_status();
 }

@@ -385,12 +385,14 @@ class Engine:
         emb = self._mlp(content.view(-1, C), self.P.track_embed).view(NI, nb * nb, -1)
         return coords, content, emb
 
-    def dec_values(self, enc, geo):
+    def dec_values(self, enc, geo, out=None):
         """All decoder value_proj's (cross_attn + temp_attn_inst of every layer) for each frame, once:
         value = masked_fill(Linear(x)) (ms_deform_attn.py:136-139,193-196) -> [NI, N, n_val*C]."""
         NI, N, C = enc.shape
+        if out is not None:
+            out = out.view(NI * N, -1)
         return ops.linear(enc.view(-1, C), self.P.dec_vw, self.P.dec_vb, rowmask=geo.rowmask(NI),
-                          mask_cols=self.P.dec_vw.shape[0]).view(NI, N, -1)
+                          mask_cols=self.P.dec_vw.shape[0], out=out).view(NI, N, -1)
 
     # ---- a11 (association) + a12-a14: decoder over one clip ---------------------------------------
     def _mha(self, sa, qk_in, v_in, nh):

@@ -87,16 +87,23 @@ class MDQE(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):           # neutralise ambient autocast
             return self.inference_vis(batched_inputs)
 
-    def _frame_cache(self, frames, geo):
-        """Per-frame stages a1-a11 for a batch of frames: everything a clip needs, computed once."""
+    def _frame_cache(self, frames, geo, ring=None, at=0):
+        """Per-frame stages a1-a11 for a batch of frames: everything a clip needs, computed once.  With `ring`
+        (preallocated per-frame buffers) the results land in ring[k][at:at+n] -- the 63 MB/frame decoder value
+        cache is written there directly by its GEMM."""
         eng = self.engine
+        n = frames.shape[0]
         feats = eng.backbone(frames, geo)
         enc = eng.encode(feats, geo)
         del feats
         mf = eng.mask_features(enc, geo)
         coords, content, emb = eng.frame_queries(enc, geo)
-        vals = eng.dec_values(enc, geo)
-        return {"mf": mf, "coords": coords, "content": content, "emb": emb, "vals": vals}
+        if ring is None:
+            return {"mf": mf, "coords": coords, "content": content, "emb": emb, "vals": eng.dec_values(enc, geo)}
+        eng.dec_values(enc, geo, out=ring["vals"][at:at + n])
+        for k, v in (("mf", mf), ("coords", coords), ("content", content), ("emb", emb)):
+            ring[k][at:at + n].copy_(v)
+        return None
 
     @staticmethod
     def clip_schedule(L, T, stride):
@@ -118,20 +125,35 @@ class MDQE(nn.Module):
         h, w = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
         geo = eng.geometry(h, w)
         n_local = frames_dev.shape[0]
-        st = {"cache": None, "base": 0, "nxt": 0}  # cache covers local frames [base, base + len)
+        # Frame cache = preallocated ring of (T-1 carried + frame_batch new) frames; no concatenations, no re-allocation.
+        Tmax = max((c[1] - c[0] for c in clips), default=1)
+        cap = Tmax - 1 + self.frame_batch
+        st = {"cache": None, "ring": None, "base": 0, "count": 0, "nxt": 0}   # ring holds local frames [base, base+count)
 
         def prepare(ci):
             """Extend the frame cache up to the last frame of clip `ci` (async launches only)."""
             ls, le = clips[ci][0] - frame_offset, clips[ci][1] - frame_offset
             while st["nxt"] < le:
                 c1 = min(n_local, st["nxt"] + self.frame_batch)
-                new = self._frame_cache(frames_dev[st["nxt"]:c1], geo)
-                if st["cache"] is None:
-                    st["cache"], st["base"] = new, st["nxt"]
+                n_new = c1 - st["nxt"]
+                if st["ring"] is None:
+                    first = self._frame_cache(frames_dev[st["nxt"]:c1], geo)
+                    st["ring"] = {k: torch.empty((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for k, v in first.items()}
+                    for k, v in first.items():
+                        st["ring"][k][:n_new].copy_(v)
+                    st["base"], st["count"] = st["nxt"], n_new
+                    del first
                 else:
-                    keep = ls - st["base"]        # frames before the clip start are never needed again
-                    st["cache"] = {k: torch.cat([v[keep:], new[k]], 0) for k, v in st["cache"].items()}
-                    st["base"] = ls
+                    shift = ls - st["base"]        # frames before the clip start are never needed again
+                    keep = st["count"] - shift
+                    if shift > 0:
+                        for k, v in st["ring"].items():
+                            if keep > 0:
+                                v[:keep].copy_(v[shift:st["count"]].clone())
+                        st["base"], st["count"] = ls, max(keep, 0)
+                    self._frame_cache(frames_dev[st["nxt"]:c1], geo, ring=st["ring"], at=st["count"])
+                    st["count"] += n_new
+                st["cache"] = {k: v[:st["count"]] for k, v in st["ring"].items()}
                 st["nxt"] = c1
 
         i = 0
