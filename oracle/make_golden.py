@@ -352,6 +352,30 @@ def gen_tracker():
     save("tracker_seq", n_clips=n_clip, n_windows=saved, T=T, WIN=WIN, K=K, E=E, HW=np.array(HW), MAXI=MAXI, THR=THR, **arrs)
 
 
+def gen_swin():
+    """Small SwinV2 (embed 32, heads 2/4/8/16 -> head dim 16, window 4 / last stage 2) on 2 x 64x96: exercises window
+    padding (4x6 and 2x3 maps), cyclic shift masks, cosine attention with CPB bias, res-post-norm, patch merging."""
+    sw = refshim.ref("mdqe.backbone.swin_transformer_v2")
+    g = torch.Generator().manual_seed(66)
+    torch.manual_seed(66)
+    m = sw.SwinTransformerV2(patch_size=4, in_chans=3, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16], window_size=4,
+                             mlp_ratio=4, drop_path_rate=0.0, out_features=["stage3", "stage4", "stage5"])
+    m.eval()                                  # SwinTransformerV2.train() returns None (swin_transformer_v2.py:661-664)
+    manifest = apply_synth(m, seed=6, prefix="bb.")
+    with torch.no_grad():                     # logit_scale / q_bias etc. got synthetic values; keep logit_scale in a sane range
+        for n, p_ in m.named_parameters():
+            if n.endswith("logit_scale"):
+                p_.copy_(torch.log(torch.full_like(p_, 10.0)) + 0.3 * torch.randn(p_.shape, generator=g))
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    with torch.no_grad():
+        outs = m(x)
+    arrs = {"x": x}
+    arrs.update({k: v for k, v in outs.items()})
+    arrs.update({"ls::" + n: p_ for n, p_ in m.named_parameters() if n.endswith("logit_scale")})
+    arrs.update(manifest_to_arrays(manifest))
+    save("swin_small", synth_seed=6, **arrs)
+
+
 def gen_layer256():
     """One encoder layer + one decoder layer at the real width (C=256, D=32) on a small map."""
     enc_mod = refshim.ref("mdqe.models.transformer_enc")
@@ -388,3 +412,4 @@ if __name__ == "__main__":
         gen_layer256()
         gen_video()
         gen_tracker()
+        gen_swin()

@@ -826,3 +826,133 @@ def inference_vis(sd, hp: Hyper, frames: List[Tensor], backbone_fn, out_size=Non
         if last:
             break
     return inference_video(hp, out_size, cls_clips, mask_clips)
+
+
+# --------------------------------------------------------------------------------------------
+# a4': SwinV2 backbone (mdqe/backbone/swin_transformer_v2.py)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class SwinHyper:
+    embed_dim: int = 192
+    depths: Tuple[int, ...] = (2, 2, 18, 2)
+    num_heads: Tuple[int, ...] = (6, 12, 24, 48)
+    window_size: int = 12
+    mlp_ratio: float = 4.0
+    out_stages: Tuple[int, ...] = (1, 2, 3)        # stage3, stage4, stage5
+
+
+def _window_partition(x, ws):
+    B, H, W, C = x.shape
+    x = x.view(B, H // ws, ws, W // ws, ws, C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
+
+
+def _window_reverse(w, ws, H, W):
+    B = int(w.shape[0] / (H * W / ws / ws))
+    x = w.view(B, H // ws, W // ws, ws, ws, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def swin_rel_tables(ws):
+    """relative_coords_table [1,2ws-1,2ws-1,2] and relative_position_index [ws*ws, ws*ws] (WindowAttention.__init__,
+    swin_transformer_v2.py:101-131, pretrained_window_size = 0)."""
+    rh = torch.arange(-(ws - 1), ws, dtype=torch.float32)
+    tab = torch.stack(torch.meshgrid([rh, rh], indexing="ij")).permute(1, 2, 0).contiguous().unsqueeze(0)
+    tab = tab / (ws - 1) * 8
+    tab = torch.sign(tab) * torch.log2(torch.abs(tab) + 1.0) / np.log2(8)
+    c = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return tab, rel.sum(-1)
+
+
+def swin_attn_bias(sd, p, ws, nh):
+    """16*sigmoid(cpb_mlp(table))[index] -> [nh, N, N] (swin_transformer_v2.py:164-169)."""
+    tab, idx = swin_rel_tables(ws)
+    t = F.linear(F.relu(F.linear(tab, sd[p + ".cpb_mlp.0.weight"], sd[p + ".cpb_mlp.0.bias"])), sd[p + ".cpb_mlp.2.weight"])
+    b = t.view(-1, nh)[idx.view(-1)].view(ws * ws, ws * ws, nh).permute(2, 0, 1).contiguous()
+    return 16 * torch.sigmoid(b)
+
+
+def swin_shift_mask(H, W, ws):
+    """BasicLayer.forward mask build (swin_transformer_v2.py:397-415)."""
+    ss = ws // 2
+    Hp, Wp = int(np.ceil(H / ws)) * ws, int(np.ceil(W / ws)) * ws
+    img = torch.zeros(1, Hp, Wp, 1)
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+        for w in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+            img[:, h, w, :] = cnt
+            cnt += 1
+    mw = _window_partition(img, ws).view(-1, ws * ws)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+
+
+def swin_block(sd, p, x, H, W, ws, shift, nh, mask):
+    """SwinTransformerBlock.forward + WindowAttention.forward (swin_transformer_v2.py:147-186,236-290)."""
+    B, L, C = x.shape
+    shortcut = x
+    x = x.view(B, H, W, C)
+    pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+    x = F.pad(x, (0, 0, 0, pr, 0, pb))
+    Hp, Wp = x.shape[1], x.shape[2]
+    if shift > 0:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = _window_partition(x, ws).view(-1, ws * ws, C)
+    a = p + ".attn"
+    bias = torch.cat((sd[a + ".q_bias"], torch.zeros_like(sd[a + ".v_bias"]), sd[a + ".v_bias"]))
+    qkv = F.linear(xw, sd[a + ".qkv.weight"], bias).reshape(xw.shape[0], ws * ws, 3, nh, -1).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
+    attn = attn * torch.clamp(sd[a + ".logit_scale"], max=math.log(1. / 0.01)).exp()
+    attn = attn + swin_attn_bias(sd, a, ws, nh).unsqueeze(0)
+    if shift > 0:
+        nW = mask.shape[0]
+        attn = (attn.view(-1, nW, nh, ws * ws, ws * ws) + mask.unsqueeze(1).unsqueeze(0)).view(-1, nh, ws * ws, ws * ws)
+    attn = attn.softmax(-1)
+    o = (attn @ v).transpose(1, 2).reshape(xw.shape[0], ws * ws, C)
+    o = _lin(sd, a + ".proj", o).view(-1, ws, ws, C)
+    x = _window_reverse(o, ws, Hp, Wp)
+    if shift > 0:
+        x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
+    x = x[:, :H, :W, :].contiguous().view(B, H * W, C)
+    x = shortcut + _ln(sd, p + ".norm1", x)                                    # res-post-norm (:287-288)
+    return x + _ln(sd, p + ".norm2", _lin(sd, p + ".mlp.fc2", F.gelu(_lin(sd, p + ".mlp.fc1", x))))
+
+
+def swin_patch_merge(sd, p, x, H, W):
+    """PatchMerging.forward (swin_transformer_v2.py:311-335)."""
+    B, L, C = x.shape
+    x = x.view(B, H, W, C)
+    if H % 2 == 1 or W % 2 == 1:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).view(B, -1, 4 * C)
+    return _ln(sd, p + ".norm", F.linear(x, sd[p + ".reduction.weight"]))
+
+
+def swinv2(sd, p, x, sh: SwinHyper):
+    """SwinTransformerV2.forward (swin_transformer_v2.py:639-659): x [B,3,H,W] -> [stage3, stage4, stage5] NCHW."""
+    if x.shape[3] % 4:
+        x = F.pad(x, (0, 4 - x.shape[3] % 4))
+    if x.shape[2] % 4:
+        x = F.pad(x, (0, 0, 0, 4 - x.shape[2] % 4))
+    x = F.conv2d(x, sd[p + ".patch_embed.proj.weight"], sd[p + ".patch_embed.proj.bias"], stride=4)
+    H, W = x.shape[2], x.shape[3]
+    x = _ln(sd, p + ".patch_embed.norm", x.flatten(2).transpose(1, 2))
+    outs = []
+    nl = len(sh.depths)
+    for i in range(nl):
+        ws = sh.window_size // 2 if i == nl - 1 else sh.window_size
+        mask = swin_shift_mask(H, W, ws)
+        for j in range(sh.depths[i]):
+            x = swin_block(sd, f"{p}.layers.{i}.blocks.{j}", x, H, W, ws, 0 if j % 2 == 0 else ws // 2, sh.num_heads[i], mask)
+        if i in sh.out_stages:
+            o = _ln(sd, f"{p}.norm{i}", x)
+            outs.append(o.view(-1, H, W, o.shape[-1]).permute(0, 3, 1, 2).contiguous())
+        if i < nl - 1:
+            x = swin_patch_merge(sd, f"{p}.layers.{i}.downsample", x, H, W)
+            H, W = (H + 1) // 2, (W + 1) // 2
+    return outs

@@ -19,7 +19,7 @@ import torch
 
 # buffers that are *defined* by formulas in the reference and must be kept, not synthesised
 KEEP_SUFFIXES = ("cross_attn.sampling_offsets", "temp_attn_inst.sampling_offsets", "lvl_spatial_scales",
-                 "query_relpos_grid", "num_batches_tracked")
+                 "query_relpos_grid", "num_batches_tracked", "relative_coords_table")
 
 
 def _kind(name: str, shape: Tuple[int, ...]) -> str:

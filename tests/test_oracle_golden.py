@@ -219,3 +219,23 @@ def resnet50_manifest(p="bb"):
             conv(q + ".conv3", cout, mid, 1)
             cin = cout
     return m
+
+
+def swin_small_state(fx):
+    sd = fx.state()
+    for k in fx.z.files:
+        if k.startswith("ls::"):
+            sd["bb." + k[4:]] = fx.t(k)
+    return sd
+
+
+def test_swinv2_backbone():
+    """SwinTransformerV2.forward (mdqe/backbone/swin_transformer_v2.py:639-659) incl. padded windows and shift masks."""
+    fx = Fixture("swin_small")
+    sd = swin_small_state(fx)
+    sh = O.SwinHyper(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16), window_size=4)
+    outs = O.swinv2(sd, "bb", fx.t("x"), sh)
+    for o, name in zip(outs, ("stage3", "stage4", "stage5")):
+        ref = fx.t(name)
+        assert o.shape == ref.shape
+        assert maxdiff(o, ref) < TOL
