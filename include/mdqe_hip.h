@@ -173,6 +173,24 @@ int mdqe_final_masks_u8(const float* logits, int n_sel, const int* inst_idx_dev,
                         int h, int w, int Ho, int Wo, unsigned char* out, long out_inst_stride, int f_off,
                         void* stream);
 
+/* ---- SwinV2 backbone (mdqe/backbone/swin_transformer_v2.py) --------------------------------------------
+ * layernorm_post: y = LN(x)*gamma + beta + post (res-post-norm :287-288).
+ * patch4_im2col: normalise + zero-pad + 4x4/s4 im2col, k = c*16+kh*4+kw -> [NI*Hp/4*Wp/4, 48] (PatchEmbed :466-479).
+ * swin_window: mode 0 gathers the zero-padded, cyclically shifted map into window-ordered rows [B*nW*ws*ws, C];
+ *              mode 1 writes dst[b,y,x,:] = shortcut[b,y,x,:] + rows (window reverse + un-shift + crop, :252-288).
+ * window_attn: cosine attention of WindowAttention.forward (:147-186) on qkv rows [n_windows*N, 3C]; scale [nh] =
+ *              exp(clamp(logit_scale)), bias [nh,N,N] = 16*sigmoid(cpb), mask [nW,N,N] or NULL (device arrays).
+ * patch_merge_gather: [B,H,W,C] -> [B*ceil(H/2)*ceil(W/2), 4C] in the order x0|x1|x2|x3 of PatchMerging (:311-335). */
+int mdqe_layernorm_post_f32(const float* x, const float* gamma, const float* beta, const float* post, float* y,
+                            long rows, int C, float eps, void* stream);
+int mdqe_patch4_im2col_f32(const void* frames, int is_u8, long frame_stride, int NI, int h, int w, int Hp, int Wp,
+                           const float* mean3_host, const float* std3_host, float* out, void* stream);
+int mdqe_swin_window_f32(const float* src, const float* shortcut, float* dst, int B, int H, int W, int C, int ws,
+                         int shift, int mode, void* stream);
+int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int N, int C, int nh,
+                         const float* scale, const float* bias, const float* mask, int nW, void* stream);
+int mdqe_patch_merge_gather_f32(const float* x, float* out, int B, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

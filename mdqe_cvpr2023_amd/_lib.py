@@ -21,6 +21,11 @@ SIGNATURES = {
     "mdqe_sample_levels_mean_f32": [p, i, l, i, p, i, p, p, p, i, p, p],
     "mdqe_final_masks_u8": [p, i, p, i, i, i, i, i, i, i, i, p, l, i, p],
     "mdqe_set_gemm_precision": [i],
+    "mdqe_layernorm_post_f32": [p, p, p, p, p, l, i, f, p],
+    "mdqe_patch4_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],
+    "mdqe_swin_window_f32": [p, p, p, i, i, i, i, i, i, i, p],
+    "mdqe_window_attn_f32": [p, l, p, l, i, i, i, i, p, p, p, i, p],
+    "mdqe_patch_merge_gather_f32": [p, p, i, i, i, i, p],
     "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, i, p, i, i, i, p, p],
     "mdqe_mask_row_stats_f32": [p, i, i, i, i, i, p, p, p, p],
     "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p],

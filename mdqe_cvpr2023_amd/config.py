@@ -12,7 +12,12 @@ from typing import Tuple
 
 @dataclass
 class MDQEConfig:
-    backbone: str = "R50"                     # "R50" | "R101" | "custom"
+    backbone: str = "R50"                     # "R50" | "R101" | "SwinV2" | "custom"
+    swin_embed_dim: int = 192                 # MODEL.SWIN.* (mdqe/backbone/config.py:60-75, configs/swinl_coco.yaml)
+    swin_depths: Tuple[int, ...] = (2, 2, 18, 2)
+    swin_heads: Tuple[int, ...] = (6, 12, 24, 48)
+    swin_window: int = 12
+    swin_mlp_ratio: float = 4.0
     backbone_channels: Tuple[int, ...] = (512, 1024, 2048)
     backbone_strides: Tuple[int, ...] = (8, 16, 32)
     hidden_dim: int = 256
@@ -62,14 +67,23 @@ class MDQEConfig:
 
 R50_OVIS_360 = MDQEConfig()
 R50_OVIS_720 = replace(R50_OVIS_360, n_frames_window_test=20, merge_on_cpu=True, apply_cls_thres=0.2, min_size_test=640)
-PRESETS = {"R50_ovis_360": R50_OVIS_360, "R50_ovis_720": R50_OVIS_720}
+SWINL_OVIS = MDQEConfig(backbone="SwinV2", backbone_channels=(384, 768, 1536), hidden_dim=192, n_frames=2, n_frames_test=2,
+                        n_frames_window_test=20, merge_on_cpu=True, apply_cls_thres=0.1, min_size_test=480)
+PRESETS = {"R50_ovis_360": R50_OVIS_360, "R50_ovis_720": R50_OVIS_720, "swinl_ovis": SWINL_OVIS}
 
 
 def from_d2_cfg(cfg) -> MDQEConfig:
     m = cfg.MODEL.MDQE
     depth = getattr(getattr(cfg.MODEL, "RESNETS", None), "DEPTH", 50)
+    name = getattr(getattr(cfg.MODEL, "BACKBONE", None), "NAME", "build_resnet_backbone")
+    swin = {}
+    if "swinv2" in name:
+        sw = cfg.MODEL.SWIN
+        swin = dict(backbone="SwinV2", swin_embed_dim=sw.EMBED_DIM, swin_depths=tuple(sw.DEPTHS), swin_heads=tuple(sw.NUM_HEADS),
+                    swin_window=sw.WINDOW_SIZE, swin_mlp_ratio=sw.MLP_RATIO,
+                    backbone_channels=tuple(sw.EMBED_DIM * 2 ** i for i in (1, 2, 3)))
     return MDQEConfig(
-        backbone="R%d" % depth,
+        **({"backbone": "R%d" % depth} if not swin else swin),
         hidden_dim=m.HIDDEN_DIM, nheads=m.NHEADS, enc_layers=m.ENC_LAYERS, dec_layers=m.DEC_LAYERS,
         n_levels=m.NUM_FEATURE_LEVELS, enc_points=m.ENC_NUM_POINTS, dec_points=m.DEC_NUM_POINTS,
         n_frames=cfg.INPUT.SAMPLING_FRAME_NUM, num_classes=m.NUM_CLASSES, num_queries=m.NUM_OBJECT_QUERIES,

@@ -13,7 +13,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int NCH>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
-                 const float* __restrict__ beta, float* __restrict__ y, long rows, int C, float eps) {
+                 const float* __restrict__ beta, const float* __restrict__ post, float* __restrict__ y, long rows, int C, float eps) {
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nw = (long)gridDim.x * (blockDim.x >> 6);
@@ -48,14 +48,16 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
       if (c < C) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
         const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
-        *reinterpret_cast<f32x4*>(y + r * C + c) = (v[i] - mean) * rstd * g + b;
+        f32x4 o = (v[i] - mean) * rstd * g + b;
+        if (post != nullptr) o += *reinterpret_cast<const f32x4*>(post + r * C + c);
+        *reinterpret_cast<f32x4*>(y + r * C + c) = o;
       }
     }
   }
 }
 
-extern "C" int mdqe_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                                  long rows, int C, float eps, void* stream) {
+static int layernorm_impl(const float* x, const float* res, const float* gamma, const float* beta, const float* post, float* y,
+                          long rows, int C, float eps, void* stream) {
   MDQE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 1024);
   if (rows == 0) return MDQE_OK;
   MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta); MDQE_CHECK_PTR(y);
@@ -63,10 +65,22 @@ extern "C" int mdqe_layernorm_f32(const float* x, const float* res, const float*
   long nb = (rows + 3) / 4;
   if (nb > 256 * 32) nb = 256 * 32;
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, y, rows, C, eps);
-  else if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, y, rows, C, eps);
-  else hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, y, rows, C, eps);
+  if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
+  else if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
   return mdqe_launch_status();
+}
+
+extern "C" int mdqe_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                  long rows, int C, float eps, void* stream) {
+  return layernorm_impl(x, res, gamma, beta, nullptr, y, rows, C, eps, stream);
+}
+
+// y = LN(x)*gamma + beta + post   (SwinV2 res-post-norm, swin_transformer_v2.py:287-288)
+extern "C" int mdqe_layernorm_post_f32(const float* x, const float* gamma, const float* beta, const float* post, float* y,
+                                       long rows, int C, float eps, void* stream) {
+  MDQE_CHECK_PTR(post);
+  return layernorm_impl(x, nullptr, gamma, beta, post, y, rows, C, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -41,6 +41,35 @@ def _krsc(w):
     return w.permute(0, 2, 3, 1).contiguous()
 
 
+def _swin_rel_tables(ws):
+    """relative_coords_table / relative_position_index of WindowAttention.__init__ (swin_transformer_v2.py:101-131)."""
+    rh = torch.arange(-(ws - 1), ws, dtype=torch.float32)
+    tab = torch.stack(torch.meshgrid([rh, rh], indexing="ij")).permute(1, 2, 0).contiguous().unsqueeze(0)
+    tab = tab / max(ws - 1, 1) * 8
+    tab = torch.sign(tab) * torch.log2(torch.abs(tab) + 1.0) / np.log2(8)
+    c = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return tab, rel.sum(-1)
+
+
+def _swin_shift_mask(H, W, ws):
+    """Attention mask of the cyclic shift (BasicLayer.forward, swin_transformer_v2.py:397-415) -> [nW, N, N]."""
+    ss = ws // 2
+    Hp, Wp = int(np.ceil(H / ws)) * ws, int(np.ceil(W / ws)) * ws
+    img = torch.zeros(Hp, Wp)
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+        for w in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+            img[h, w] = cnt
+            cnt += 1
+    mw = img.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0).contiguous()
+
+
 class Packed:
     """Device-resident weights in kernel layouts, built from a reference-named state dict."""
 
@@ -80,6 +109,44 @@ class Packed:
                     blocks.append(blk)
                 bb.stages.append(blocks)
             self.bb = bb
+
+        # ---- SwinV2 backbone (a4') ----------------------------------------------------------------
+        self.swin = None
+        if cfg.backbone == "SwinV2":
+            bp = "detr.backbone.0.backbone"
+            sw = NS(stages=[])
+            C0 = cfg.swin_embed_dim
+            sw.pe_w, sw.pe_b = up(sd[bp + ".patch_embed.proj.weight"].reshape(C0, 48)), up(sd[bp + ".patch_embed.proj.bias"])
+            sw.pe_n = (up(sd[bp + ".patch_embed.norm.weight"]), up(sd[bp + ".patch_embed.norm.bias"]))
+            nl = len(cfg.swin_depths)
+            for i, depth in enumerate(cfg.swin_depths):
+                dim, nhs = C0 * 2 ** i, cfg.swin_heads[i]
+                ws = cfg.swin_window // 2 if i == nl - 1 else cfg.swin_window      # swin_transformer_v2.py:562
+                tab, idx = _swin_rel_tables(ws)
+                stg = NS(dim=dim, nh=nhs, ws=ws, blocks=[], down=None, out_norm=None)
+                for j in range(depth):
+                    q = f"{bp}.layers.{i}.blocks.{j}"
+                    a = q + ".attn"
+                    # continuous position bias: input independent -> evaluated once here (the reference re-runs the
+                    # cpb MLP in every block of every call, :164-169)
+                    t = F.linear(F.relu(F.linear(tab, sd[a + ".cpb_mlp.0.weight"], sd[a + ".cpb_mlp.0.bias"])), sd[a + ".cpb_mlp.2.weight"])
+                    bias = 16 * torch.sigmoid(t.view(-1, nhs)[idx.view(-1)].view(ws * ws, ws * ws, nhs).permute(2, 0, 1).contiguous())
+                    scale = torch.clamp(sd[a + ".logit_scale"], max=math.log(1. / 0.01)).exp().flatten()
+                    stg.blocks.append(NS(
+                        shift=0 if j % 2 == 0 else ws // 2,
+                        wqkv=up(sd[a + ".qkv.weight"]),
+                        bqkv=up(torch.cat([sd[a + ".q_bias"], torch.zeros_like(sd[a + ".v_bias"]), sd[a + ".v_bias"]])),
+                        wproj=up(sd[a + ".proj.weight"]), bproj=up(sd[a + ".proj.bias"]), scale=up(scale), bias=up(bias),
+                        n1=(up(sd[q + ".norm1.weight"]), up(sd[q + ".norm1.bias"])), n2=(up(sd[q + ".norm2.weight"]), up(sd[q + ".norm2.bias"])),
+                        fc1=(up(sd[q + ".mlp.fc1.weight"]), up(sd[q + ".mlp.fc1.bias"])),
+                        fc2=(up(sd[q + ".mlp.fc2.weight"]), up(sd[q + ".mlp.fc2.bias"]))))
+                if i < nl - 1:
+                    d_ = f"{bp}.layers.{i}.downsample"
+                    stg.down = NS(w=up(sd[d_ + ".reduction.weight"]), n=(up(sd[d_ + ".norm.weight"]), up(sd[d_ + ".norm.bias"])))
+                if (f"{bp}.norm{i}.weight") in sd:
+                    stg.out_norm = (up(sd[f"{bp}.norm{i}.weight"]), up(sd[f"{bp}.norm{i}.bias"]))
+                sw.stages.append(stg)
+            self.swin = sw
 
         # ---- input_proj (a6) ---------------------------------------------------------------------
         self.inproj = []
@@ -224,6 +291,13 @@ class Geometry:
             ops.linear(pos_d, lyr.wq, None, out=t[:, C:], ldc=C + nq)
             self.pos_tables.append(t)
         self._masks_rep = {}
+        self.swin_masks = None
+        if P.swin is not None:
+            H, W = self.Hp // 4, self.Wp // 4
+            self.swin_masks = []
+            for stg in P.swin.stages:
+                self.swin_masks.append((H, W, _swin_shift_mask(H, W, stg.ws).to(dev)))
+                H, W = (H + 1) // 2, (W + 1) // 2
 
     @staticmethod
     def _ref_points(H, W):
@@ -276,6 +350,8 @@ class Engine:
         (STRIDE_IN_1X1 False, FrozenBN folded; configs/R50_coco.yaml:7-10)."""
         if self.backbone_fn is not None:
             return self.backbone_fn(frames, geo)
+        if self.P.swin is not None:
+            return self.backbone_swin(frames, geo)
         bb, cfg = self.P.bb, self.cfg
         NI = frames.shape[0]
         col = ops.stem_im2col(frames, geo.Hp, geo.Wp, cfg.pixel_mean, cfg.pixel_std)
@@ -292,6 +368,38 @@ class Engine:
                 x = self._conv(y, blk.conv3, 1, 1, 0, "relu", residual=sc)
             if si >= 1:
                 outs.append(x)
+        return outs
+
+    def backbone_swin(self, frames, geo):
+        """SwinTransformerV2.forward (mdqe/backbone/swin_transformer_v2.py:639-659) on channels-last tokens: returns the
+        normalised stage3/4/5 maps NHWC.  Window partition / cyclic shift / reverse are index kernels around the GEMMs;
+        the attention core is one block per (window, head)."""
+        sw, cfg = self.P.swin, self.cfg
+        NI = frames.shape[0]
+        col = ops.patch4_im2col(frames, geo.Hp, geo.Wp, cfg.pixel_mean, cfg.pixel_std)
+        x = ops.layernorm(ops.linear(col, sw.pe_w, sw.pe_b), *sw.pe_n)
+        del col
+        outs = []
+        for si, stg in enumerate(sw.stages):
+            H, W, mask = geo.swin_masks[si]
+            C, ws, nh = stg.dim, stg.ws, stg.nh
+            N = ws * ws
+            nWy, nWx = (H + ws - 1) // ws, (W + ws - 1) // ws
+            x4 = x.view(NI, H, W, C)
+            for blk in stg.blocks:
+                win = ops.swin_window_gather(x4, ws, blk.shift)
+                qkv = ops.linear(win, blk.wqkv, blk.bqkv)
+                a = ops.window_attn(qkv, NI * nWy * nWx, N, C, nh, blk.scale, blk.bias, mask if blk.shift > 0 else None, nWy * nWx)
+                pr = ops.layernorm(ops.linear(a, blk.wproj, blk.bproj), *blk.n1)           # norm1(attn(x)), window order
+                x4 = ops.swin_window_scatter_add(pr, x4, ws, blk.shift)                     # shortcut + ... (:287)
+                x2 = x4.view(-1, C)
+                h = ops.linear(x2, *blk.fc1, act="gelu")
+                x4 = ops.layernorm_post(ops.linear(h, *blk.fc2), *blk.n2, post=x2).view(NI, H, W, C)   # x + norm2(mlp(x)) (:288)
+            if stg.out_norm is not None:
+                outs.append(ops.layernorm(x4, *stg.out_norm).view(NI, H, W, C))
+            if stg.down is not None:
+                g = ops.patch_merge_gather(x4)
+                x = ops.layernorm(ops.linear(g, stg.down.w, None), *stg.down.n)
         return outs
 
     @staticmethod

@@ -258,3 +258,61 @@ def final_masks(logits, inst_idx, factor, h, w, Ho, Wo, out, f_off):
     check(lib.mdqe_final_masks_u8(ptr(logits), int(inst_idx.numel()), ptr(inst_idx), Fw, Hm, Wm, factor, h, w, Ho, Wo, ptr(out),
                                   out.stride(0), f_off, cur_stream()), "final_masks")
     return out
+
+
+def layernorm_post(x, gamma, beta, post, eps=1e-5, out=None):
+    """out = LN(x)*gamma + beta + post."""
+    _chk(x, "x"); _chk(post, "post")
+    C = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.mdqe_layernorm_post_f32(ptr(x), ptr(gamma), ptr(beta), ptr(post), ptr(out), x.numel() // C, C, eps, cur_stream()),
+          "layernorm_post")
+    return out
+
+
+def patch4_im2col(frames, Hp, Wp, mean, std):
+    import ctypes
+    NI, _, h, w = frames.shape
+    out = torch.empty((NI * (Hp // 4) * (Wp // 4), 48), dtype=torch.float32, device=frames.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(lib.mdqe_patch4_im2col_f32(ptr(frames), int(frames.dtype == torch.uint8), 3 * h * w, NI, h, w, Hp, Wp, m, s, ptr(out),
+                                     cur_stream()), "patch4_im2col")
+    return out
+
+
+def swin_window_gather(x, ws, shift):
+    """x [B,H,W,C] -> window rows [B*nW*ws*ws, C] (zero pad + cyclic shift + partition)."""
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    Hp, Wp = (H + ws - 1) // ws * ws, (W + ws - 1) // ws * ws
+    out = torch.empty((B * Hp * Wp, C), dtype=torch.float32, device=x.device)
+    check(lib.mdqe_swin_window_f32(ptr(x), None, ptr(out), B, H, W, C, ws, shift, 0, cur_stream()), "swin_window_gather")
+    return out
+
+
+def swin_window_scatter_add(rows, shortcut, ws, shift, out=None):
+    """out[b,y,x] = shortcut[b,y,x] + rows[window order] (reverse + un-shift + crop)."""
+    _chk(rows, "rows"); _chk(shortcut, "shortcut")
+    B, H, W, C = shortcut.shape
+    if out is None:
+        out = torch.empty_like(shortcut)
+    check(lib.mdqe_swin_window_f32(ptr(rows), ptr(shortcut), ptr(out), B, H, W, C, ws, shift, 1, cur_stream()), "swin_window_scatter")
+    return out
+
+
+def window_attn(qkv, n_windows, N, C, nh, scale, bias, mask=None, nW=1):
+    _chk(qkv, "qkv"); _chk(scale, "scale"); _chk(bias, "bias"); _chk(mask, "mask")
+    out = torch.empty((n_windows * N, C), dtype=torch.float32, device=qkv.device)
+    check(lib.mdqe_window_attn_f32(ptr(qkv), qkv.stride(0), ptr(out), C, n_windows, N, C, nh, ptr(scale), ptr(bias), ptr(mask), nW,
+                                   cur_stream()), "window_attn")
+    return out
+
+
+def patch_merge_gather(x):
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    out = torch.empty((B * ((H + 1) // 2) * ((W + 1) // 2), 4 * C), dtype=torch.float32, device=x.device)
+    check(lib.mdqe_patch_merge_gather_f32(ptr(x), ptr(out), B, H, W, C, cur_stream()), "patch_merge_gather")
+    return out

@@ -46,6 +46,46 @@ def resnet_manifest(kind="R50", p="detr.backbone.0.backbone"):
     return m
 
 
+def swin_manifest(cfg: MDQEConfig, p="detr.backbone.0.backbone"):
+    """SwinTransformerV2 parameters (mdqe/backbone/swin_transformer_v2.py:97-145,217-229,305-309,459-464,605-611)."""
+    m = OrderedDict()
+    C0 = cfg.swin_embed_dim
+    m[f"{p}.patch_embed.proj.weight"] = (C0, 3, 4, 4)
+    m[f"{p}.patch_embed.proj.bias"] = (C0,)
+    m[f"{p}.patch_embed.norm.weight"] = (C0,)
+    m[f"{p}.patch_embed.norm.bias"] = (C0,)
+    nl = len(cfg.swin_depths)
+    for i, depth in enumerate(cfg.swin_depths):
+        dim, nh = C0 * 2 ** i, cfg.swin_heads[i]
+        hid = int(dim * cfg.swin_mlp_ratio)
+        for j in range(depth):
+            q = f"{p}.layers.{i}.blocks.{j}"
+            for n in ("norm1", "norm2"):
+                m[f"{q}.{n}.weight"] = (dim,)
+                m[f"{q}.{n}.bias"] = (dim,)
+            m[q + ".attn.logit_scale"] = (nh, 1, 1)
+            m[q + ".attn.cpb_mlp.0.weight"] = (512, 2)
+            m[q + ".attn.cpb_mlp.0.bias"] = (512,)
+            m[q + ".attn.cpb_mlp.2.weight"] = (nh, 512)
+            m[q + ".attn.qkv.weight"] = (3 * dim, dim)
+            m[q + ".attn.q_bias"] = (dim,)
+            m[q + ".attn.v_bias"] = (dim,)
+            m[q + ".attn.proj.weight"] = (dim, dim)
+            m[q + ".attn.proj.bias"] = (dim,)
+            m[q + ".mlp.fc1.weight"] = (hid, dim)
+            m[q + ".mlp.fc1.bias"] = (hid,)
+            m[q + ".mlp.fc2.weight"] = (dim, hid)
+            m[q + ".mlp.fc2.bias"] = (dim,)
+        if i < nl - 1:
+            m[f"{p}.layers.{i}.downsample.reduction.weight"] = (2 * dim, 4 * dim)
+            m[f"{p}.layers.{i}.downsample.norm.weight"] = (2 * dim,)
+            m[f"{p}.layers.{i}.downsample.norm.bias"] = (2 * dim,)
+    for i in (1, 2, 3):
+        m[f"{p}.norm{i}.weight"] = (C0 * 2 ** i,)
+        m[f"{p}.norm{i}.bias"] = (C0 * 2 ** i,)
+    return m
+
+
 def _lin(m, name, out_f, in_f):
     m[name + ".weight"] = (out_f, in_f)
     m[name + ".bias"] = (out_f,)
@@ -145,6 +185,8 @@ def full_manifest(cfg: MDQEConfig):
     m = OrderedDict()
     if cfg.backbone in RESNET_BLOCKS:
         m.update(resnet_manifest(cfg.backbone))
+    elif cfg.backbone == "SwinV2":
+        m.update(swin_manifest(cfg))
     m.update(head_manifest(cfg))
     return m
 
@@ -176,11 +218,15 @@ def random_state(cfg: MDQEConfig, seed=0, remove_zero_init_trap=True):
             t = torch.zeros(shape)
         elif ".norm." in name and "backbone" in name:
             t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
-        elif len(shape) == 1:
+        elif len(shape) == 1 and not name.endswith(("q_bias", "v_bias")):
             is_gamma = name.endswith(".weight")
             t = torch.ones(shape) if is_gamma else torch.zeros(shape)
         elif name.endswith("level_embed"):
             t = torch.randn(shape, generator=g)
+        elif name.endswith("logit_scale"):
+            t = torch.log(10 * torch.ones(shape))
+        elif "backbone" in name and cfg.backbone == "SwinV2":
+            t = torch.randn(shape, generator=g) * 0.02                 # trunc_normal_(std=.02) stand-in
         elif "backbone" in name:
             fan_out = shape[0] * shape[2] * shape[3]
             t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
