@@ -100,8 +100,9 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
                     help="GEMM arithmetic of the headline number: exact fp32 MFMA (default) or split-precision f16x3")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 pass reported as `fast_mode`")
-    ap.add_argument("--config", choices=["R50_ovis_360", "R50_ovis_720"], default="R50_ovis_360",
-                    help="R50_ovis_360 is BASELINE.json's metric config; R50_ovis_720 = 640x1138 frames (configs[2])")
+    ap.add_argument("--config", choices=["R50_ovis_360", "R50_ovis_720", "swinl_ovis"], default="R50_ovis_360",
+                    help="R50_ovis_360 is BASELINE.json's metric config; R50_ovis_720 = 640x1138 frames (configs[2]); "
+                         "swinl_ovis = SwinV2-L, 480x853 frames, 2-frame clips (configs[3])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +123,7 @@ def main():
     from mdqe_cvpr2023_amd import sharding
 
     cfg = PRESETS[args.config]
-    fh, fw = (360, 640) if args.config == "R50_ovis_360" else (640, 1138)
+    fh, fw = {"R50_ovis_360": (360, 640), "R50_ovis_720": (640, 1138), "swinl_ovis": (480, 853)}[args.config]
     sd = random_state(cfg, seed=0)
     model = MDQE(cfg, state_dict=sd).eval()
     meter = GemmMeter()
@@ -182,12 +183,14 @@ def main():
     if rank == 0:
         g = meter.summary()
         line = {
-            "metric": "frames/sec (eval-only) R50 OVIS %s 4-frame clip" % ("360p" if args.config == "R50_ovis_360" else "640p"), "value": L * args.steps / dt, "unit": "frames/s",
+            "metric": {"R50_ovis_360": "frames/sec (eval-only) R50 OVIS 360p 4-frame clip",
+                       "R50_ovis_720": "frames/sec (eval-only) R50 OVIS 640p 4-frame clip",
+                       "swinl_ovis": "frames/sec (eval-only) Swin-L OVIS 480p 2-frame clip"}[args.config], "value": L * args.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s eval-only: %d synthetic %dx%d uint8 frames per GPU per step, 4-frame clips stride 1, "
+            "config": {"workload": "%s eval-only: %d synthetic %dx%d uint8 frames per GPU per step, %d-frame clips stride 1, "
                                    "%d-frame windows, random-init weights (zero-init trap removed)"
-                                   % (args.config, args.frames, fh, fw, cfg.n_frames_window_test),
+                                   % (args.config, args.frames, fh, fw, cfg.n_frames_test, cfg.n_frames_window_test),
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
                        "instances_out": len(out["pred_scores"]),
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",

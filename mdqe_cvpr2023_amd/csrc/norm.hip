@@ -58,7 +58,7 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
 
 static int layernorm_impl(const float* x, const float* res, const float* gamma, const float* beta, const float* post, float* y,
                           long rows, int C, float eps, void* stream) {
-  MDQE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 1024);
+  MDQE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 2048);
   if (rows == 0) return MDQE_OK;
   MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta); MDQE_CHECK_PTR(y);
   mdqe_clear_error();
@@ -67,7 +67,8 @@ static int layernorm_impl(const float* x, const float* res, const float* gamma, 
   hipStream_t st = (hipStream_t)stream;
   if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
   else if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
-  else hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
+  else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<8>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
   return mdqe_launch_status();
 }
 
