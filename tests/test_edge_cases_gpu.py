@@ -1,0 +1,71 @@
+"""GPU edge cases of the driver against the CPU oracle (small model, R50 backbone): odd frame sizes (padding masks
+active on every level), float32 frames (demo path), videos shorter than one clip, single-frame video, output size
+different from the frame size, clip stride 2."""
+import pytest
+import torch
+
+import mdqe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(enc_layers=1, dec_layers=2, n_frames=3, num_classes=5, num_queries=16, query_embed_dim=16)
+
+
+def run_both(frames, out_size, ev, dtype=torch.uint8):
+    from mdqe_cvpr2023_amd.config import MDQEConfig
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    from mdqe_cvpr2023_amd.params import random_state
+    cfg = MDQEConfig(**KW, **ev)
+    sd = random_state(cfg, seed=11)
+    model = MDQE(cfg, state_dict=sd).eval()
+    trace, ref_trace = [], []
+    fr = [f.to(dtype) for f in frames]
+    with torch.no_grad():
+        out = model.inference_vis([{"image": fr, "height": out_size[0], "width": out_size[1]}], trace=trace)
+        ref = O.inference_vis(sd, O.Hyper(**KW, **ev), fr, lambda im: O.resnet(sd, "detr.backbone.0.backbone", im, 50),
+                              out_size=out_size, trace=ref_trace)
+    assert len(trace) == len(ref_trace)
+    for a, b in zip(trace, ref_trace):
+        assert a["pred_masks"].shape == b["pred_masks"].shape
+        assert float((a["pred_masks"].cpu() - b["pred_masks"]).abs().max()) < 1e-3
+    assert out["pred_labels"] == ref["pred_labels"]
+    assert out["image_size"] == tuple(out_size)
+    got, want = torch.stack(out["pred_masks"]), torch.stack(ref["pred_masks"])
+    assert got.shape == want.shape and (got != want).float().mean() < 2e-3
+    return out
+
+
+def video(L, h, w, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).float()
+    return [(0.8 * base + 0.2 * torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).float()).round() for _ in range(L)]
+
+
+EV = dict(n_frames_test=3, n_frames_window_test=4, n_max_inst=40, apply_cls_thres=0.12)
+
+
+def test_odd_frame_size_and_resized_output():
+    run_both(video(6, 57, 83), (101, 150), EV)           # 57x83 -> padded 64x96; masks active on all levels
+
+
+def test_float_frames_like_demo():
+    run_both(video(4, 64, 96, 1), (64, 96), EV, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_video_shorter_than_or_equal_to_a_clip(L):
+    run_both(video(L, 64, 96, 2), (64, 96), EV)
+
+
+def test_clip_stride_two_and_exact_window_boundary():
+    run_both(video(8, 64, 96, 3), (64, 96), dict(EV, clip_stride=2))
+
+
+def test_wrong_inputs_raise():
+    from mdqe_cvpr2023_amd.config import MDQEConfig
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    model = MDQE(MDQEConfig(**KW, **EV), seed=1)
+    with pytest.raises(RuntimeError):
+        model([{"image": video(2, 64, 96)}, {"image": video(2, 64, 96)}])      # one video per call (mdqe/mdqe.py:292)
+    with pytest.raises(RuntimeError):
+        model.train(True)
