@@ -8,7 +8,7 @@ import mdqe_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-KW = dict(enc_layers=1, dec_layers=2, n_frames=3, num_classes=5, num_queries=16, query_embed_dim=16)
+KW = dict(enc_layers=1, dec_layers=2, n_frames=3, num_classes=12, num_queries=16, query_embed_dim=16)
 
 
 def run_both(frames, out_size, ev, dtype=torch.uint8):
