@@ -7,13 +7,11 @@
 //   o[b,q,h,:] = softmax_k( (q[b,q,h,:] * D^-0.5) . k[b,k,h,:] ) @ v[b,k,h,:]
 // (transformer_dec.py:348-353,397-402; torch scales q before the product).  One block per (batch, head):
 // K and V of the head live in LDS (2 x Q x D floats, 50 KB at Q=196, D=32), one thread per query row,
-// single-pass online softmax; every lane reads the same K/V row -> LDS broadcast reads.  128 threads, 2 rows each.
+// single-pass online softmax; every lane reads the same K/V row -> LDS broadcast reads.
 // qk: [B*Q, ldqk] with q at column h*D and k at column C + h*D; v: [B*Q, ldv]; o: [B*Q, ldo].
 // ------------------------------------------------------------------------------------------------
-// Two query rows per thread (rows r and r + RH): every K/V row fetched from LDS (a broadcast read) feeds two dot
-// products / two accumulators, halving the LDS instruction stream that bounds this kernel.
 template <int D>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(256)
 mha_small_kernel(const float* __restrict__ qk, long ldqk, const float* __restrict__ v, long ldv, float* __restrict__ o,
                  long ldo, int Q, int C, int nh) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -27,46 +25,40 @@ mha_small_kernel(const float* __restrict__ qk, long ldqk, const float* __restric
     *reinterpret_cast<f32x4*>(sV + r * D + c4 * 4) = *reinterpret_cast<const f32x4*>(v + (row0 + r) * ldv + h * D + c4 * 4);
   }
   __syncthreads();
-  const int RH = (Q + 1) / 2;
-  const int r0 = threadIdx.x, r1 = threadIdx.x + RH;
-  if (r0 >= RH) return;
-  const bool has1 = r1 < Q;
+  const int r = threadIdx.x;
+  if (r >= Q) return;
   const float scale = rsqrtf((float)D);
-  float q0[D], q1[D], a0[D], a1[D];
+  float q[D], acc[D];
 #pragma unroll
   for (int c = 0; c < D; c += 4) {
-    const f32x4 t0 = *reinterpret_cast<const f32x4*>(qk + (row0 + r0) * ldqk + h * D + c);
-    const f32x4 t1 = has1 ? *reinterpret_cast<const f32x4*>(qk + (row0 + r1) * ldqk + h * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { q0[c + e] = t0[e] * scale; q1[c + e] = t1[e] * scale; a0[c + e] = 0.f; a1[c + e] = 0.f; }
+    const f32x4 t = *reinterpret_cast<const f32x4*>(qk + (row0 + r) * ldqk + h * D + c);
+    q[c] = t[0] * scale; q[c + 1] = t[1] * scale; q[c + 2] = t[2] * scale; q[c + 3] = t[3] * scale;
+    acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.f;
   }
-  float m0 = -INFINITY, l0 = 0.f, m1 = -INFINITY, l1 = 0.f;
+  float m = -INFINITY, l = 0.f;
   for (int j = 0; j < Q; ++j) {
-    float s0 = 0.f, s1 = 0.f;
+    float s = 0.f;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
       const f32x4 kk = *reinterpret_cast<const f32x4*>(sK + j * D + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s0 += q0[c + e] * kk[e]; s1 += q1[c + e] * kk[e]; }
+      s += q[c] * kk[0] + q[c + 1] * kk[1] + q[c + 2] * kk[2] + q[c + 3] * kk[3];
     }
-    const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);
-    const float c0 = expf(m0 - n0), c1 = expf(m1 - n1);
-    const float p0 = expf(s0 - n0), p1 = expf(s1 - n1);
-    l0 = l0 * c0 + p0; l1 = l1 * c1 + p1;
+    const float mn = fmaxf(m, s);
+    const float corr = expf(m - mn);
+    const float p = expf(s - mn);
+    l = l * corr + p;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
       const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + j * D + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { a0[c + e] = a0[c + e] * c0 + p0 * vv[e]; a1[c + e] = a1[c + e] * c1 + p1 * vv[e]; }
+      acc[c] = acc[c] * corr + p * vv[0]; acc[c + 1] = acc[c + 1] * corr + p * vv[1];
+      acc[c + 2] = acc[c + 2] * corr + p * vv[2]; acc[c + 3] = acc[c + 3] * corr + p * vv[3];
     }
-    m0 = n0; m1 = n1;
+    m = mn;
   }
-  const float i0 = 1.f / l0, i1 = 1.f / l1;
+  const float inv = 1.f / l;
 #pragma unroll
-  for (int c = 0; c < D; c += 4) {
-    *reinterpret_cast<f32x4*>(o + (row0 + r0) * ldo + h * D + c) = f32x4{a0[c] * i0, a0[c + 1] * i0, a0[c + 2] * i0, a0[c + 3] * i0};
-    if (has1) *reinterpret_cast<f32x4*>(o + (row0 + r1) * ldo + h * D + c) = f32x4{a1[c] * i1, a1[c + 1] * i1, a1[c + 2] * i1, a1[c + 3] * i1};
-  }
+  for (int c = 0; c < D; c += 4)
+    *reinterpret_cast<f32x4*>(o + (row0 + r) * ldo + h * D + c) = f32x4{acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv};
 }
 
 extern "C" int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, long ldv, float* o, long ldo, int B, int Q,
@@ -80,7 +72,7 @@ extern "C" int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, lo
   const size_t smem = (size_t)2 * Q * D * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define L(DD) do { (void)hipFuncSetAttribute((const void*)mha_small_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((mha_small_kernel<DD>), dim3(B * nh), dim3(128), smem, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh); } while (0)
+    hipLaunchKernelGGL((mha_small_kernel<DD>), dim3(B * nh), dim3(256), smem, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh); } while (0)
   if (D == 32) L(32); else if (D == 24) L(24); else if (D == 16) L(16); else L(8);
 #undef L
   return mdqe_launch_status();

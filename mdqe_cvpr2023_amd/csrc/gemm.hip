@@ -290,7 +290,7 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     else if (b128 >= 192) tile = 1;
     else tile = 3;
   }
-  if ((tile == 1 || tile == 2 || (tile == 3 && p.K >= 64)) && g_gemm_precision == 1) {
+  if ((tile == 1 || tile == 2) && g_gemm_precision == 1) {
     int rc = mdqe_launch_gemm_f16x3(p, tile, st);
     if (rc || p.ksplit <= 1) return rc;
     long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;

@@ -257,6 +257,5 @@ static int launch_f16x3(const GemmParams& p, hipStream_t st) {
 }
 
 int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st) {
-  if (tile == 3) return launch_f16x3<64, 64>(p, st);
   return tile == 2 ? launch_f16x3<128, 64>(p, st) : launch_f16x3<128, 128>(p, st);
 }

@@ -101,7 +101,7 @@ extern "C" int mdqe_swin_window_f32(const float* src, const float* shortcut, flo
 // (+ mask[win % nW, i, j]) -> softmax -> @ v.  One block per (window, head); K/V in LDS (K rows pre-normalised),
 // one thread per query row, online softmax.  N <= 256, D in {8,16,24,32}.
 template <int D>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(256)
 window_attn_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o, long ldo, int N, int C, int nh,
                    const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ mask, int nW) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -109,7 +109,8 @@ window_attn_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o
   float* sV = sm + N * D;
   const int win = blockIdx.x / nh, h = blockIdx.x % nh;
   const long row0 = (long)win * N;
-  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+  const int r = threadIdx.x;
+  if (r < N) {
     const float* kp = qkv + (row0 + r) * ld + C + h * D;
     const float* vp = qkv + (row0 + r) * ld + 2 * C + h * D;
     float kk[D], ss = 0.f;
@@ -125,61 +126,50 @@ window_attn_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o
     for (int c = 0; c < D; ++c) sK[r * D + c] = kk[c] * inv;
   }
   __syncthreads();
-  // two query rows per thread: each broadcast K/V row read from LDS feeds both
-  const int RH = (N + 1) / 2;
-  const int r0 = threadIdx.x, r1 = threadIdx.x + RH;
-  if (r0 >= RH) return;
-  const bool has1 = r1 < N;
-  float q0[D], q1[D], a0[D], a1[D];
+  if (r >= N) return;
+  float q[D], acc[D];
   {
-    float s0 = 0.f, s1 = 0.f;
+    float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(qkv + (row0 + r0) * ld + h * D + c);
-      const f32x4 t1 = has1 ? *reinterpret_cast<const f32x4*>(qkv + (row0 + r1) * ld + h * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q0[c + e] = t0[e]; q1[c + e] = t1[e]; s0 += t0[e] * t0[e]; s1 += t1[e] * t1[e]; a0[c + e] = 0.f; a1[c + e] = 0.f;
-      }
+      const f32x4 t = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * ld + h * D + c);
+      q[c] = t[0]; q[c + 1] = t[1]; q[c + 2] = t[2]; q[c + 3] = t[3];
+      ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+      acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.f;
     }
-    const float i0 = 1.f / fmaxf(sqrtf(s0), 1e-12f), i1 = 1.f / fmaxf(sqrtf(s1), 1e-12f);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
-    for (int c = 0; c < D; ++c) { q0[c] *= i0; q1[c] *= i1; }
+    for (int c = 0; c < D; ++c) q[c] *= inv;
   }
   const float sc = scale[h];
-  const float* b0 = bias + ((long)h * N + r0) * N;
-  const float* b1 = bias + ((long)h * N + (has1 ? r1 : r0)) * N;
-  const float* k0 = mask != nullptr ? mask + ((long)(win % nW) * N + r0) * N : nullptr;
-  const float* k1 = mask != nullptr ? mask + ((long)(win % nW) * N + (has1 ? r1 : r0)) * N : nullptr;
-  float m0 = -INFINITY, l0 = 0.f, m1 = -INFINITY, l1 = 0.f;
+  const float* bp = bias + ((long)h * N + r) * N;
+  const float* mp = mask != nullptr ? mask + ((long)(win % nW) * N + r) * N : nullptr;
+  float m = -INFINITY, l = 0.f;
   for (int j = 0; j < N; ++j) {
-    float s0 = 0.f, s1 = 0.f;
+    float s = 0.f;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
       const f32x4 kk = *reinterpret_cast<const f32x4*>(sK + j * D + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s0 += q0[c + e] * kk[e]; s1 += q1[c + e] * kk[e]; }
+      s += q[c] * kk[0] + q[c + 1] * kk[1] + q[c + 2] * kk[2] + q[c + 3] * kk[3];
     }
-    s0 = s0 * sc + b0[j]; s1 = s1 * sc + b1[j];
-    if (k0 != nullptr) { s0 += k0[j]; s1 += k1[j]; }
-    const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);
-    const float c0 = expf(m0 - n0), c1 = expf(m1 - n1);
-    const float p0 = expf(s0 - n0), p1 = expf(s1 - n1);
-    l0 = l0 * c0 + p0; l1 = l1 * c1 + p1;
+    s = s * sc + bp[j];
+    if (mp != nullptr) s += mp[j];
+    const float mn = fmaxf(m, s);
+    const float corr = expf(m - mn);
+    const float p = expf(s - mn);
+    l = l * corr + p;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
       const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + j * D + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { a0[c + e] = a0[c + e] * c0 + p0 * vv[e]; a1[c + e] = a1[c + e] * c1 + p1 * vv[e]; }
+      acc[c] = acc[c] * corr + p * vv[0]; acc[c + 1] = acc[c + 1] * corr + p * vv[1];
+      acc[c + 2] = acc[c + 2] * corr + p * vv[2]; acc[c + 3] = acc[c + 3] * corr + p * vv[3];
     }
-    m0 = n0; m1 = n1;
+    m = mn;
   }
-  const float i0 = 1.f / l0, i1 = 1.f / l1;
+  const float inv = 1.f / l;
 #pragma unroll
-  for (int c = 0; c < D; c += 4) {
-    *reinterpret_cast<f32x4*>(o + (row0 + r0) * ldo + h * D + c) = f32x4{a0[c] * i0, a0[c + 1] * i0, a0[c + 2] * i0, a0[c + 3] * i0};
-    if (has1) *reinterpret_cast<f32x4*>(o + (row0 + r1) * ldo + h * D + c) = f32x4{a1[c] * i1, a1[c + 1] * i1, a1[c + 2] * i1, a1[c + 3] * i1};
-  }
+  for (int c = 0; c < D; c += 4)
+    *reinterpret_cast<f32x4*>(o + (row0 + r) * ldo + h * D + c) = f32x4{acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv};
 }
 
 extern "C" int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int N, int C, int nh,
@@ -193,7 +183,7 @@ extern "C" int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ld
   const size_t smem = (size_t)2 * N * D * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define L(DD) do { (void)hipFuncSetAttribute((const void*)window_attn_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((window_attn_kernel<DD>), dim3(n_windows * nh), dim3(128), smem, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW); } while (0)
+    hipLaunchKernelGGL((window_attn_kernel<DD>), dim3(n_windows * nh), dim3(256), smem, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW); } while (0)
   if (D == 32) L(32); else if (D == 24) L(24); else if (D == 16) L(16); else L(8);
 #undef L
   return mdqe_launch_status();
