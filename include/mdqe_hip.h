@@ -64,12 +64,13 @@ int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* shapes, con
  * M*L*P*2 floats, logits row t holds M*L*P.  mode 0 (encoder): loc = ref_xy + off/8.  mode 1 (decoder):
  * loc = ref_xy + (grid*0.5*wh + clamp(off, +-8*wh))/8 with ref = (cx,cy,w,h) and grid [M,L,P,2] (device).
  * ref row = b*ref_bstride + q*ref_dim (ref_bstride 0 broadcasts one table over the batch).
- * Level tables (HOST int[G*L]): H, W, start row.  out row t, ldout floats apart; out = scale * sum_g(...). */
+ * Level tables (HOST int[G*L]): H, W, start row.  out row t, ldout floats apart; out = scale * sum_g(...).
+ * value_rows = number of rows of the value buffer (> 0 enables the bounds-checked buffer-load kernel; 0 = unknown). */
 int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* vidx, const float* offs, long ldo,
                         const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
                         int mode, const float* grid, const int* lvH_host, const int* lvW_host,
                         const int* lvStart_host, int B, int M, int D, int G, int L, int Q, int P, float scale,
-                        float* out, long ldout, void* stream);
+                        float* out, long ldout, long value_rows, void* stream);
 
 /* ---- fp32 NT GEMM with fused epilogue (v_mfma_f32_32x32x2_f32, exact fp32) ----------------------
  * C[m,n] = mask( act(sum_k A[m*lda+k] * W[n*K+k] + bias[n]) + residual[(res_mod? m%res_mod : m)*ldr + n] )

@@ -13,7 +13,7 @@ i, f, p, l = c_int, c_float, c_void_p, c_long
 SIGNATURES = {
     "mdqe_msda_forward_f32": [p, p, p, p, p, i, i, i, i, i, i, i, p, p],
     "mdqe_msda_forward_grouped_f32": [p, p, p, p, p, i, i, i, i, i, i, i, i, f, p, p],
-    "mdqe_msda_fused_f32": [p, l, l, p, p, l, p, l, p, l, i, i, p, p, p, p, i, i, i, i, i, i, i, f, p, l, p],
+    "mdqe_msda_fused_f32": [p, l, l, p, p, l, p, l, p, l, i, i, p, p, p, p, i, i, i, i, i, i, i, f, p, l, l, p],
     "mdqe_trk_siou_f32": [p, l, i, p, l, i, l, p, p],
     "mdqe_trk_accumulate_f32": [p, l, p, l, p, l, l, i, p, p, i, p],
     "mdqe_mha_small_f32": [p, l, p, l, p, l, i, i, i, i, p],

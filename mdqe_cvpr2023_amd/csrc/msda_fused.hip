@@ -105,11 +105,105 @@ msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows, const
   }
 }
 
+// ---- v2 (D == 32, L*P == 16): cooperative sample set-up --------------------------------------------------------------
+// The 8 lanes that own the 32 channels of one (query, head) all need the same 16 sample descriptors.  v1 recomputes them in
+// every lane (~60 VALU x 16 samples).  Here lane j of the group prepares samples 2j and 2j+1 only -- softmax across the
+// group with 3 xor-shuffles, locations, the four corner byte offsets and the four (bilinear x attention) weights -- and
+// publishes 8 floats per sample in LDS; then every lane walks the 16 samples with two broadcast ds_read_b128 and four
+// bounds-checked buffer loads each (a corner outside the map carries an out-of-range offset and reads as 0: no branches).
+#define MSDA_OOB 0xF0000000u
+template <int L, int P>
+__global__ void __launch_bounds__(256)
+msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
+                     const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
+                     const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode,
+                     const float* __restrict__ grid, MsdaLevels lv,
+                     int B, int M, int G, int Q, float scale, float* __restrict__ out, long ldout, long total) {
+  constexpr int LP = L * P;                    // 16
+  constexpr int D = 32, DV = 8;
+  __shared__ __attribute__((aligned(16))) float sdesc[32][LP][8];      // [group in block][sample][off x4 | w x4]
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
+  const int grp = threadIdx.x >> 3, j = threadIdx.x & 7;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx / DV;
+    const int m = (int)(t % M);
+    t /= M;                                    // t = b*Q + q
+    const int b = (int)(t / Q);
+    const int q = (int)(t - (long)b * Q);
+    // ---- this lane's two samples: i0 = 2j, i1 = 2j+1
+    const f32x4 o4 = *reinterpret_cast<const f32x4*>(offs + t * ldo + m * (2 * LP) + 4 * j);
+    const f32x2 l2 = *reinterpret_cast<const f32x2*>(logits + t * ldl + m * LP + 2 * j);
+    float mx = fmaxf(l2[0], l2[1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    const float e0 = expf(l2[0] - mx), e1 = expf(l2[1] - mx);
+    float sm = e0 + e1;
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+    const float inv = 1.0f / sm;
+    const float* rp = ref + (long)b * ref_bstride + (long)q * ref_dim;
+    const float rx = rp[0], ry = rp[1];
+    float bw = 0.f, bh = 0.f;
+    if (mode == 1) { bw = rp[2]; bh = rp[3]; }
+    const long brow = vidx != nullptr ? (long)vidx[b] * v_brows : (long)b * v_brows;
+    const unsigned lane_off = (unsigned)((m * D + j * 4) * 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = 2 * j + k;
+        const int l = i / P;
+        float ox = o4[2 * k], oy = o4[2 * k + 1];
+        if (mode == 1) {
+          const float gx = grid[(m * LP + i) * 2], gy = grid[(m * LP + i) * 2 + 1];
+          ox = fminf(fmaxf(ox, -bw * 8.f), bw * 8.f);
+          oy = fminf(fmaxf(oy, -bh * 8.f), bh * 8.f);
+          ox = gx * 0.5f * bw + ox;
+          oy = gy * 0.5f * bh + oy;
+        }
+        const float lx = rx + ox / 8.f, ly = ry + oy / 8.f;
+        const float aw = (k == 0 ? e0 : e1) * inv;
+        const int H = lv.H[g * L + l], W = lv.W[g * L + l];
+        const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+        const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool h0 = in && h_low >= 0, h1 = in && h_low + 1 <= H - 1;
+        const bool w0 = w_low >= 0, w1 = w_low + 1 <= W - 1;
+        const long prow = brow + lv.start[g * L + l] + (long)h_low * W + w_low;       // pixel row of the (low, low) corner
+        const unsigned base = (unsigned)(prow * ldv * 4);
+        const unsigned dW = (unsigned)((long)W * ldv * 4), d1 = (unsigned)(ldv * 4);
+        f32x4 offv, wv;
+        offv[0] = __builtin_bit_cast(float, (h0 && w0) ? base : MSDA_OOB);
+        offv[1] = __builtin_bit_cast(float, (h0 && w1) ? base + d1 : MSDA_OOB);
+        offv[2] = __builtin_bit_cast(float, (h1 && w0) ? base + dW : MSDA_OOB);
+        offv[3] = __builtin_bit_cast(float, (h1 && w1) ? base + dW + d1 : MSDA_OOB);
+        wv[0] = hh * hw * aw; wv[1] = hh * lw * aw; wv[2] = lh * hw * aw; wv[3] = lh * lw * aw;
+        *reinterpret_cast<f32x4*>(&sdesc[grp][i][0]) = offv;
+        *reinterpret_cast<f32x4*>(&sdesc[grp][i][4]) = wv;
+      }
+      __builtin_amdgcn_wave_barrier();         // the 8 lanes of a group sit in one wave: in-order LDS suffices
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const f32x4 offv = *reinterpret_cast<const f32x4*>(&sdesc[grp][i][0]);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&sdesc[grp][i][4]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned o = __builtin_bit_cast(unsigned, offv[c]) + lane_off;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+          acc += v * wv[c];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    *reinterpret_cast<f32x4*>(out + t * ldout + m * D + j * 4) = acc * scale;
+  }
+}
+
 extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* vidx, const float* offs, long ldo,
                                    const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
                                    int mode, const float* grid, const int* lvH_host, const int* lvW_host,
                                    const int* lvStart_host, int B, int M, int D, int G, int L, int Q, int P, float scale,
-                                   float* out, long ldout, void* stream) {
+                                   float* out, long ldout, long value_rows, void* stream) {
   MDQE_REQUIRE(B >= 0 && M > 0 && D > 0 && D % 4 == 0 && G > 0 && L > 0 && P > 0 && Q >= 0 && G * L <= 16);
   MDQE_REQUIRE(ldv % 4 == 0 && ldo % 4 == 0 && ldl % 4 == 0 && ldout % 4 == 0 && (ref_dim == 2 || ref_dim == 4));
   MDQE_REQUIRE(mode == 0 || (mode == 1 && ref_dim == 4));
@@ -126,6 +220,15 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
   if (nb > 256L * 64) nb = 256L * 64;
   hipStream_t st = (hipStream_t)stream;
   mdqe_clear_error();
+  // v2 (cooperative sample set-up, buffer loads): D == 32, 16 samples, value buffer addressable with 32-bit offsets
+  const long vbytes = value_rows > 0 ? ((value_rows - 1) * ldv + (long)M * D) * 4 : 0;
+  if (D == 32 && L * P == 16 && vbytes > 0 && vbytes < 0xF0000000L) {
+#define LAUNCH2(LL, PP) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP>), dim3((unsigned)nb), dim3(256), 0, st, value, (unsigned)vbytes, \
+      ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total)
+    if (L == 4 && P == 4) { LAUNCH2(4, 4); return mdqe_launch_status(); }
+    if (L == 2 && P == 8) { LAUNCH2(2, 8); return mdqe_launch_status(); }
+#undef LAUNCH2
+  }
 #define LAUNCH(LL, PP) hipLaunchKernelGGL((msda_fused_kernel<LL, PP>), dim3((unsigned)nb), dim3(256), 0, st, value, ldv, v_brows, vidx, \
     offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, D, G, Q, scale, out, ldout, total)
   if (L == 4 && P == 4) LAUNCH(4, 4);

@@ -199,7 +199,7 @@ def msda_fused(value, offs, logits, ref, levels, B, Q, M, D, L, P, mode=0, grid=
         raise RuntimeError("msda_fused: vidx must be a CUDA int32 tensor with B entries")
     check(lib.mdqe_msda_fused_f32(ptr(value), value.stride(0), v_brows, ptr(vidx), ptr(offs), offs.stride(0), ptr(logits),
                                   logits.stride(0), ptr(ref), ref_b, ref_dim, mode, ptr(grid), arr(Hs), arr(Ws), arr(Ss),
-                                  B, M, D, groups, L, Q, P, scale, ptr(out), out.stride(0), cur_stream()), "msda_fused")
+                                  B, M, D, groups, L, Q, P, scale, ptr(out), out.stride(0), value.shape[0], cur_stream()), "msda_fused")
     return out
 
 
