@@ -121,7 +121,12 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
                      int B, int M, int G, int Q, float scale, float* __restrict__ out, long ldout, long total) {
   constexpr int LP = L * P;                    // 16
   constexpr int D = 32, DV = 8;
-  __shared__ __attribute__((aligned(16))) float sdesc[32][LP][8];      // [group in block][sample][off x4 | w x4]
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) unsigned soff[32][LP][4];     // [group in block][sample][corner byte offset]
+  __shared__ __attribute__((aligned(16))) float swgt[32][LP][4];        // [group in block][sample][corner weight]
+  __shared__ int sH[16], sW[16], sS[16];                                 // level table (indexed with a runtime level)
+  if (threadIdx.x < 16) { sH[threadIdx.x] = lv.H[threadIdx.x]; sW[threadIdx.x] = lv.W[threadIdx.x]; sS[threadIdx.x] = lv.start[threadIdx.x]; }
+  __syncthreads();
   const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
   const int grp = threadIdx.x >> 3, j = threadIdx.x & 7;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -161,7 +166,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
         }
         const float lx = rx + ox / 8.f, ly = ry + oy / 8.f;
         const float aw = (k == 0 ? e0 : e1) * inv;
-        const int H = lv.H[g * L + l], W = lv.W[g * L + l];
+        const int H = sH[g * L + l], W = sW[g * L + l];
         const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
         const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
@@ -169,26 +174,27 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
         const float hh = 1.f - lh, hw = 1.f - lw;
         const bool h0 = in && h_low >= 0, h1 = in && h_low + 1 <= H - 1;
         const bool w0 = w_low >= 0, w1 = w_low + 1 <= W - 1;
-        const long prow = brow + lv.start[g * L + l] + (long)h_low * W + w_low;       // pixel row of the (low, low) corner
+        const long prow = brow + sS[g * L + l] + (long)h_low * W + w_low;             // pixel row of the (low, low) corner
         const unsigned base = (unsigned)(prow * ldv * 4);
         const unsigned dW = (unsigned)((long)W * ldv * 4), d1 = (unsigned)(ldv * 4);
-        f32x4 offv, wv;
-        offv[0] = __builtin_bit_cast(float, (h0 && w0) ? base : MSDA_OOB);
-        offv[1] = __builtin_bit_cast(float, (h0 && w1) ? base + d1 : MSDA_OOB);
-        offv[2] = __builtin_bit_cast(float, (h1 && w0) ? base + dW : MSDA_OOB);
-        offv[3] = __builtin_bit_cast(float, (h1 && w1) ? base + dW + d1 : MSDA_OOB);
+        u32x4 offv;
+        f32x4 wv;
+        offv[0] = (h0 && w0) ? base : MSDA_OOB;
+        offv[1] = (h0 && w1) ? base + d1 : MSDA_OOB;
+        offv[2] = (h1 && w0) ? base + dW : MSDA_OOB;
+        offv[3] = (h1 && w1) ? base + dW + d1 : MSDA_OOB;
         wv[0] = hh * hw * aw; wv[1] = hh * lw * aw; wv[2] = lh * hw * aw; wv[3] = lh * lw * aw;
-        *reinterpret_cast<f32x4*>(&sdesc[grp][i][0]) = offv;
-        *reinterpret_cast<f32x4*>(&sdesc[grp][i][4]) = wv;
+        *reinterpret_cast<u32x4*>(&soff[grp][i][0]) = offv;
+        *reinterpret_cast<f32x4*>(&swgt[grp][i][0]) = wv;
       }
       __builtin_amdgcn_wave_barrier();         // the 8 lanes of a group sit in one wave: in-order LDS suffices
 #pragma unroll
       for (int i = 0; i < LP; ++i) {
-        const f32x4 offv = *reinterpret_cast<const f32x4*>(&sdesc[grp][i][0]);
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(&sdesc[grp][i][4]);
+        const u32x4 offv = *reinterpret_cast<const u32x4*>(&soff[grp][i][0]);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&swgt[grp][i][0]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const unsigned o = __builtin_bit_cast(unsigned, offv[c]) + lane_off;
+          const unsigned o = offv[c] + lane_off;
           const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
           acc += v * wv[c];
         }
