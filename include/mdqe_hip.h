@@ -87,14 +87,11 @@ int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* v
 int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                      int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
                      int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
-                     float* splitk_ws, const void* w_hi, const void* w_lo, void* stream);
+                     float* splitk_ws, void* stream);
 
 /* GEMM arithmetic of the 128x128 tile (process-wide): 0 = exact fp32 MFMA (default), 1 = "f16x3": operands split
  * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752). */
 int mdqe_set_gemm_precision(int mode);
-/* Pre-split a constant fp32 weight [n] into the f16 hi / scaled-lo planes of the f16x3 kernels (w_hi / w_lo arguments of
- * the GEMM and conv entry points; NULL = split W in-kernel).  hi, lo: n f16 values each. */
-int mdqe_split_f16x3(const float* w, long n, void* hi, void* lo, void* stream);
 int mdqe_get_gemm_precision(void);
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
@@ -103,8 +100,7 @@ int mdqe_get_gemm_precision(void);
  * mdqe/mdqe.py:27,33; input_proj 3x3 s2 models/mdqe.py:40-43; MaskHead 3x3 segmentation.py:42-57). */
 int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                          int NI, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                         int act, const float* residual, long ldr, int res_first, int tile, const void* w_hi,
-                         const void* w_lo, void* stream);
+                         int act, const float* residual, long ldr, int res_first, int tile, void* stream);
 
 /* ---- LayerNorm over the last dim: y = LN(x + res) * gamma + beta (res may be NULL) -----------------
  * nn.LayerNorm call sites transformer_enc.py:103-108,136; transformer_dec.py:345-358,394-408,466,492. */

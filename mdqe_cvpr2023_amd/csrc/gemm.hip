@@ -291,8 +291,7 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     else tile = 3;
   }
   if ((tile == 1 || tile == 2) && g_gemm_precision == 1) {
-    int rc = (tile == 1 && p.Wh != nullptr && p.Wl != nullptr && p.K % 8 == 0) ? mdqe_launch_gemm_f16x3_dma(p, st)
-                                                                                 : mdqe_launch_gemm_f16x3(p, tile, st);
+    int rc = mdqe_launch_gemm_f16x3(p, tile, st);
     if (rc || p.ksplit <= 1) return rc;
     long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
@@ -309,7 +308,7 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
 extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                                 int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
                                 int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
-                                float* splitk_ws, const void* w_hi, const void* w_lo, void* stream) {
+                                float* splitk_ws, void* stream) {
   MDQE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N);
   if (M == 0) return MDQE_OK;
   MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
@@ -320,7 +319,7 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
   p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = res_mod; p.res_first = res_first; p.rowmask = rowmask; p.mask_cols = mask_cols;
   p.act = act; p.act_cols = act_cols; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
-  p.ksplit = 1; p.kchunk = K; p.ws = nullptr; p.Wh = w_hi; p.Wl = w_lo;
+  p.ksplit = 1; p.kchunk = K; p.ws = nullptr;
   if (ksplit > 1) {
     MDQE_CHECK_PTR(splitk_ws);
     int kc = (K + ksplit - 1) / ksplit; kc = (kc + 31) / 32 * 32;
@@ -333,8 +332,7 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
 
 extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                                     int NI, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                    int act, const float* residual, long ldr, int res_first, int tile, const void* w_hi,
-                                    const void* w_lo, void* stream) {
+                                    int act, const float* residual, long ldr, int res_first, int tile, void* stream) {
   MDQE_REQUIRE(NI >= 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MDQE_REQUIRE(Cin % 32 == 0);
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
@@ -351,7 +349,7 @@ extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const flo
   p.conv = 1; p.H = H; p.Wd = Wd; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = 0; p.res_first = res_first; p.img_stride = x_img_stride; p.rowmask = nullptr; p.mask_cols = 0;
   p.act = act; p.act_cols = 0; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
-  p.ksplit = 1; p.kchunk = p.K; p.ws = nullptr; p.Wh = w_hi; p.Wl = w_lo;
+  p.ksplit = 1; p.kchunk = p.K; p.ws = nullptr;
   mdqe_clear_error();
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }

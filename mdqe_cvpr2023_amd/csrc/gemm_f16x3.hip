@@ -259,278 +259,3 @@ static int launch_f16x3(const GemmParams& p, hipStream_t st) {
 int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st) {
   return tile == 2 ? launch_f16x3<128, 64>(p, st) : launch_f16x3<128, 128>(p, st);
 }
-
-// =================================================================================================
-// v2: LDS-DMA ring.  The register-staged kernel above keeps only ONE K-step of global loads in flight
-// (its 8 float4 staging registers), which is less than the memory latency at 16x-rate MFMAs.  Here:
-//   * A (fp32 activations) streams HBM/L2 -> LDS with buffer_load ... lds into a 3-deep ring (two
-//     K-steps in flight, no VGPRs), rows 128 B, source-side XOR swizzle as in gemm.hip; the split into
-//     f16 hi / scaled lo happens on the fragment (2 x ds_read_b128 -> 8 floats -> h8 hi, h8 lo);
-//   * W arrives PRE-SPLIT as two f16 planes [N][K] (weights are constants: split once at load time by
-//     mdqe_split_f16x3), also via LDS-DMA (64-B rows, chunk XOR (row>>2)&3) -> no conversion for B.
-// One 128x128 block per CU (96 KB ring), 4 waves, counted vmcnt + raw s_barrier.
-// =================================================================================================
-template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN)
-gemm_nt_f16x3_dma_kernel(const GemmParams p) {
-  constexpr int NW = WM * WN;
-  constexpr int NT_ = 64 * NW;
-  constexpr int BK = 32;
-  constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
-  constexpr int NS = 3;
-  constexpr int A_BYTES = BM * BK * 4;                 // fp32 tile
-  constexpr int W_BYTES = BN * BK * 2;                 // one f16 plane
-  constexpr int STAGE = A_BYTES + 2 * W_BYTES;         // 32 KB at 128x128
-  constexpr int IA = BM / 8 / NW;                      // A instructions per wave per stage (8 rows x 128 B each)
-  constexpr int IW = BN / 16 / NW;                     // W instructions per wave per plane (16 rows x 64 B each)
-  static_assert((BM / 8) % NW == 0 && (BN / 16) % NW == 0, "tile split");
-  extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  char* lds = reinterpret_cast<char*>(lds_f);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int nblk = nbm * nbn;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
-  const int bm = bid / nbn, bn = bid % nbn;
-  const int m0 = bm * BM, n0 = bn * BN;
-
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wh, 0, p.w_bytes / 2, 0x00020000);
-  const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wl, 0, p.w_bytes / 2, 0x00020000);
-
-  // A: instruction j of this wave covers tile rows (wave*IA + j)*8 .. +7; lane -> row += lane>>3, chunk' = lane&7
-  unsigned arow[IA]; int ih0[IA], iw0[IA], acs[IA];
-#pragma unroll
-  for (int j = 0; j < IA; ++j) {
-    const int irow = (wave * IA + j) * 8 + (lane >> 3);
-    acs[j] = (lane & 7) ^ ((irow >> 1) & 7);
-    int m = m0 + irow; if (m > p.M - 1) m = p.M - 1;
-    ih0[j] = 0; iw0[j] = 0;
-    if (p.conv) {
-      const int ow = m % p.OW; const int t = m / p.OW; const int oh = t % p.OH; const int img = t / p.OH;
-      ih0[j] = oh * p.stride - p.pad; iw0[j] = ow * p.stride - p.pad;
-      arow[j] = (unsigned)(((long)img * p.img_stride + ((long)ih0[j] * p.Wd + iw0[j]) * p.Cin) * 4);
-    } else {
-      arow[j] = (unsigned)((long)m * p.lda * 4);
-    }
-  }
-  // W planes: instruction j covers tile rows (wave*IW + j)*16 .. +15; lane -> row += lane>>2, chunk' = lane&3 (8 halves)
-  unsigned wrow[IW]; int wcs[IW];
-#pragma unroll
-  for (int j = 0; j < IW; ++j) {
-    const int irow = (wave * IW + j) * 16 + (lane >> 2);
-    wcs[j] = (lane & 3) ^ ((irow >> 2) & 3);
-    int n = n0 + irow; if (n > p.N - 1) n = p.N - 1;
-    wrow[j] = (unsigned)((long)n * p.K * 2);
-  }
-
-  auto issue = [&](int kt, int slot) {
-    const int k0 = kt * BK;
-    int tap_off = 0, kh = 0, kw = 0;
-    if (p.conv) {
-      const int tap = k0 / p.Cin; const int cin0 = k0 - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW;
-      tap_off = ((kh * p.Wd + kw) * p.Cin + cin0) * 4;
-    }
-    char* base = lds + slot * STAGE;
-#pragma unroll
-    for (int j = 0; j < IA; ++j) {
-      const int kk = k0 + acs[j] * 4;
-      unsigned off;
-      if (p.conv) {
-        const int ih = ih0[j] + kh, iw = iw0[j] + kw;
-        const bool ok = (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.Wd);
-        off = ok ? arow[j] + (unsigned)tap_off + (unsigned)(acs[j] * 16) : OOB_OFF;
-      } else {
-        off = kk < p.K ? arow[j] + (unsigned)(kk * 4) : OOB_OFF;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + (wave * IA + j) * 1024), 16, off, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < IW; ++j) {
-      const int kk = k0 + wcs[j] * 8;
-      const unsigned off = kk < p.K ? wrow[j] + (unsigned)(kk * 2) : OOB_OFF;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave * IW + j) * 1024), 16, off, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (__attribute__((address_space(3))) void*)(base + A_BYTES + W_BYTES + (wave * IW + j) * 1024), 16, off, 0, 0, 0);
-    }
-  };
-
-  f32x16 acc[MT][NT], acx[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acx[i][j][r] = 0.f; }
-
-  const int kbeg = p.ksplit > 1 ? blockIdx.y * p.kchunk : 0;
-  const int kend = p.ksplit > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
-  const int kt0 = kbeg / BK;
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  issue(kt0, 0);
-  if (nk > 1) issue(kt0 + 1, 1);
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed: at most the (IA + 2*IW) LDS-DMAs of stage kt+1 may still be in flight
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + 2 * IW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                        // everyone's part of stage kt landed; slot (kt+2)%3 is free
-    if (kt + 2 < nk) issue(kt0 + kt + 2, (kt + 2) % NS);
-    const char* sb = lds + (kt % NS) * STAGE;
-    const float* sA = reinterpret_cast<const float*>(sb);
-    const _Float16* sH = reinterpret_cast<const _Float16*>(sb + A_BYTES);
-    const _Float16* sL = reinterpret_cast<const _Float16*>(sb + A_BYTES + W_BYTES);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      h8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * (BM / WM) + i * 32 + lr;
-        const int c0 = 4 * g + 2 * lh;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + row * BK + ((c0 ^ ((row >> 1) & 7)) << 2));
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + row * BK + (((c0 + 1) ^ ((row >> 1) & 7)) << 2));
-        const h2 a0 = pkrtz(x0[0], x0[1]), a1 = pkrtz(x0[2], x0[3]), a2 = pkrtz(x1[0], x1[1]), a3 = pkrtz(x1[2], x1[3]);
-        const h2 d0 = pkrtz((x0[0] - (float)a0[0]) * 2048.f, (x0[1] - (float)a0[1]) * 2048.f);
-        const h2 d1 = pkrtz((x0[2] - (float)a1[0]) * 2048.f, (x0[3] - (float)a1[1]) * 2048.f);
-        const h2 d2 = pkrtz((x1[0] - (float)a2[0]) * 2048.f, (x1[1] - (float)a2[1]) * 2048.f);
-        const h2 d3 = pkrtz((x1[2] - (float)a3[0]) * 2048.f, (x1[3] - (float)a3[1]) * 2048.f);
-        ah[i] = h8{a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
-        al[i] = h8{d0[0], d0[1], d1[0], d1[1], d2[0], d2[1], d3[0], d3[1]};
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * (BN / WN) + j * 32 + lr;
-        const int pos = row * BK + (((2 * g + lh) ^ ((row >> 2) & 3)) << 3);
-        bh[j] = *reinterpret_cast<const h8*>(sH + pos);
-        bl[j] = *reinterpret_cast<const h8*>(sL + pos);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
-        }
-    }
-  }
-
-  // ---- epilogue: identical to the register-staged kernel --------------------------------------------
-  __syncthreads();
-  float* sC = lds_f;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int col = wn * (BN / WN) + j * 32 + lr;
-        sC[row * BN + col] = acc[i][j][r] + acx[i][j][r] * (1.0f / 2048.f);
-      }
-  __syncthreads();
-  constexpr int C4 = BN / 4;
-  constexpr int NV = BM * C4 / NT_;
-  if (p.ksplit > 1) {
-    float* w = p.ws + (long)blockIdx.y * p.M * p.N;
-    for (int it = 0; it < NV; ++it) {
-      const int idx = it * NT_ + tid;
-      const int row = idx / C4, c4 = idx - row * C4;
-      const int m = m0 + row, n = n0 + c4 * 4;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < p.N) w[(long)m * p.N + n + e] = sC[row * BN + c4 * 4 + e];
-    }
-    return;
-  }
-  const bool vec = p.vec_ok;
-  int rr0 = 0;
-  if (p.residual != nullptr && p.res_mod > 0) rr0 = m0 % p.res_mod;
-#pragma unroll 4
-  for (int it = 0; it < NV; ++it) {
-    const int idx = it * NT_ + tid;
-    const int row = idx / C4, c4 = idx - row * C4;
-    const int m = m0 + row, n = n0 + c4 * 4;
-    if (m >= p.M || n >= p.N) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * BN + c4 * 4);
-    const bool full = vec && (n + 3 < p.N);
-    long rrow = m;
-    if (p.res_mod > 0) { int t = rr0 + row; while (t >= p.res_mod) t -= p.res_mod; rrow = t; }
-    const bool masked = p.rowmask != nullptr && p.rowmask[m];
-    if (full) {
-      if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-      if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
-      if (p.res_first) v += rv;
-      if (p.act != MDQE_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (p.act_cols <= 0 || n + e < p.act_cols) v[e] = mdqe_act(v[e], p.act);
-      }
-      if (!p.res_first) v += rv;
-      if (masked) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < p.mask_cols) v[e] = 0.f;
-      }
-      *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) break;
-        float x = v[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f);
-        const float rv = p.residual != nullptr ? p.residual[rrow * p.ldr + n + e] : 0.f;
-        if (p.res_first) x += rv;
-        if (p.act != MDQE_ACT_NONE && (p.act_cols <= 0 || n + e < p.act_cols)) x = mdqe_act(x, p.act);
-        if (!p.res_first) x += rv;
-        if (masked && n + e < p.mask_cols) x = 0.f;
-        p.C[(long)m * p.ldc + n + e] = x;
-      }
-    }
-  }
-}
-
-int mdqe_launch_gemm_f16x3_dma(const GemmParams& p, hipStream_t st) {
-  constexpr int BM = 128, BN = 128;
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t smem = 3 * (BM * 32 * 4 + 2 * BN * 32 * 2);          // 96 KB ring (>= 64 KB epilogue restage)
-  auto kern = gemm_nt_f16x3_dma_kernel<BM, BN, 2, 2>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(256), smem, st, p);
-  return mdqe_launch_status();
-}
-
-// W [n] fp32 -> hi/lo f16 planes with the same split as the in-kernel one
-__global__ void __launch_bounds__(256)
-split_f16x3_kernel(const float* __restrict__ w, long n, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += (long)gridDim.x * blockDim.x * 2) {
-    const float x0 = w[i], x1 = (i + 1 < n) ? w[i + 1] : 0.f;
-    const h2 a = pkrtz(x0, x1);
-    const h2 d = pkrtz((x0 - (float)a[0]) * 2048.f, (x1 - (float)a[1]) * 2048.f);
-    hi[i] = a[0]; lo[i] = d[0];
-    if (i + 1 < n) { hi[i + 1] = a[1]; lo[i + 1] = d[1]; }
-  }
-}
-
-extern "C" int mdqe_split_f16x3(const float* w, long n, void* hi, void* lo, void* stream) {
-  MDQE_REQUIRE(n >= 0);
-  if (n == 0) return MDQE_OK;
-  MDQE_CHECK_PTR(w); MDQE_CHECK_PTR(hi); MDQE_CHECK_PTR(lo);
-  mdqe_clear_error();
-  long nb = (n / 2 + 255) / 256; if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(split_f16x3_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, n, (_Float16*)hi, (_Float16*)lo);
-  return mdqe_launch_status();
-}

@@ -18,11 +18,9 @@ struct GemmParams {
   int vec_ok;               // C/bias/residual are 16-B aligned with ld % 4 == 0: float4 epilogue
   int ksplit, kchunk;       // split-K: blockIdx.y = split, K range [y*kchunk, (y+1)*kchunk); raw partials -> ws
   float* ws;                // [ksplit][M][N] partial sums (deterministic two-pass reduction)
-  const void* Wh; const void* Wl;   // optional pre-split f16 planes of W (f16x3 LDS-DMA kernel), else null
 };
 
 #define OOB_OFF 0xFFFFFFF0u
 
 // defined in gemm_f16x3.hip
 int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st);
-int mdqe_launch_gemm_f16x3_dma(const GemmParams& p, hipStream_t st);

@@ -231,25 +231,6 @@ class Packed:
         ii, jj = torch.meshgrid(torch.arange(nb), torch.arange(nb), indexing="ij")
         ind = torch.stack([jj, ii], -1).view(-1, 2)
         self.relpos = (ind[:, None] - ind[None]).abs().to(dev)          # transformer_dec.py:61-64
-        self._register_weights()
-
-    def _register_weights(self):
-        """Pre-split every constant GEMM/conv weight for the f16x3 fast mode (f16 hi + scaled lo planes; +1x weight memory)."""
-        seen = set()
-
-        def walk(o):
-            if torch.is_tensor(o):
-                if o.is_cuda and o.dtype == torch.float32 and o.dim() >= 2 and o.numel() >= 4096 and o.data_ptr() not in seen:
-                    seen.add(o.data_ptr())
-                    ops.register_weight(o)
-            elif isinstance(o, (list, tuple)):
-                for v in o:
-                    walk(v)
-            elif isinstance(o, NS):
-                for v in vars(o).values():
-                    walk(v)
-        for v in vars(self).values():
-            walk(v)
 
 
 # ------------------------------------------------------------------------------------------------

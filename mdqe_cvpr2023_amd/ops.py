@@ -17,30 +17,6 @@ def set_gemm_precision(mode):
     check(lib.mdqe_set_gemm_precision({"f32": 0, "f16x3": 1}[mode]), "set_gemm_precision")
 
 
-_wsplit = {}      # weight.data_ptr() -> (weight (kept alive), hi plane, lo plane)
-
-
-def register_weight(w):
-    """Pre-split a CONSTANT weight matrix / packed conv filter for the f16x3 kernels (done once at model load).  The registry
-    keeps the tensor alive, so its address can never be reused by another tensor."""
-    if w is None or not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
-        return
-    key = w.data_ptr()
-    if key in _wsplit:
-        return
-    hi = torch.empty(w.numel(), dtype=torch.float16, device=w.device)
-    lo = torch.empty(w.numel(), dtype=torch.float16, device=w.device)
-    check(lib.mdqe_split_f16x3(ptr(w), w.numel(), ptr(hi), ptr(lo), cur_stream()), "split_f16x3")
-    _wsplit[key] = (w, hi, lo)
-
-
-def _split_of(w):
-    e = _wsplit.get(w.data_ptr())
-    if e is None or e[0].numel() != w.numel():
-        return None, None
-    return e[1], e[2]
-
-
 def get_gemm_precision():
     return {0: "f32", 1: "f16x3"}[lib.mdqe_get_gemm_precision()]
 
@@ -93,7 +69,7 @@ def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=Non
         ws = _workspace(ksplit * M * N * 4 + 64, x.device)
     check(lib.mdqe_gemm_nt_f32(ptr(x2), lda, ptr(weight), ptr(bias), ptr(out), ldc_, M, N, K, ACT[act], act_cols,
                                ptr(residual), ldr, res_mod, int(res_first), ptr(rowmask), mask_cols, tile, ksplit, ptr(ws),
-                               *[ptr(t) for t in _split_of(weight)], cur_stream()), "gemm_nt_f32")
+                               cur_stream()), "gemm_nt_f32")
     if x.dim() != 2 and ldc is None and out.dim() == 2 and out.shape == (M, N):
         return out.view(*x.shape[:-1], N)
     return out
@@ -115,8 +91,7 @@ def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None
     ldy = out.stride(-2)
     ldr = residual.stride(-2) if residual is not None else 0
     check(lib.mdqe_conv2d_nhwc_f32(ptr(x), xis, ptr(w_packed), ptr(bias), ptr(out), ldy, NI, H, W, Cin, Cout, KH, KW, stride,
-                                   pad, ACT[act], ptr(residual), ldr, int(res_first), tile, *[ptr(t) for t in _split_of(w_packed)],
-                                   cur_stream()), "conv2d_nhwc_f32")
+                                   pad, ACT[act], ptr(residual), ldr, int(res_first), tile, cur_stream()), "conv2d_nhwc_f32")
     return out
 
 

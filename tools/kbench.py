@@ -68,8 +68,6 @@ def bench_gemm(args):
                                 ("enc_ffn1_4f", 20400, 1024, 256, 1), ("dec_q_784", 784, 256, 256, 3),
                                 ("dec_val_4f", 20400, 256, 256, 1), ("dec_val_4f_t3", 20400, 256, 256, 3)):
         x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
-        if ops.get_gemm_precision() == "f16x3":
-            ops.register_weight(w)
         out = torch.empty(M, N, device="cuda")
         ms = time_ms(lambda: ops.linear(x, w, b, out=out, tile=tile), iters=20, warm=5)
         tf = 2.0 * M * N * K / ms / 1e9
@@ -80,8 +78,6 @@ def bench_gemm(args):
                                                ("res4_3x3", 30, 24, 40, 256, 256, 3, 1, 1), ("res5_3x3", 30, 12, 20, 512, 512, 3, 1, 1),
                                                ("res4_1x1", 30, 24, 40, 1024, 256, 1, 1, 0)):
         x = torch.randn(NI, H, W, Cin, device="cuda"); w = torch.randn(Cout, k, k, Cin, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
-        if ops.get_gemm_precision() == "f16x3":
-            ops.register_weight(w)
         ms = time_ms(lambda: ops.conv2d_nhwc(x, w, b, s, p, act="relu"), iters=20, warm=5)
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         tf = 2.0 * NI * OH * OW * Cout * Cin * k * k / ms / 1e9
