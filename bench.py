@@ -108,12 +108,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (1-GPU box): MDQE_BENCH_BACKEND=gloo + MDQE_BENCH_ONE_DEVICE=1 run all ranks on cuda:0 without RCCL
+    one_dev = os.environ.get("MDQE_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("MDQE_BENCH_BACKEND", "nccl")
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from mdqe_cvpr2023_amd import _lib
     _lib.load_library()                                   # loud if the HIP library is missing
