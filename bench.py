@@ -64,11 +64,16 @@ class GemmMeter:
         return dict(launches=len(self.rec), avg_us=1e3 * ms / len(self.rec), tflops=fl / ms / 1e9)
 
 
-def synth_video(n, seed, h=360, w=640):
+def synth_video(f0, f1, seed, h=360, w=640):
+    """Frames [f0, f1) of the synthetic video: frame f depends only on (seed, f), so every rank can build just its shard
+    (temporally coherent: a fixed base image blended with per-frame noise)."""
     g = torch.Generator().manual_seed(seed)
     base = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).float()
-    fr = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).float()
-    return (0.7 * base[None] + 0.3 * fr).round().to(torch.uint8)       # temporally coherent frames
+    out = torch.empty(f1 - f0, 3, h, w, dtype=torch.uint8)
+    for f in range(f0, f1):
+        g.manual_seed(seed * 1000003 + f + 1)
+        out[f - f0] = (0.7 * base + 0.3 * torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).float()).round().to(torch.uint8)
+    return out
 
 
 def cpu_baseline(cfg, sd, frames4):
@@ -139,9 +144,9 @@ def main():
 
     L = args.frames * world
     T = cfg.n_frames_test
-    video = synth_video(L, seed=0, h=fh, w=fw)            # identical on all ranks; each keeps its shard (+halo) in HBM
     f0, f1 = sharding.frame_range(L, world, rank, T, cfg.clip_stride)
-    shard = video[f0:f1].cuda()
+    video = synth_video(f0, f1, seed=0, h=fh, w=fw)       # only this rank's frames (+halo), kept in HBM
+    shard = video.cuda()
     torch.cuda.synchronize()
 
     def step():
@@ -217,7 +222,7 @@ def main():
         if fast:
             line["fast_mode"] = fast
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
