@@ -7,9 +7,10 @@
 Metric (BASELINE.json): frames/sec, eval-only, R50 OVIS 360p 4-frame clips.  One "step" = one pass of
 `MDQE.forward` over one synthetic video shard of --frames 360x640 uint8 frames already resident in HBM
 (stride-1 4-frame clips, 30-frame tracker windows, random reference-style weights with the zero-init
-trap removed).  N>1: ONE long video of N*frames frames is sharded over ranks as
-contiguous frame ranges (+T-1 halo); per-clip results are all-gathered over RCCL and every rank replays
-the tracker in global clip order (weak scaling: per-GPU frames fixed).  Rank 0 prints ONE JSON line.
+trap removed).  N>1: ONE long video of N*frames frames; its 30-frame chunks (+T-1 halo) are dealt
+round-robin to the ranks, each round's clip results are all-gathered over RCCL and every rank replays the
+tracker in global clip order while the next round computes (weak scaling: per-GPU frames fixed).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -144,15 +145,20 @@ def main():
 
     L = args.frames * world
     T = cfg.n_frames_test
-    f0, f1 = sharding.frame_range(L, world, rank, T, cfg.clip_stride)
-    video = synth_video(f0, f1, seed=0, h=fh, w=fw)       # only this rank's frames (+halo), kept in HBM
-    shard = video.cuda()
+    if world == 1:
+        video = synth_video(0, L, seed=0, h=fh, w=fw)
+        shard = video.cuda()                               # the whole video, resident in HBM
+    else:
+        # chunks of one tracker window dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ...
+        plan = sharding.chunk_plan(L, T, cfg.clip_stride, cfg.n_frames_window_test)
+        chunk_frames = {g: synth_video(plan[g][1], plan[g][2], seed=0, h=fh, w=fw).cuda() for g in sharding.owned_chunks(plan, world, rank)}
+        shard = next(iter(chunk_frames.values()))
     torch.cuda.synchronize()
 
     def step():
         if world == 1:
             return model([{"image": shard, "height": fh, "width": fw}])
-        return sharding.run_sharded(model, shard, f0, L, rank, world, dist, out_size=(fh, fw))
+        return sharding.run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size=(fh, fw))
 
     def sync():
         if dist is not None:
@@ -207,7 +213,8 @@ def main():
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
                        "instances_out": len(out["pred_scores"]),
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
-                       "parallelism": "1 process/GPU; frame-range shards + RCCL all-gather of clip results" if world > 1 else "single GPU"},
+                       "parallelism": "1 process/GPU; 30-frame chunks dealt round-robin, per-round RCCL all-gather of clip results, "
+                                      "tracker replay overlapped with the next round" if world > 1 else "single GPU"},
         }
         if g:
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_kernel<128,128,2,2>", "achieved": g["tflops"],

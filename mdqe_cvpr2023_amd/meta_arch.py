@@ -118,7 +118,7 @@ class MDQE(nn.Module):
                 break
         return clips
 
-    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None):
+    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res)."""
         eng = self.engine
@@ -159,6 +159,8 @@ class MDQE(nn.Module):
         i = 0
         if clips:
             prepare(0)
+        if primed:
+            yield None                            # per-frame work of the first chunk is queued; the caller resumes later
         while i < len(clips):
             cache, base, nxt = st["cache"], st["base"], st["nxt"]
             ls, le = clips[i][0] - frame_offset, clips[i][1] - frame_offset
@@ -184,46 +186,11 @@ class MDQE(nn.Module):
 
     def merge_clips(self, results, frame_hw, out_size, mask_hw):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""
-        cfg = self.cfg
-        T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
-        # MODEL.MDQE.MERGE_ON_CPU exists in the reference to fit 16-40 GB GPUs (mdqe/mdqe.py:185-186,354-355); with
-        # 288 GB of HBM the merge always stays on the device (results are identical either way).
-        merge_dev = self.device
-        saved, tracker = 0, None
-        cls_clips, windows, f_off = [], [], 0
-        # The tracker runs on its own HIP stream: its small kernels and its per-clip host syncs then overlap with the
-        # next chunk's per-frame work that the producer has already queued on the main stream.
-        use_side = merge_dev.type == "cuda"
-        main = torch.cuda.current_stream(merge_dev) if use_side else None
-        if use_side and self._trk_stream is None:
-            self._trk_stream = torch.cuda.Stream(merge_dev)
-        side = self._trk_stream if use_side else None
-        for start, end, last, res in results:
-            ctx = torch.cuda.stream(side) if use_side else contextlib.nullcontext()
-            with ctx:
-                if use_side:
-                    if res.get("ready") is not None:
-                        side.wait_event(res["ready"])
-                    else:
-                        side.wait_stream(main)
-                    res["pred_masks"].record_stream(side)
-                if tracker is None:
-                    tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
-                                          mask_hw, merge_dev, cfg.apply_cls_thres)
-                tracker.update(Clips(range(start, end), res))
-                if last or (start + stride >= win * (saved + 1)):
-                    c, m = tracker.get_result(is_last_clip=last)    # m: mean logits [n, F, Hm, Wm] of this window
-                    cls_clips.append(c)
-                    windows.append((f_off, m.contiguous()))
-                    f_off += m.shape[1]
-                    saved += 1
-            if last:
+        m = ClipMerger(self, frame_hw, out_size, mask_hw)
+        for item in results:
+            if m.feed(*item):
                 break
-        if use_side:
-            main.wait_stream(side)
-            for _, m in windows:
-                m.record_stream(main)
-        return self.inference_video(out_size, cls_clips, windows, frame_hw, f_off)
+        return m.finish()
 
     def to_device_frames(self, imgs):
         stack = imgs if torch.is_tensor(imgs) else torch.stack(list(imgs))
@@ -269,6 +236,58 @@ class MDQE(nn.Module):
         pos = {i: p for p, i in enumerate(sel)}
         return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels,
                 "pred_masks": [host[pos[i]] for i in inst]}
+
+
+class ClipMerger:
+    """Incremental form of the clip loop's second half (mdqe/mdqe.py:337-366): tracker update per clip, window flushes,
+    final video merge.  The tracker runs on its own HIP stream so that its small kernels and per-clip host syncs overlap
+    with per-frame work the producer has already queued on the main stream."""
+
+    def __init__(self, model, frame_hw, out_size, mask_hw):
+        self.model, self.frame_hw, self.out_size, self.mask_hw = model, frame_hw, out_size, mask_hw
+        # MODEL.MDQE.MERGE_ON_CPU exists in the reference to fit 16-40 GB GPUs (mdqe/mdqe.py:185-186,354-355); with
+        # 288 GB of HBM the merge always stays on the device (results are identical either way).
+        self.dev = model.device
+        self.use_side = self.dev.type == "cuda"
+        self.main = torch.cuda.current_stream(self.dev) if self.use_side else None
+        if self.use_side and model._trk_stream is None:
+            model._trk_stream = torch.cuda.Stream(self.dev)
+        self.side = model._trk_stream if self.use_side else None
+        self.saved, self.tracker = 0, None
+        self.cls_clips, self.windows, self.f_off = [], [], 0
+        self.done = False
+
+    def feed(self, start, end, last, res):
+        """Returns True once the last clip has been consumed."""
+        cfg = self.model.cfg
+        T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
+        ctx = torch.cuda.stream(self.side) if self.use_side else contextlib.nullcontext()
+        with ctx:
+            if self.use_side:
+                if res.get("ready") is not None:
+                    self.side.wait_event(res["ready"])
+                else:
+                    self.side.wait_stream(self.main)
+                res["pred_masks"].record_stream(self.side)
+            if self.tracker is None:
+                self.tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
+                                           self.mask_hw, self.dev, cfg.apply_cls_thres)
+            self.tracker.update(Clips(range(start, end), res))
+            if last or (start + stride >= win * (self.saved + 1)):
+                c, m = self.tracker.get_result(is_last_clip=last)   # m: mean logits [n, F, Hm, Wm] of this window
+                self.cls_clips.append(c)
+                self.windows.append((self.f_off, m.contiguous()))
+                self.f_off += m.shape[1]
+                self.saved += 1
+        self.done = bool(last)
+        return self.done
+
+    def finish(self):
+        if self.use_side:
+            self.main.wait_stream(self.side)
+            for _, m in self.windows:
+                m.record_stream(self.main)
+        return self.model.inference_video(self.out_size, self.cls_clips, self.windows, self.frame_hw, self.f_off)
 
 
 try:                                              # drop-in registration when detectron2 is present

@@ -95,6 +95,63 @@ def all_gather_clips(local, T, dist, world, device, proto_shapes):
     return merged
 
 
+# ------------------------------------------------------------------------------------------------
+# Round-robin chunks: overlap the (inherently sequential) tracker replay with compute
+# ------------------------------------------------------------------------------------------------
+def chunk_plan(L, T, stride, chunk):
+    """Global chunks in clip order: [(clips, f0, f1)] with clips = those that START in frames [g*chunk, (g+1)*chunk) and
+    [f0, f1) the frames they need (chunk + (T-1)-frame halo)."""
+    from .meta_arch import MDQE
+    clips = MDQE.clip_schedule(L, T, stride)
+    plan = []
+    g = 0
+    while g * chunk < L:
+        cl = [c for c in clips if g * chunk <= c[0] < (g + 1) * chunk]
+        if cl:
+            plan.append((cl, cl[0][0], max(c[1] for c in cl)))
+        g += 1
+    return plan
+
+
+def owned_chunks(plan, world, rank):
+    """Chunk g goes to rank g % world: after round q the chunks q*world .. q*world+world-1 -- the NEXT ones in global clip
+    order -- are complete, so their all-gather and tracker replay run while round q+1 computes."""
+    return [g for g in range(len(plan)) if g % world == rank]
+
+
+def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size):
+    """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns."""
+    from .meta_arch import ClipMerger
+    cfg = model.cfg
+    T = cfg.n_frames_test
+    any_fr = next(iter(chunk_frames.values()))
+    h, w = int(any_fr.shape[-2]), int(any_fr.shape[-1])
+    geo = model.engine.geometry(h, w)
+    ms = cfg.match_stride
+    mask_hw = (geo.Hp // ms, geo.Wp // ms)
+    proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
+             "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((T,) + tuple(mask_hw), torch.float32)}
+    merger = ClipMerger(model, (h, w), out_size, mask_hw)
+    rounds = (len(plan) + world - 1) // world
+
+    def start(q):
+        g = q * world + rank
+        if q >= rounds or g >= len(plan):
+            return None
+        gen = model.iter_clip_results(chunk_frames[g], plan[g][0], plan[g][1], primed=True)
+        next(gen)                                  # queues the chunk's per-frame work (async) and returns
+        return gen
+
+    cur = start(0)
+    for q in range(rounds):
+        local = [r for r in cur] if cur is not None else []        # decoder + clip inference of this rank's chunk
+        merged = all_gather_clips(local, T, dist, world, any_fr.device, proto)
+        cur = start(q + 1)                         # next round's per-frame work is on the GPU before the replay starts
+        for item in merged:                        # global clip order within the round: chunk q*world, q*world+1, ...
+            merger.feed(*item)
+    return merger.finish()
+
+
 def run_sharded(model, shard_frames, f0, L, rank, world, dist, out_size):
     """shard_frames: device tensor of this rank's frames, first one is global frame f0."""
     cfg = model.cfg

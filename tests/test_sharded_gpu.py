@@ -35,15 +35,22 @@ def worker(rank, world, port, outdir):
     model = MDQE(cfg, seed=5).eval()
     video = _video()
     L = video.shape[0]
-    f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
     with torch.no_grad():
-        out = sharding.run_sharded(model, video[f0:f1].cuda(), f0, L, rank, world, dist, (64, 96))
+        if os.environ.get("MDQE_TEST_SHARDING") == "contiguous":
+            f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
+            out = sharding.run_sharded(model, video[f0:f1].cuda(), f0, L, rank, world, dist, (64, 96))
+        else:
+            plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, 4)       # 4-frame chunks -> 3 chunks, 2 rounds
+            frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}
+            out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96))
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_video_equals_single_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["round_robin", "contiguous"])
+def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
     from mdqe_cvpr2023_amd.meta_arch import MDQE
+    os.environ["MDQE_TEST_SHARDING"] = mode
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]

@@ -94,3 +94,15 @@ def test_ranges_cover_all_clips_once():
         for r in range(world):
             seen += sharding.owned_clips(clips, L_, world, r)
         assert sorted(seen) == clips
+
+
+def test_round_robin_plan_covers_all_clips_in_order():
+    for L_, T, chunk, world in ((13, 3, 4, 2), (120, 4, 30, 8), (960, 4, 30, 8), (7, 4, 30, 4), (61, 4, 30, 3)):
+        plan = sharding.chunk_plan(L_, T, 1, chunk)
+        clips = clip_schedule(L_, T, 1)
+        flat = [c for ch in plan for c in ch[0]]
+        assert flat == clips                                         # global order preserved, every clip once
+        for cl, f0, f1 in plan:
+            assert all(f0 <= s and e <= f1 for s, e, _ in cl)       # halo covers every clip of the chunk
+        owned = sorted(g for r in range(world) for g in sharding.owned_chunks(plan, world, r))
+        assert owned == list(range(len(plan)))
