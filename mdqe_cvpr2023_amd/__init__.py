@@ -5,5 +5,15 @@ this package is the host-side mirror of the reference's operator surface for tha
 (SURVEY.md §8b).  It requires the compiled library: there is NO CPU or PyTorch fallback.
 """
 from ._lib import lib, load_library, LibraryMissing  # noqa: F401
+from .d2_compat import add_mdqe_config, add_swinl_config, add_swinb_config, add_swins_config, add_swint_config  # noqa: F401
 
-__all__ = ["lib", "load_library", "LibraryMissing"]
+
+def __getattr__(name):                 # `from mdqe_cvpr2023_amd import MDQE` without importing torch.nn at package import
+    if name == "MDQE":
+        from .meta_arch import MDQE
+        return MDQE
+    raise AttributeError(name)
+
+
+__all__ = ["lib", "load_library", "LibraryMissing", "MDQE", "add_mdqe_config", "add_swinl_config", "add_swinb_config",
+           "add_swins_config", "add_swint_config"]
