@@ -87,12 +87,24 @@ int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* v
 int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                      int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
                      int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
-                     float* splitk_ws, void* stream);
+                     float* splitk_ws, const void* w_split, void* stream);
 
 /* GEMM arithmetic of the 128x128 tile (process-wide): 0 = exact fp32 MFMA (default), 1 = "f16x3": operands split
  * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752). */
 int mdqe_set_gemm_precision(int mode);
 int mdqe_get_gemm_precision(void);
+
+/* One-time split of a CONSTANT weight tensor W (n = N*K fp32 values, row-major [N][K]) into the two f16 planes the
+ * f16x3 mode consumes: planes = { hi[n], lo[n] } (4*n bytes), hi = f16_rtz(w), lo = f16_rtz((w - hi) * 2048).
+ * Passing the planes as `w_split` to mdqe_gemm_nt_f32 / mdqe_conv2d_nhwc_f32 (NULL = none) lets mode 1 stream them
+ * straight into LDS (gemm_f16x3w.hip: 128 x 256 tiles, no in-kernel weight conversion); requires K % 32 == 0 and
+ * max|w| < 32752 (f16 range, caller-checked).  Ignored in mode 0.  Weights are constants of the eval path (nn.Linear / conv
+ * parameters, FrozenBatchNorm folded), so this replaces no reference call. */
+int mdqe_f16x3_split_f32(const float* w, long n, void* planes, void* stream);
+
+/* tools/ only: while buf != NULL the f16x3w GEMM kernel writes 4 s_memtime stamps per block (start, prologue done, K loop done,
+ * end) to buf[block*4 ..]; NULL (default) disables. */
+int mdqe_debug_gemm_stamps(void* buf);
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
  * X [NI,H,W,Cin] (Cin % 32 == 0; images x_img_stride floats apart, <=0: dense), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,
@@ -100,7 +112,8 @@ int mdqe_get_gemm_precision(void);
  * mdqe/mdqe.py:27,33; input_proj 3x3 s2 models/mdqe.py:40-43; MaskHead 3x3 segmentation.py:42-57). */
 int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                          int NI, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                         int act, const float* residual, long ldr, int res_first, int tile, void* stream);
+                         int act, const float* residual, long ldr, int res_first, int tile, const void* w_split,
+                         void* stream);
 
 /* ---- LayerNorm over the last dim: y = LN(x + res) * gamma + beta (res may be NULL) -----------------
  * nn.LayerNorm call sites transformer_enc.py:103-108,136; transformer_dec.py:345-358,394-408,466,492. */

@@ -26,9 +26,11 @@ SIGNATURES = {
     "mdqe_swin_window_f32": [p, p, p, i, i, i, i, i, i, i, p],
     "mdqe_window_attn_f32": [p, l, p, l, i, i, i, i, p, p, p, i, p],
     "mdqe_patch_merge_gather_f32": [p, p, i, i, i, i, p],
-    "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, i, p, i, i, i, p, p],
+    "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, i, p, i, i, i, p, p, p],
+    "mdqe_f16x3_split_f32": [p, l, p, p],
+    "mdqe_debug_gemm_stamps": [p],
     "mdqe_mask_row_stats_f32": [p, i, i, i, i, i, p, p, p, p],
-    "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p],
+    "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p, p],
     "mdqe_layernorm_f32": [p, p, p, p, p, l, i, f, p],
     "mdqe_groupnorm_nhwc_f32": [p, l, l, p, l, l, i, i, i, i, p, p, f, i, p, p],
     "mdqe_stem_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],

@@ -272,6 +272,9 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
   return mdqe_launch_status();
 }
 
+static unsigned long long* g_gemm_stamps = nullptr;   // tools/ only: in-kernel phase stamps of the f16x3w kernel
+extern "C" int mdqe_debug_gemm_stamps(void* buf) { g_gemm_stamps = (unsigned long long*)buf; return MDQE_OK; }
+
 static int g_gemm_precision = 0;      // 0: exact fp32 MFMA; 1: f16x3 split on the 128-row tiles (gemm_f16x3.hip)
 extern "C" int mdqe_set_gemm_precision(int mode) {
   if (mode != 0 && mode != 1) return MDQE_EINVAL;
@@ -281,6 +284,7 @@ extern "C" int mdqe_set_gemm_precision(int mode) {
 extern "C" int mdqe_get_gemm_precision(void) { return g_gemm_precision; }
 
 static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
+  p.stamps = g_gemm_stamps;
   p.vec_ok = ((((uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.residual) & 15) == 0) && (p.ldc % 4 == 0) &&
              (p.residual == nullptr || p.ldr % 4 == 0);
   // tile: 0 = auto
@@ -289,6 +293,18 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
     else if (b128 >= 192) tile = 1;
     else tile = 3;
+  }
+  if (tile == 1 && g_gemm_precision == 1 && p.Wh != nullptr && p.K % 32 == 0 && p.N >= 128 && p.N % 4 == 0 &&
+      p.vec_ok && p.ksplit <= 1) {
+    // constant weights with pre-split planes: 128 x BN tile, BN by column waste, then by grid size
+    const int n256 = (p.N + 255) / 256 * 256, n128 = (p.N + 127) / 128 * 128;
+    int bn = 256;
+    if (n256 > n128 || (long)((p.M + 127) / 128) * (n256 / 256) < 200) bn = 128;
+    int rc = mdqe_launch_gemm_f16x3w(p, bn, st);
+    if (rc || p.ksplit <= 1) return rc;
+    long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
+    return mdqe_launch_status();
   }
   if ((tile == 1 || tile == 2) && g_gemm_precision == 1) {
     int rc = mdqe_launch_gemm_f16x3(p, tile, st);
@@ -308,7 +324,7 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
 extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                                 int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
                                 int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
-                                float* splitk_ws, void* stream) {
+                                float* splitk_ws, const void* w_split, void* stream) {
   MDQE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N);
   if (M == 0) return MDQE_OK;
   MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
@@ -320,6 +336,7 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = res_mod; p.res_first = res_first; p.rowmask = rowmask; p.mask_cols = mask_cols;
   p.act = act; p.act_cols = act_cols; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
   p.ksplit = 1; p.kchunk = K; p.ws = nullptr;
+  if (w_split != nullptr) { p.Wh = w_split; p.Wl = (const char*)w_split + (long)N * K * 2; }
   if (ksplit > 1) {
     MDQE_CHECK_PTR(splitk_ws);
     int kc = (K + ksplit - 1) / ksplit; kc = (kc + 31) / 32 * 32;
@@ -332,7 +349,8 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
 
 extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                                     int NI, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                    int act, const float* residual, long ldr, int res_first, int tile, void* stream) {
+                                    int act, const float* residual, long ldr, int res_first, int tile, const void* w_split,
+                                    void* stream) {
   MDQE_REQUIRE(NI >= 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MDQE_REQUIRE(Cin % 32 == 0);
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
@@ -350,6 +368,7 @@ extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const flo
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = 0; p.res_first = res_first; p.img_stride = x_img_stride; p.rowmask = nullptr; p.mask_cols = 0;
   p.act = act; p.act_cols = 0; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
   p.ksplit = 1; p.kchunk = p.K; p.ws = nullptr;
+  if (w_split != nullptr) { p.Wh = w_split; p.Wl = (const char*)w_split + (long)Cout * p.K * 2; }
   mdqe_clear_error();
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }

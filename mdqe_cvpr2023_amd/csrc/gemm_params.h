@@ -18,9 +18,13 @@ struct GemmParams {
   int vec_ok;               // C/bias/residual are 16-B aligned with ld % 4 == 0: float4 epilogue
   int ksplit, kchunk;       // split-K: blockIdx.y = split, K range [y*kchunk, (y+1)*kchunk); raw partials -> ws
   float* ws;                // [ksplit][M][N] partial sums (deterministic two-pass reduction)
+  unsigned long long* stamps;   // debug: per-block s_memtime stamps (mdqe_debug_gemm_stamps), null in production
+  const void* Wh; const void* Wl;   // pre-split f16 planes of W ([N][K] each; gemm_f16x3w.hip) or null
 };
 
 #define OOB_OFF 0xFFFFFFF0u
 
 // defined in gemm_f16x3.hip
 int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st);
+// defined in gemm_f16x3w.hip (bn = 256 or 128)
+int mdqe_launch_gemm_f16x3w(const GemmParams& p, int bn, hipStream_t st);

@@ -81,7 +81,7 @@ class Packed:
             for a, b in ALIASES.items():
                 if k.startswith(a) and (b + k[len(a):]) not in sd:
                     sd[b + k[len(a):]] = sd[k]
-        up = lambda t: t.contiguous().to(dev)
+        up = lambda t: ops.const_weight(t.contiguous().to(dev))      # GEMM-sized ones get f16x3 planes
         C, nh = cfg.hidden_dim, cfg.nheads
         self.dev = dev
 

@@ -21,6 +21,37 @@ def get_gemm_precision():
     return {0: "f32", 1: "f16x3"}[lib.mdqe_get_gemm_precision()]
 
 
+# ---- constant weights: pre-split f16 planes for the f16x3 mode (gemm_f16x3w.hip) ---------------------
+_split = {}          # data_ptr -> (weakref to the weight tensor, its _version, planes tensor)
+
+
+def const_weight(w):
+    """Declare `w` ([N, ...] CUDA fp32, contiguous) a constant GEMM/conv weight: its f16 hi / lo planes are computed
+    once and handed to the kernels as `w_split`.  Returns w.  Tensors the fast kernel cannot take are left alone."""
+    import weakref
+    if not (torch.is_tensor(w) and w.is_cuda and w.dtype == torch.float32 and w.dim() >= 2 and w.is_contiguous()):
+        return w
+    N = w.shape[0]
+    K = w.numel() // max(N, 1)
+    if N < 128 or K % 32 != 0 or float(w.abs().max()) >= 32752.0:
+        return w
+    planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=w.device)
+    check(lib.mdqe_f16x3_split_f32(ptr(w), w.numel(), ptr(planes), cur_stream()), "f16x3_split")
+    _split[w.data_ptr()] = (weakref.ref(w), w._version, planes)
+    return w
+
+
+def _wsplit(w):
+    ent = _split.get(w.data_ptr())
+    if ent is None:
+        return None
+    ref, ver, planes = ent
+    if ref() is not w or w._version != ver:          # freed-and-reused address, or modified in place
+        del _split[w.data_ptr()]
+        return None
+    return planes
+
+
 def _workspace(nbytes, device):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     t = _ws.get(key)
@@ -69,7 +100,7 @@ def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=Non
         ws = _workspace(ksplit * M * N * 4 + 64, x.device)
     check(lib.mdqe_gemm_nt_f32(ptr(x2), lda, ptr(weight), ptr(bias), ptr(out), ldc_, M, N, K, ACT[act], act_cols,
                                ptr(residual), ldr, res_mod, int(res_first), ptr(rowmask), mask_cols, tile, ksplit, ptr(ws),
-                               cur_stream()), "gemm_nt_f32")
+                               ptr(_wsplit(weight)), cur_stream()), "gemm_nt_f32")
     if x.dim() != 2 and ldc is None and out.dim() == 2 and out.shape == (M, N):
         return out.view(*x.shape[:-1], N)
     return out
@@ -91,7 +122,8 @@ def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None
     ldy = out.stride(-2)
     ldr = residual.stride(-2) if residual is not None else 0
     check(lib.mdqe_conv2d_nhwc_f32(ptr(x), xis, ptr(w_packed), ptr(bias), ptr(out), ldy, NI, H, W, Cin, Cout, KH, KW, stride,
-                                   pad, ACT[act], ptr(residual), ldr, int(res_first), tile, cur_stream()), "conv2d_nhwc_f32")
+                                   pad, ACT[act], ptr(residual), ldr, int(res_first), tile, ptr(_wsplit(w_packed)), cur_stream()),
+          "conv2d_nhwc_f32")
     return out
 
 

@@ -250,3 +250,64 @@ def test_gemm_f16x3_accuracy():
         assert float((out.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()) < 3e-6
     finally:
         ops.set_gemm_precision("f32")
+
+
+def test_gemm_f16x3_presplit_weights():
+    """f16x3 with pre-split constant weights (gemm_f16x3w.hip: 128 x 256 / 128 x 128 tiles, single scaled accumulator) vs
+    an fp64 reference and vs the in-kernel-split f16x3 kernel: same accuracy class (<= 4x the fp32 MFMA kernel's error),
+    every epilogue option, ragged M / N / K, conv mode with padding and stride."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(33)
+    try:
+        for (M, N, K) in ((20000, 640, 256), (40000, 256, 1024), (33000, 1024, 256), (26001, 3072, 256), (40000, 328, 136)):
+            x = torch.randn(M, K, generator=g) * 3
+            x[::7] *= 1e-3
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            b = torch.randn(N, generator=g)
+            ref = (x.double() @ w.double().t() + b.double())
+            xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+            ops.set_gemm_precision("f32")
+            e32 = float((ops.linear(xd, wd, bd, tile=1).cpu().double() - ref).abs().max() / ref.abs().max())
+            ops.set_gemm_precision("f16x3")
+            ops.const_weight(wd)
+            assert (ops._wsplit(wd) is not None) == (K % 32 == 0)      # ragged K stays on the in-kernel-split kernel
+            o3 = ops.linear(xd, wd, bd, tile=1).cpu().double()
+            e3 = float((o3 - ref).abs().max() / ref.abs().max())
+            assert e3 < max(4 * e32, 2e-6), (M, N, K, e32, e3)
+            rows = slice(0, M, 7)
+            er = float((o3[rows] - ref[rows]).abs().max() / ref[rows].abs().max())
+            assert er < 5e-6, er
+        # epilogue: gelu on the first columns, residual broadcast by res_mod, row mask, strided output
+        M, N, K = 25600, 640, 256
+        x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / 16; b = torch.randn(N, generator=g)
+        res = torch.randn(5120, N, generator=g); rm = torch.rand(M, generator=g) < 0.2
+        wd = ops.const_weight(w.cuda())
+        out = torch.full((M, N + 64), 7.0, device="cuda")
+        ops.linear(x.cuda(), wd, b.cuda(), act="gelu", act_cols=256, residual=res.cuda(), res_mod=5120, rowmask=rm.cuda(), mask_cols=256,
+                   out=out, ldc=N + 64, tile=1)
+        y = x.double() @ w.double().t() + b.double()
+        y[:, :256] = F.gelu(y[:, :256])
+        y = y + res.double().repeat(M // 5120, 1)
+        y[:, :256][rm] = 0
+        assert float((out[:, :N].cpu().double() - y).abs().max()) < 2e-5
+        assert bool((out[:, N:] == 7.0).all())
+        # in-place update of the weight invalidates the planes (falls back to the in-kernel split, still correct)
+        wd.mul_(2.0)
+        assert ops._wsplit(wd) is None
+        o = ops.linear(x.cuda(), wd, b.cuda(), tile=1).cpu().double()
+        yy = x.double() @ (2 * w.double()).t() + b.double()
+        assert float((o - yy).abs().max() / yy.abs().max()) < 3e-6
+        # implicit-GEMM conv: 3x3 pad 1, 3x3 stride 2, 1x1, with residual-before-relu
+        for (Cin, Cout, k, s, p_) in ((256, 256, 3, 1, 1), (512, 512, 3, 2, 1), (1024, 256, 1, 1, 0)):
+            xi = torch.randn(6, Cin, 24, 40, generator=g); wc = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+            bc = torch.randn(Cout, generator=g)
+            ref = F.conv2d(xi.double(), wc.double(), bc.double(), s, p_)
+            rs = torch.randn(ref.shape, generator=g)
+            ref = F.relu(ref + rs.double())
+            wk = ops.const_weight(wc.permute(0, 2, 3, 1).contiguous().cuda())
+            assert ops._wsplit(wk) is not None
+            out = ops.conv2d_nhwc(xi.permute(0, 2, 3, 1).contiguous().cuda(), wk, bc.cuda(), s, p_, act="relu",
+                                  residual=rs.permute(0, 2, 3, 1).contiguous().cuda(), res_first=True, tile=1)
+            assert float((out.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()) < 3e-6, (Cin, Cout, k, s)
+    finally:
+        ops.set_gemm_precision("f32")

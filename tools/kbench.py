@@ -60,14 +60,15 @@ if __name__ == "__main__":
         bench_msda(a)
 
 
-def bench_gemm(args):
+def bench_gemm(args, const=False):
     from mdqe_cvpr2023_amd import ops
+    cw = ops.const_weight if const else (lambda t: t)
     res = []
     for name, M, N, K, tile in (("enc_qkv_30f", 153000, 640, 256, 1), ("enc_ffn1_30f", 153000, 1024, 256, 1),
                                 ("enc_ffn2_30f", 153000, 256, 1024, 1), ("enc_out_30f", 153000, 256, 256, 1),
                                 ("enc_ffn1_4f", 20400, 1024, 256, 1), ("dec_q_784", 784, 256, 256, 3),
                                 ("dec_val_4f", 20400, 256, 256, 1), ("dec_val_4f_t3", 20400, 256, 256, 3)):
-        x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+        x = torch.randn(M, K, device="cuda"); w = cw(torch.randn(N, K, device="cuda") / K ** 0.5); b = torch.randn(N, device="cuda")
         out = torch.empty(M, N, device="cuda")
         ms = time_ms(lambda: ops.linear(x, w, b, out=out, tile=tile), iters=20, warm=5)
         tf = 2.0 * M * N * K / ms / 1e9
@@ -77,7 +78,7 @@ def bench_gemm(args):
     for name, NI, H, W, Cin, Cout, k, s, p in (("res2_3x3", 30, 96, 160, 64, 64, 3, 1, 1), ("res3_3x3", 30, 48, 80, 128, 128, 3, 1, 1),
                                                ("res4_3x3", 30, 24, 40, 256, 256, 3, 1, 1), ("res5_3x3", 30, 12, 20, 512, 512, 3, 1, 1),
                                                ("res4_1x1", 30, 24, 40, 1024, 256, 1, 1, 0)):
-        x = torch.randn(NI, H, W, Cin, device="cuda"); w = torch.randn(Cout, k, k, Cin, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
+        x = torch.randn(NI, H, W, Cin, device="cuda"); w = cw(torch.randn(Cout, k, k, Cin, device="cuda") * 0.05); b = torch.randn(Cout, device="cuda")
         ms = time_ms(lambda: ops.conv2d_nhwc(x, w, b, s, p, act="relu"), iters=20, warm=5)
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         tf = 2.0 * NI * OH * OW * Cout * Cin * k * k / ms / 1e9
@@ -93,6 +94,8 @@ if __name__ == "__main__" and a.what in ("gemm", "all"):
 if __name__ == "__main__" and a.what in ("gemm", "all"):
     from mdqe_cvpr2023_amd import ops as _ops
     _ops.set_gemm_precision("f16x3")
-    print("--- f16x3 ---")
+    print("--- f16x3 (in-kernel split of both operands) ---")
     bench_gemm(a)
+    print("--- f16x3 (pre-split constant weights) ---")
+    bench_gemm(a, const=True)
     _ops.set_gemm_precision("f32")

@@ -6,7 +6,7 @@ from mdqe_cvpr2023_amd import ops
 M, N, K = 153000, 1024, 256
 if len(sys.argv) > 3:
     M, N, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / 16; b = torch.randn(N, device="cuda")
+x = torch.randn(M, K, device="cuda"); w = ops.const_weight(torch.randn(N, K, device="cuda") / 16); b = torch.randn(N, device="cuda")
 out = torch.empty(M, N, device="cuda")
 for mode in ("f32", "f16x3"):
     ops.set_gemm_precision(mode)
