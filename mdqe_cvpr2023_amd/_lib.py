@@ -4,7 +4,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmdqe_hip.so")
+LIB_PATH = os.environ.get("MDQE_HIP_LIB") or os.path.join(_HERE, "csrc", "libmdqe_hip.so")   # env override: A/B kernel builds (tools/)
 
 from ctypes import c_long
 i, f, p, l = c_int, c_float, c_void_p, c_long

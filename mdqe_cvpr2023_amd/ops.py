@@ -46,10 +46,13 @@ def _wsplit(w):
     if ent is None:
         return None
     ref, ver, planes = ent
-    if ref() is not w or w._version != ver:          # freed-and-reused address, or modified in place
+    base = ref()
+    if base is None or base._version != ver:         # freed (the address may be reused) or modified in place
         del _split[w.data_ptr()]
         return None
-    return planes
+    if w.numel() != base.numel() or w._version != ver or not w.is_contiguous():
+        return None                                  # some other tensor at the same address (a partial view): not ours
+    return planes                                    # w is the registered tensor or a full reshaped view of it
 
 
 def _workspace(nbytes, device):

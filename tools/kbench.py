@@ -54,7 +54,7 @@ def bench_msda(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["msda", "gemm", "all"])
+    ap.add_argument("what", choices=["msda", "gemm", "gemm32", "all"])
     a = ap.parse_args()
     if a.what in ("msda", "all"):
         bench_msda(a)
@@ -64,13 +64,13 @@ def bench_gemm(args, const=False):
     from mdqe_cvpr2023_amd import ops
     cw = ops.const_weight if const else (lambda t: t)
     res = []
-    for name, M, N, K, tile in (("enc_qkv_30f", 153000, 640, 256, 1), ("enc_ffn1_30f", 153000, 1024, 256, 1),
+    for name, M, N, K, tile in (("enc_qkv_30f", 153000, 640, 256, 1), ("enc_ffn1_30f", 153000, 1024, 256, 1), ("enc_ffn1_30f_gelu", 153000, 1024, 256, 1),
                                 ("enc_ffn2_30f", 153000, 256, 1024, 1), ("enc_out_30f", 153000, 256, 256, 1),
                                 ("enc_ffn1_4f", 20400, 1024, 256, 1), ("dec_q_784", 784, 256, 256, 3),
                                 ("dec_val_4f", 20400, 256, 256, 1), ("dec_val_4f_t3", 20400, 256, 256, 3)):
         x = torch.randn(M, K, device="cuda"); w = cw(torch.randn(N, K, device="cuda") / K ** 0.5); b = torch.randn(N, device="cuda")
         out = torch.empty(M, N, device="cuda")
-        ms = time_ms(lambda: ops.linear(x, w, b, out=out, tile=tile), iters=20, warm=5)
+        ms = time_ms(lambda: ops.linear(x, w, b, out=out, tile=tile, act="gelu" if name.endswith("gelu") else None), iters=20, warm=5)
         tf = 2.0 * M * N * K / ms / 1e9
         res.append(dict(case=name, M=M, N=N, K=K, tile=tile, ms=ms, TFLOPs=tf, frac_f32_mfma_peak=tf / 157.3))
         print(json.dumps(res[-1]))
@@ -87,7 +87,7 @@ def bench_gemm(args, const=False):
     return res
 
 
-if __name__ == "__main__" and a.what in ("gemm", "all"):
+if __name__ == "__main__" and a.what in ("gemm", "gemm32", "all"):
     bench_gemm(a)
 
 
