@@ -65,16 +65,69 @@ class GemmMeter:
         return dict(launches=len(self.rec), avg_us=1e3 * ms / len(self.rec), tflops=fl / ms / 1e9)
 
 
-def synth_video(f0, f1, seed, h=360, w=640):
-    """Frames [f0, f1) of the synthetic video: frame f depends only on (seed, f), so every rank can build just its shard
-    (temporally coherent: a fixed base image blended with per-frame noise)."""
+def synth_video(f0, f1, seed, h=360, w=640, n_obj=10):
+    """Frames [f0, f1) of the synthetic video: frame f depends only on (seed, f), so every rank can build just its shard.
+    OVIS-like content instead of i.i.d. pixels (which make every location of a random-weight network look alike and collapse
+    all queries into one instance): a smooth textured background and `n_obj` textured rectangles of different colours that
+    move with constant velocity and occlude each other, plus per-frame sensor noise."""
     g = torch.Generator().manual_seed(seed)
-    base = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).float()
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+
+    def texture(scale):
+        """[3,h,w] smooth random pattern in 0..255: a few random sinusoids per channel."""
+        t = torch.zeros(3, h, w)
+        for c in range(3):
+            for _ in range(4):
+                fx, fy, ph = (torch.rand(3, generator=g) * torch.tensor([scale, scale, 6.28])).tolist()
+                t[c] += torch.sin(xx * fx + yy * fy + ph)
+        t = (t - t.amin(dim=(1, 2), keepdim=True)) / (t.amax(dim=(1, 2), keepdim=True) - t.amin(dim=(1, 2), keepdim=True) + 1e-6)
+        return t * 255.0
+
+    bg = 0.5 * texture(0.02) + 64.0
+    objs = []
+    for _ in range(n_obj):
+        r = torch.rand(8, generator=g).tolist()
+        ow, oh = int(40 + r[0] * 0.3 * w), int(40 + r[1] * 0.45 * h)
+        colour = torch.rand(3, generator=g).view(3, 1, 1) * 255.0
+        tex = 0.5 * texture(0.15) + 0.5 * colour
+        objs.append((ow, oh, r[2] * (w - ow), r[3] * (h - oh), (r[4] - 0.5) * 6.0, (r[5] - 0.5) * 3.0, tex))
     out = torch.empty(f1 - f0, 3, h, w, dtype=torch.uint8)
     for f in range(f0, f1):
+        img = bg.clone()
+        for ow, oh, x0, y0, vx, vy, tex in objs:
+            x = int(x0 + vx * f) % (w - ow); y = int(y0 + vy * f) % (h - oh)
+            img[:, y:y + oh, x:x + ow] = tex[:, y:y + oh, x:x + ow]
         g.manual_seed(seed * 1000003 + f + 1)
-        out[f - f0] = (0.7 * base + 0.3 * torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).float()).round().to(torch.uint8)
+        img = img + (torch.rand(3, h, w, generator=g) - 0.5) * 16.0
+        out[f - f0] = img.clamp(0, 255).round().to(torch.uint8)
     return out
+
+
+def calibrate_synthetic_scores(model, sd, cfg, fh, fw):
+    """Synthetic weights only: shift the class-logit bias so that the 95th percentile of the per-query max-class logit on
+    the first tracker window of the synthetic video sits at sigmoid^-1(0.3).  About a fifth of the queries then pass
+    APPLY_CLS_THRES and a handful of instances per clip survive duplicate removal, NMS and rescoring -- an untrained head
+    would otherwise pass all queries or none, and the data-dependent stages (NMS, tracker, up-sampling) would idle.
+    Deterministic and a function of (weights seed, video seed) only, so every rank derives the same shift."""
+    key = "detr.transformer_dec.cls_embed.layers.2.bias"
+    eng = model.engine
+    nf, T = cfg.n_frames_window_test, cfg.n_frames_test
+    frames = synth_video(0, nf, seed=0, h=fh, w=fw).cuda()
+    with torch.no_grad():
+        geo = eng.geometry(fh, fw)
+        c = model._frame_cache(frames, geo)
+        outs = eng.decode_clips(c, list(range(nf - T + 1)), T, geo)
+        s = outs["cls"].max(-1)[0].clamp(1e-6, 1 - 1e-6)
+        q95 = float(torch.quantile(torch.logit(s), 0.95, dim=1).mean())
+        delta = -0.85 - q95
+        eng.P.cls_embed[-1][1].add_(delta)
+        sd[key] = sd[key] + delta
+        for name, prm in model.named_parameters():
+            if name == key:
+                prm.add_(delta)
+    del c, outs, frames
+    torch.cuda.empty_cache()
+    return delta
 
 
 def cpu_baseline(cfg, sd, frames4):
@@ -140,6 +193,7 @@ def main():
     fh, fw = {"R50_ovis_360": (360, 640), "R50_ovis_720": (640, 1138), "swinl_ovis": (480, 853)}[args.config]
     sd = random_state(cfg, seed=0)
     model = MDQE(cfg, state_dict=sd).eval()
+    bias_shift = calibrate_synthetic_scores(model, sd, cfg, fh, fw)
     meter = GemmMeter()
     meter.install()
 
@@ -211,7 +265,8 @@ def main():
                                    "%d-frame windows, random-init weights (zero-init trap removed)"
                                    % (args.config, args.frames, fh, fw, cfg.n_frames_test, cfg.n_frames_window_test),
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
-                       "instances_out": len(out["pred_scores"]),
+                       "instances_out": len(out["pred_scores"]), "tracked_instances": len(set(m.data_ptr() for m in out["pred_masks"])),
+                       "cls_bias_shift": round(bias_shift, 3),
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
                        "parallelism": "1 process/GPU; 30-frame chunks dealt round-robin, per-round RCCL all-gather of clip results, "
                                       "tracker replay overlapped with the next round" if world > 1 else "single GPU"},

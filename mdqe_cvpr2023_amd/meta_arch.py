@@ -11,6 +11,7 @@ detectron2 is importable the class is registered in its META_ARCH_REGISTRY under
 Training and the COCO single-image branch are out of scope and raise.
 """
 import contextlib
+import os
 from collections import OrderedDict
 
 import torch
@@ -51,6 +52,9 @@ class MDQE(nn.Module):
         self._extra = {k: v for k, v in sd.items() if k not in man}      # e.g. custom-backbone weights
         self.frame_batch = self.cfg.n_frames_window_test
         self._trk_stream = None
+        self._frame_stream = None
+        self._copy_stream = None
+        self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.stage_times = None
 
     # ---- checkpoint contract ---------------------------------------------------------------------
@@ -120,73 +124,103 @@ class MDQE(nn.Module):
 
     def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
-        `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res)."""
+        `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
+
+        Two HIP streams: the per-frame stages (backbone .. decoder value cache: large GEMMs) of chunk k+1 run on a frame
+        stream while the decoder + inference_clip of chunk k (many small kernels and three host syncs) run on the caller's
+        stream, so the matrix cores stay fed through the data-dependent part.  The frame cache is double buffered (two
+        rings of T-1 carried + frame_batch new frames); events order ring reuse."""
         eng = self.engine
         h, w = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
         geo = eng.geometry(h, w)
         n_local = frames_dev.shape[0]
-        # Frame cache = preallocated ring of (T-1 carried + frame_batch new) frames; no concatenations, no re-allocation.
         Tmax = max((c[1] - c[0] for c in clips), default=1)
         cap = Tmax - 1 + self.frame_batch
-        st = {"cache": None, "ring": None, "base": 0, "count": 0, "nxt": 0}   # ring holds local frames [base, base+count)
+        cuda = frames_dev.is_cuda
+        clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
+        if cuda and self._frame_stream is None:
+            self._frame_stream = torch.cuda.Stream(frames_dev.device)
+        fstream = (self._frame_stream if self.overlap_streams else clip_stream) if cuda else None
+        rings = [None, None]                      # slot -> {name: [cap, ...] buffer}
+        free_ev = [None, None]                    # slot -> event: the clip work that read this ring has finished
+        nxt = 0                                   # local frames [0, nxt) have been through the per-frame stages
 
-        def prepare(ci):
-            """Extend the frame cache up to the last frame of clip `ci` (async launches only)."""
+        def prepare(ci, slot, prev):
+            """Frame cache for the clips starting at index ci, built in ring `slot` from the carried tail of `prev` (the
+            state of the other ring) + new frames; asynchronous on the frame stream.  Returns the state dict."""
+            nonlocal nxt
             ls, le = clips[ci][0] - frame_offset, clips[ci][1] - frame_offset
-            while st["nxt"] < le:
-                c1 = min(n_local, st["nxt"] + self.frame_batch)
-                n_new = c1 - st["nxt"]
-                if st["ring"] is None:
-                    first = self._frame_cache(frames_dev[st["nxt"]:c1], geo)
-                    st["ring"] = {k: torch.empty((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for k, v in first.items()}
-                    for k, v in first.items():
-                        st["ring"][k][:n_new].copy_(v)
-                    st["base"], st["count"] = st["nxt"], n_new
-                    del first
-                else:
-                    shift = ls - st["base"]        # frames before the clip start are never needed again
-                    keep = st["count"] - shift
-                    if shift > 0:
-                        for k, v in st["ring"].items():
-                            if keep > 0:
-                                v[:keep].copy_(v[shift:st["count"]].clone())
-                        st["base"], st["count"] = ls, max(keep, 0)
-                    self._frame_cache(frames_dev[st["nxt"]:c1], geo, ring=st["ring"], at=st["count"])
-                    st["count"] += n_new
-                st["cache"] = {k: v[:st["count"]] for k, v in st["ring"].items()}
-                st["nxt"] = c1
+            ctx = torch.cuda.stream(fstream) if cuda else contextlib.nullcontext()
+            with ctx:
+                if cuda:
+                    if prev is None and fstream is not clip_stream:
+                        fstream.wait_stream(clip_stream)           # the frames (and weights) were produced on the caller's stream
+                    if free_ev[slot] is not None:
+                        fstream.wait_event(free_ev[slot])
+                base, count = ls, 0
+                if prev is not None:                               # carry frames [ls, prev end) -- never more than T-1
+                    keep = prev["base"] + prev["count"] - ls
+                    if keep > 0:
+                        if rings[slot] is None:
+                            rings[slot] = {k: torch.empty_like(v) for k, v in rings[prev["slot"]].items()}
+                        o = ls - prev["base"]
+                        for k, v in rings[slot].items():
+                            v[:keep].copy_(rings[prev["slot"]][k][o:o + keep])
+                        count = keep
+                while nxt < le:
+                    c1 = min(n_local, nxt + self.frame_batch)
+                    n_new = c1 - nxt
+                    if rings[slot] is None:
+                        first = self._frame_cache(frames_dev[nxt:c1], geo)
+                        rings[slot] = {k: torch.empty((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for k, v in first.items()}
+                        for k, v in first.items():
+                            rings[slot][k][count:count + n_new].copy_(v)
+                        del first
+                    else:
+                        self._frame_cache(frames_dev[nxt:c1], geo, ring=rings[slot], at=count)
+                    count += n_new
+                    nxt = c1
+                ready = None
+                if cuda:
+                    ready = torch.cuda.Event()
+                    ready.record(fstream)
+            return {"slot": slot, "base": base, "count": count, "ready": ready, "covered": nxt,
+                    "cache": {k: v[:count] for k, v in rings[slot].items()}}
 
-        i = 0
-        if clips:
-            prepare(0)
+        i, k = 0, 0
+        cur = prepare(0, 0, None) if clips else None
         if primed:
             yield None                            # per-frame work of the first chunk is queued; the caller resumes later
         while i < len(clips):
-            cache, base, nxt = st["cache"], st["base"], st["nxt"]
+            cache, base, covered = cur["cache"], cur["base"], cur["covered"]
             ls, le = clips[i][0] - frame_offset, clips[i][1] - frame_offset
             # every further clip of the same length whose frames are already cached joins the batch:
             # clips are independent through the decoder, so they run as ONE pass (M = clips*T*Q rows)
             T = le - ls
             j = i
-            while j < len(clips) and clips[j][1] - frame_offset <= nxt and clips[j][1] - clips[j][0] == T:
+            while j < len(clips) and clips[j][1] - frame_offset <= covered and clips[j][1] - clips[j][0] == T:
                 j += 1
             group = clips[i:j]
+            nxt_state = prepare(j, (k + 1) % 2, cur) if j < len(clips) else None     # queued BEFORE this group's clip work
+            if cuda:
+                clip_stream.wait_event(cur["ready"])
             outs = eng.decode_clips(cache, [c[0] - frame_offset - base for c in group], T, geo)
             ress = eng.inference_clips(outs, [cache["mf"][c[0] - frame_offset - base:c[1] - frame_offset - base] for c in group])
-            ready = torch.cuda.Event()
-            ready.record()                        # the clip results are complete once this event fires
-            i = j
-            if i < len(clips):
-                prepare(i)                        # prefetch: the next chunk's per-frame work is queued before the tracker runs
+            ready = None
+            if cuda:
+                ready = torch.cuda.Event()
+                ready.record(clip_stream)         # the clip results are complete once this event fires
+                free_ev[cur["slot"]] = ready      # ... and ring `slot` may be overwritten
             for (start, end, last), res in zip(group, ress):
                 if trace is not None:
-                    trace.append({k: v.clone() for k, v in res.items() if torch.is_tensor(v)})
+                    trace.append({k_: v.clone() for k_, v in res.items() if torch.is_tensor(v)})
                 res["ready"] = ready
                 yield start, end, last, res
+            i, k, cur = j, k + 1, nxt_state
 
-    def merge_clips(self, results, frame_hw, out_size, mask_hw):
+    def merge_clips(self, results, frame_hw, out_size, mask_hw, n_frames=None):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""
-        m = ClipMerger(self, frame_hw, out_size, mask_hw)
+        m = ClipMerger(self, frame_hw, out_size, mask_hw, n_frames)
         for item in results:
             if m.feed(*item):
                 break
@@ -209,12 +243,13 @@ class MDQE(nn.Module):
         ms = cfg.match_stride
         clips = self.clip_schedule(L, cfg.n_frames_test, cfg.clip_stride)
         return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace), (h, w), out_size,
-                                (geo.Hp // ms, geo.Wp // ms))
+                                (geo.Hp // ms, geo.Wp // ms), n_frames=L)
 
-    def inference_video(self, image_size, cls_clips, windows, frame_hw, n_frames):
+    def inference_video(self, image_size, cls_clips, windows, frame_hw, n_frames, early=None):
         """mdqe/mdqe.py:430-471.  The x4 aligned-bilinear up-sampling, sigmoid, crop (:357-358), nearest resize to the
-        original size and the 0.5 threshold (:458-462) run as ONE kernel per window, only for the instances that
-        survive the top-k; windows in which an instance did not exist yet stay zero (:442)."""
+        original size and the 0.5 threshold (:458-462) run as ONE kernel per window; windows in which an instance did not
+        exist yet stay zero (:442).  `early` (ClipMerger, CUDA): the masks of every tracked instance were already produced
+        and copied to pinned host memory window by window, under the later windows' compute; only the selection is left."""
         from . import ops
         K = self.cfg.num_classes
         total = cls_clips[-1].shape[0]
@@ -226,6 +261,16 @@ class MDQE(nn.Module):
         inst = torch.div(ti, K, rounding_mode="floor").tolist()
         sel = sorted(set(inst))
         Ho, Wo = int(image_size[0]), int(image_size[1])
+        if early is not None:
+            host = early["host"]                                   # [cap, n_frames, Ho, Wo] uint8, pinned
+            early["done"].synchronize()
+            for f_off, nf, n_w in early["windows"]:                # instances born after a window: zero there (:442)
+                for i in sel:
+                    if i >= n_w:
+                        host[i, f_off:f_off + nf].zero_()
+            hb = host.view(torch.bool)
+            return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels,
+                    "pred_masks": [hb[i, :n_frames] for i in inst]}
         out = torch.zeros(len(sel), n_frames, Ho, Wo, dtype=torch.uint8, device=self.device)
         sel_dev = torch.tensor(sel, dtype=torch.int32, device=self.device)
         for f_off, m in windows:
@@ -243,8 +288,10 @@ class ClipMerger:
     final video merge.  The tracker runs on its own HIP stream so that its small kernels and per-clip host syncs overlap
     with per-frame work the producer has already queued on the main stream."""
 
-    def __init__(self, model, frame_hw, out_size, mask_hw):
+    def __init__(self, model, frame_hw, out_size, mask_hw, n_frames=None):
         self.model, self.frame_hw, self.out_size, self.mask_hw = model, frame_hw, out_size, mask_hw
+        self.n_frames = n_frames                    # total frames of the video when known: enables the early mask path
+        self.early = None
         # MODEL.MDQE.MERGE_ON_CPU exists in the reference to fit 16-40 GB GPUs (mdqe/mdqe.py:185-186,354-355); with
         # 288 GB of HBM the merge always stays on the device (results are identical either way).
         self.dev = model.device
@@ -276,18 +323,55 @@ class ClipMerger:
             if last or (start + stride >= win * (self.saved + 1)):
                 c, m = self.tracker.get_result(is_last_clip=last)   # m: mean logits [n, F, Hm, Wm] of this window
                 self.cls_clips.append(c)
-                self.windows.append((self.f_off, m.contiguous()))
+                m = m.contiguous()
+                if self.use_side and self.n_frames is not None:
+                    self._early_masks(m)
+                    self.windows.append((self.f_off, None))
+                else:
+                    self.windows.append((self.f_off, m))
                 self.f_off += m.shape[1]
                 self.saved += 1
         self.done = bool(last)
         return self.done
 
+    def _early_masks(self, m):
+        """Final masks of EVERY instance tracked so far for the window just flushed (m: [n, F, Hm, Wm] mean logits), copied to
+        pinned host memory on a copy stream while later windows compute; finish() then only selects rows.  A few rows may
+        be produced in vain (instances that miss the final top-k)."""
+        from . import ops
+        model = self.model
+        n, nf = int(m.shape[0]), int(m.shape[1])
+        Ho, Wo = int(self.out_size[0]), int(self.out_size[1])
+        if model._copy_stream is None:
+            model._copy_stream = torch.cuda.Stream(self.dev)
+        cs = model._copy_stream
+        if self.early is None or self.early["host"].shape[0] < n:
+            cap = max(16, 2 * n)
+            host = torch.empty(cap, self.n_frames, Ho, Wo, dtype=torch.uint8, pin_memory=True)
+            if self.early is not None:                  # grew past the capacity: keep what has been copied so far
+                self.early["done"].synchronize()
+                old = self.early["host"]
+                host[:old.shape[0]].copy_(old)
+            self.early = {"host": host, "windows": [] if self.early is None else self.early["windows"], "done": torch.cuda.Event()}
+        if n:
+            dev = torch.empty(n, nf, Ho, Wo, dtype=torch.uint8, device=self.dev)
+            idx = torch.arange(n, dtype=torch.int32, device=self.dev)
+            ops.final_masks(m, idx, model.cfg.match_stride, self.frame_hw[0], self.frame_hw[1], Ho, Wo, dev, 0)
+            cs.wait_stream(self.side)
+            with torch.cuda.stream(cs):
+                for i in range(n):
+                    self.early["host"][i, self.f_off:self.f_off + nf].copy_(dev[i], non_blocking=True)
+                dev.record_stream(cs)
+                self.early["done"].record(cs)
+        self.early["windows"].append((self.f_off, nf, n))
+
     def finish(self):
         if self.use_side:
             self.main.wait_stream(self.side)
             for _, m in self.windows:
-                m.record_stream(self.main)
-        return self.model.inference_video(self.out_size, self.cls_clips, self.windows, self.frame_hw, self.f_off)
+                if m is not None:
+                    m.record_stream(self.main)
+        return self.model.inference_video(self.out_size, self.cls_clips, self.windows, self.frame_hw, self.f_off, early=self.early)
 
 
 try:                                              # drop-in registration when detectron2 is present

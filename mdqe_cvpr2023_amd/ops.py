@@ -56,7 +56,10 @@ def _wsplit(w):
 
 
 def _workspace(nbytes, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch buffer (split-K partials, GroupNorm statistics), one per (device, stream): the per-frame stages and the
+    per-clip stages run on different streams and must not share it."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(device).cuda_stream)
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -9,6 +9,7 @@ Aliased entries of the reference checkpoint (transformer_dec.decoder.{bbox_embed
 are accepted on load and ignored in favour of their primary names.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -255,4 +256,19 @@ def random_state(cfg: MDQEConfig, seed=0, remove_zero_init_trap=True):
                 sd[name] += torch.randn(sd[name].shape, generator=g) * 0.02
         for h in ("cls_embed", "rpn_cls_embed"):
             sd[f"detr.transformer_dec.{h}.layers.2.bias"].zero_()
+        # class logits of an untrained head are all alike (spread 0.25): widen them and centre the threshold so that roughly a
+        # quarter of the queries pass APPLY_CLS_THRES and 4-8 instances per clip survive NMS + rescoring (R50 360p, seed 0)
+        sd["detr.transformer_dec.cls_embed.layers.2.weight"] *= float(os.environ.get("MDQE_SYNTH_CLS_GAIN", "8.0"))
+        sd["detr.transformer_dec.cls_embed.layers.2.bias"].fill_(float(os.environ.get("MDQE_SYNTH_CLS_BIAS", "-14.5")))
+        # Untrained attention averages over near-random values, which adds (almost) the same vector to every token in every
+        # layer: after 6+6 layers all 196 queries are copies of each other (pairwise cosine 0.98), inference_clip's duplicate
+        # removal and mask NMS leave ONE instance per clip and tracker / NMS / up-sampling idle.  Damping the residual-branch
+        # output projections keeps the tokens location-specific, so the data-dependent stages see several instances per
+        # clip, as on real OVIS video (synthetic weights only; any released checkpoint is loaded as is).
+        k = float(os.environ.get("MDQE_SYNTH_RES_SCALE", "0.3"))
+        for name in list(sd):
+            if "backbone" in name:
+                continue
+            if name.endswith((".output_proj.weight", ".out_proj.weight", ".linear2.weight", ".linear2_inst.weight")):
+                sd[name] *= k
     return sd

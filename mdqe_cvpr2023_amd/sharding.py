@@ -131,7 +131,7 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size):
     mask_hw = (geo.Hp // ms, geo.Wp // ms)
     proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
              "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((T,) + tuple(mask_hw), torch.float32)}
-    merger = ClipMerger(model, (h, w), out_size, mask_hw)
+    merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan))
     rounds = (len(plan) + world - 1) // world
 
     def start(q):
@@ -166,4 +166,4 @@ def run_sharded(model, shard_frames, f0, L, rank, world, dist, out_size):
     proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
              "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((T,) + tuple(mask_hw), torch.float32)}
     merged = all_gather_clips(local, T, dist, world, shard_frames.device, proto)
-    return model.merge_clips(iter(merged), (h, w), out_size, mask_hw)
+    return model.merge_clips(iter(merged), (h, w), out_size, mask_hw, n_frames=L)
