@@ -22,7 +22,7 @@
 
 #include "gemm_params.h"
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool CONV>
 __global__ void __launch_bounds__(64 * WM * WN)
 gemm_nt_f32_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
@@ -54,61 +54,66 @@ gemm_nt_f32_kernel(const GemmParams p) {
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
 
   // Per-lane source bookkeeping for this lane's IPW rows (fixed over the K loop).
-  // instruction j of this wave covers image rows (wave*IPW + j)*8 .. +7; lane -> row += lane>>3, chunk' = lane&7
-  unsigned rowoff[IPW];    // byte offset of (row, k=0) in its tensor; conv: of (img, ih0, iw0, 0)
-  int ih0[IPW], iw0[IPW];
-  int csw[IPW];            // source chunk = (lane&7) ^ ((row>>1)&7)
+  // instruction j of this wave covers image rows (wave*IPW + j)*8 .. +7; lane -> row += lane>>3, chunk' = lane&7,
+  // source chunk = (lane&7) ^ ((row>>1)&7).  voff[j] = byte offset of (row, k = 4*chunk); the K-step rides on the
+  // instruction's scalar offset (plain rows, W rows) or on the filter-tap offset (conv A rows; kept in the VGPR offset
+  // because a padded pixel's base may be "negative" and the scalar offset is not part of the bounds check).
+  unsigned voff[IPW];
+  int ih0[IPW], iw0[IPW], kch[IPW];
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
     const int irow = (wave * IPW + j) * 8 + (lane >> 3);
-    csw[j] = (lane & 7) ^ ((irow >> 1) & 7);
+    kch[j] = ((lane & 7) ^ ((irow >> 1) & 7)) * 4;
     ih0[j] = 0; iw0[j] = 0;
     if (irow < BM) {
       int m = m0 + irow; if (m > p.M - 1) m = p.M - 1;
-      if (p.conv) {
+      if (CONV) {
         const int ow = m % p.OW; const int t = m / p.OW; const int oh = t % p.OH; const int img = t / p.OH;
         ih0[j] = oh * p.stride - p.pad; iw0[j] = ow * p.stride - p.pad;
-        rowoff[j] = (unsigned)(((long)img * p.img_stride + ((long)ih0[j] * p.Wd + iw0[j]) * p.Cin) * 4);   // may wrap; fixed below
+        voff[j] = (unsigned)(((long)img * p.img_stride + ((long)ih0[j] * p.Wd + iw0[j]) * p.Cin) * 4) + (unsigned)(kch[j] * 4);   // may wrap
       } else {
-        rowoff[j] = (unsigned)((long)m * p.lda * 4);
+        voff[j] = (unsigned)((long)m * p.lda * 4) + (unsigned)(kch[j] * 4);
       }
     } else {
       int n = n0 + irow - BM; if (n > p.N - 1) n = p.N - 1;
-      rowoff[j] = (unsigned)((long)n * p.K * 4);
+      voff[j] = (unsigned)((long)n * p.K * 4) + (unsigned)(kch[j] * 4);
     }
   }
 
-  auto issue = [&](int kt, int buf) {
+  const int kbeg = p.ksplit > 1 ? blockIdx.y * p.kchunk : 0;
+  const int kend = p.ksplit > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+  const int kt0 = kbeg / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  // conv: filter tap of the K-step about to be issued (the 32-float K-step lies inside one tap: Cin % 32 == 0, host-checked)
+  int t_kh = 0, t_kw = 0, t_c = 0;
+  if (CONV) { const int tap = kbeg / p.Cin; t_c = kbeg - tap * p.Cin; t_kh = tap / p.KW; t_kw = tap - t_kh * p.KW; }
+
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
     const int k0 = kt * BK;
-    // conv: the 32-float K-step lies inside one filter tap (Cin % 32 == 0, checked on the host)
-    int tap_off = 0, kh = 0, kw = 0, cin0 = k0;
-    if (p.conv) {
-      const int tap = k0 / p.Cin; cin0 = k0 - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW;
-      tap_off = ((kh * p.Wd + kw) * p.Cin + cin0) * 4;
-    }
+    const bool ktail = k0 + BK > p.K;              // only the last K-step of a ragged K (plain mode) checks lanes against K
     float* base = lds + buf * (ROWS * BK);
+    int tap_off = 0;
+    if (CONV) tap_off = ((t_kh * p.Wd + t_kw) * p.Cin + t_c) * 4;
 #pragma unroll
     for (int j = 0; j < IPW; ++j) {
-      const int inst = wave * IPW + j;
-      const int irow0 = inst * 8;                    // wave-uniform
-      const int kk = k0 + csw[j] * 4;
-      unsigned off;
+      const int irow0 = (wave * IPW + j) * 8;        // wave-uniform
+      unsigned off = voff[j];
       if (irow0 < BM) {
-        if (p.conv) {
-          const int ih = ih0[j] + kh, iw = iw0[j] + kw;
+        if (CONV) {
+          const int ih = ih0[j] + t_kh, iw = iw0[j] + t_kw;
           const bool ok = (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.Wd);
-          off = ok ? rowoff[j] + (unsigned)tap_off + (unsigned)(csw[j] * 16) : OOB_OFF;
+          off = ok ? off + (unsigned)tap_off : OOB_OFF;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, 0, 0, 0);
         } else {
-          off = kk < p.K ? rowoff[j] + (unsigned)(kk * 4) : OOB_OFF;
+          if (ktail && k0 + kch[j] >= p.K) off = OOB_OFF;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, k0 * 4, 0, 0);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK),
-                                                 16, off, 0, 0, 0);
       } else {
-        off = kk < p.K ? rowoff[j] + (unsigned)(kk * 4) : OOB_OFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + irow0 * BK),
-                                                 16, off, 0, 0, 0);
+        if (ktail && k0 + kch[j] >= p.K) off = OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, k0 * 4, 0, 0);
       }
     }
+    if (CONV) { t_c += BK; if (t_c >= p.Cin) { t_c = 0; if (++t_kw == p.KW) { t_kw = 0; ++t_kh; } } }
   };
 
   f32x16 acc[MT][NT];
@@ -119,10 +124,6 @@ gemm_nt_f32_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int kbeg = p.ksplit > 1 ? blockIdx.y * p.kchunk : 0;
-  const int kend = p.ksplit > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
-  const int kt0 = kbeg / BK;
-  const int nk = (kend - kbeg + BK - 1) / BK;
   const int lr = lane & 31, lh = lane >> 5;
   issue(kt0, 0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -131,28 +132,35 @@ gemm_nt_f32_kernel(const GemmParams p) {
     if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
     const float* sA = lds + (kt & 1) * (ROWS * BK);
     const float* sW = sA + BM * BK;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      f32x4 a[MT], b[NT];
+    // fragments of sub-step kk+1 are fetched before the MFMAs of kk are issued (LDS latency behind 16 MFMAs)
+    f32x4 fa_[2][MT], fb_[2][NT];
+    auto frag = [&](int kk, int slot) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = wm * (BM / WM) + i * 32 + lr;
         const int ch = (kk * 2 + lh) ^ ((row >> 1) & 7);
-        a[i] = *reinterpret_cast<const f32x4*>(sA + row * BK + ch * 4);
+        fa_[slot][i] = *reinterpret_cast<const f32x4*>(sA + row * BK + ch * 4);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int row = wn * (BN / WN) + j * 32 + lr;
         const int ch = (kk * 2 + lh) ^ ((row >> 1) & 7);
-        b[j] = *reinterpret_cast<const f32x4*>(sW + row * BK + ch * 4);
+        fb_[slot][j] = *reinterpret_cast<const f32x4*>(sW + row * BK + ch * 4);
       }
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3) frag(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[kk & 1][i][s], fb_[kk & 1][j][s], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -253,12 +261,12 @@ gemm_splitk_reduce_kernel(const GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_gemm(const GemmParams& p, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool CONV>
+static int launch_gemm_(const GemmParams& p, hipStream_t st) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   size_t smem = 2 * (BM + BN) * 32 * sizeof(float);
   if (smem < (size_t)BM * BN * sizeof(float)) smem = (size_t)BM * BN * sizeof(float);   // epilogue restage
-  auto kern = gemm_nt_f32_kernel<BM, BN, WM, WN>;
+  auto kern = gemm_nt_f32_kernel<BM, BN, WM, WN, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -270,6 +278,11 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
   long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
   return mdqe_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmParams& p, hipStream_t st) {
+  return p.conv ? launch_gemm_<BM, BN, WM, WN, true>(p, st) : launch_gemm_<BM, BN, WM, WN, false>(p, st);
 }
 
 static unsigned long long* g_gemm_stamps = nullptr;   // tools/ only: in-kernel phase stamps of the f16x3w kernel

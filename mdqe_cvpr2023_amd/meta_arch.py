@@ -50,7 +50,7 @@ class MDQE(nn.Module):
             t = sd[name] if name in sd else torch.zeros(shape)
             _register(self, name, t.detach().clone().float(), buffer=name.endswith(("running_mean", "running_var")))
         self._extra = {k: v for k, v in sd.items() if k not in man}      # e.g. custom-backbone weights
-        self.frame_batch = self.cfg.n_frames_window_test
+        self.frame_batch = int(os.environ.get("MDQE_FRAME_BATCH", self.cfg.n_frames_window_test))    # frames per pass of the per-frame stages
         self._trk_stream = None
         self._frame_stream = None
         self._copy_stream = None
