@@ -27,7 +27,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
 class GemmMeter:
-    """HIP-event timing of the dominant kernel (gemm_nt_f32_kernel<128,128,2,2>) inside the timed region:
+    """HIP-event timing of the dominant kernel (the 128x128-tile fp32 GEMM / implicit-GEMM conv) inside the timed region:
     an event pair on the launch stream around each of its launches + the launch's algorithmic FLOPs."""
 
     def __init__(self):
@@ -303,7 +303,7 @@ def main():
                                       "tracker replay overlapped with the next round" if world > 1 else "single GPU"},
         }
         if g:
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_kernel<128,128,2,2>" if args.precision == "f32" else
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_k16_kernel<128,128,2,2> (+ gemm_nt_f32_kernel<128,128,2,2> for deep-K convs)" if args.precision == "f32" else
                                 "gemm_nt_f16x3w_kernel<256|128> (+ gemm_nt_f16x3_kernel<128,128> where B is not a constant weight)",
                                 "achieved": g["tflops"],
                                 "peak": F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3, "unit": "TFLOP/s",

@@ -288,6 +288,9 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
 static unsigned long long* g_gemm_stamps = nullptr;   // tools/ only: in-kernel phase stamps of the f16x3w kernel
 extern "C" int mdqe_debug_gemm_stamps(void* buf) { g_gemm_stamps = (unsigned long long*)buf; return MDQE_OK; }
 
+static int g_gemm_variant = 2;         // fp32 kernel form: 0 = K-step 32 (gemm.hip), 1 = K-step 16 (gemm_k16.hip), 2 = by shape
+extern "C" int mdqe_debug_gemm_variant(int v) { g_gemm_variant = v; return MDQE_OK; }
+
 static int g_gemm_precision = 0;      // 0: exact fp32 MFMA; 1: f16x3 split on the 128-row tiles (gemm_f16x3.hip)
 extern "C" int mdqe_set_gemm_precision(int mode) {
   if (mode != 0 && mode != 1) return MDQE_EINVAL;
@@ -321,6 +324,14 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   }
   if ((tile == 1 || tile == 2) && g_gemm_precision == 1) {
     int rc = mdqe_launch_gemm_f16x3(p, tile, st);
+    if (rc || p.ksplit <= 1) return rc;
+    long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
+    return mdqe_launch_status();
+  }
+  // K-step 16 (4 blocks per CU) wins wherever prologue/epilogue weigh (K <= ~1024); deep-K convs keep the 32-wide step
+  if (g_gemm_variant == 1 || (g_gemm_variant == 2 && !(p.conv && p.K >= 2048))) {
+    int rc = mdqe_launch_gemm_k16(p, tile, st);
     if (rc || p.ksplit <= 1) return rc;
     long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);

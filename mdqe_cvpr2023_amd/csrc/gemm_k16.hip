@@ -1,0 +1,240 @@
+// fp32 NT GEMM / implicit-GEMM conv, K-step 16 variant of gemm.hip (same arithmetic: v_mfma_f32_32x32x2_f32, exact fp32).
+//
+// Why a second form: with 32-float K-steps a 128x128 block needs 64 KB of LDS (two stages, and the same again for the
+// epilogue restage), so only two blocks -- two waves per SIMD -- fit a CU, and whenever one of them is in its prologue or
+// epilogue the other wave alone cannot keep the matrix pipe busy.  Here a stage is 16 floats deep (64-B rows, 16 rows per
+// 1-KiB LDS-DMA instruction, 16-B chunks XOR-swizzled by (row>>2)&3 -> conflict-free ds_read_b128) and the epilogue is
+// restaged per WAVE through a private 4-KB slice (32x32 sub-tile at a time, no block barrier): 32 KB per 128x128 block,
+// four blocks = four waves per SIMD resident, so prologues, epilogues and barrier waits of one block hide behind the
+// MFMAs of the others.
+#include "common.h"
+#include "gemm_params.h"
+#include <type_traits>
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ void __launch_bounds__(64 * WM * WN, (BM * BN >= 128 * 128) ? 4 : 4)
+gemm_nt_f32_k16_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int BK = 16;
+  constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+  constexpr int ROWS = BM + BN;              // A rows then W rows in one LDS image
+  constexpr int NINST = ROWS / 16;           // 1-KiB LDS-DMA instructions per stage (16 rows x 64 B)
+  constexpr int IPW = NINST / NW;            // per wave
+  static_assert(NINST % NW == 0 && BM % 16 == 0, "tile rows must split evenly over waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // max(2 * ROWS * 16, NW * 1024) floats
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // XCD-aware tile order: blocks that share an A row-panel run on the same XCD (same L2).
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int bm = bid / nbn, bn = bid % nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+
+  // instruction j of this wave covers image rows (wave*IPW + j)*16 .. +15; lane -> row += lane>>2, LDS chunk lane&3,
+  // source chunk = (lane&3) ^ ((row>>2)&3).  voff[j] = byte offset of (row, k = 4*chunk); the K-step rides on the scalar
+  // offset (plain rows, W rows) or on the filter-tap offset in the VGPR (conv A rows: a padded pixel's base may wrap).
+  unsigned voff[IPW];
+  int ih0[IPW], iw0[IPW], kch[IPW];
+#pragma unroll
+  for (int j = 0; j < IPW; ++j) {
+    const int irow = (wave * IPW + j) * 16 + (lane >> 2);
+    kch[j] = ((lane & 3) ^ ((irow >> 2) & 3)) * 4;
+    ih0[j] = 0; iw0[j] = 0;
+    if (irow < BM) {
+      int m = m0 + irow; if (m > p.M - 1) m = p.M - 1;
+      if (CONV) {
+        const int ow = m % p.OW; const int t = m / p.OW; const int oh = t % p.OH; const int img = t / p.OH;
+        ih0[j] = oh * p.stride - p.pad; iw0[j] = ow * p.stride - p.pad;
+        voff[j] = (unsigned)(((long)img * p.img_stride + ((long)ih0[j] * p.Wd + iw0[j]) * p.Cin) * 4) + (unsigned)(kch[j] * 4);   // may wrap
+      } else {
+        voff[j] = (unsigned)((long)m * p.lda * 4) + (unsigned)(kch[j] * 4);
+      }
+    } else {
+      int n = n0 + irow - BM; if (n > p.N - 1) n = p.N - 1;
+      voff[j] = (unsigned)((long)n * p.K * 4) + (unsigned)(kch[j] * 4);
+    }
+  }
+
+  const int kbeg = p.ksplit > 1 ? blockIdx.y * p.kchunk : 0;
+  const int kend = p.ksplit > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+  const int kt0 = kbeg / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  int t_kh = 0, t_kw = 0, t_c = 0;                 // conv: filter tap of the K-step about to be issued (Cin % 16 == 0)
+  if (CONV) { const int tap = kbeg / p.Cin; t_c = kbeg - tap * p.Cin; t_kh = tap / p.KW; t_kw = tap - t_kh * p.KW; }
+
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    const int k0 = kt * BK;
+    const bool ktail = k0 + BK > p.K;              // only the last K-step of a ragged K checks lanes against K
+    float* base = lds + buf * (ROWS * BK);
+    int tap_off = 0;
+    if (CONV) tap_off = ((t_kh * p.Wd + t_kw) * p.Cin + t_c) * 4;
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int irow0 = (wave * IPW + j) * 16;       // wave-uniform
+      unsigned off = voff[j];
+      if (irow0 < BM) {
+        if (CONV) {
+          const int ih = ih0[j] + t_kh, iw = iw0[j] + t_kw;
+          const bool ok = (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.Wd);
+          off = ok ? off + (unsigned)tap_off : OOB_OFF;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, 0, 0, 0);
+        } else {
+          if (ktail && k0 + kch[j] >= p.K) off = OOB_OFF;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, k0 * 4, 0, 0);
+        }
+      } else {
+        if (ktail && k0 + kch[j] >= p.K) off = OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, k0 * 4, 0, 0);
+      }
+    }
+    if (CONV) { t_c += BK; if (t_c >= p.Cin) { t_c = 0; if (++t_kw == p.KW) { t_kw = 0; ++t_kh; } } }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses (floats): row*16 + ((chunk ^ (row>>2)&3) << 2), chunk = 2*kk + lh
+  int fa[MT], fb[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { const int row = wm * (BM / WM) + i * 32 + lr; fa[i] = row * BK + ((lh ^ ((row >> 2) & 3)) << 2); }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { const int row = BM + wn * (BN / WN) + j * 32 + lr; fb[j] = row * BK + ((lh ^ ((row >> 2) & 3)) << 2); }
+
+  issue(kt0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for step kt has landed
+    __syncthreads();                                   // ... and everybody else's; all reads of the other buffer are done
+    if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
+    const float* sI = lds + (kt & 1) * (ROWS * BK);
+    f32x4 a0[MT], b0[NT], a1[MT], b1[NT];              // both 8-wide halves up front: the second hides behind 16 MFMAs
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(sI + fa[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b0[j] = *reinterpret_cast<const f32x4*>(sI + fb[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const f32x4*>(sI + (fa[i] ^ 8));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b1[j] = *reinterpret_cast<const f32x4*>(sI + (fb[j] ^ 8));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][s], b0[j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][s], b1[j][s], acc[i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue: per-wave restage of one 32x32 sub-tile at a time through the wave's own 4-KB LDS slice ----------------
+  // acc[i][j][r] is C(row = (r&3) + 8*(r>>2) + 4*lh, col = lr) of the sub-tile; after the restage a lane owns 4 consecutive
+  // columns of a row and 8 lanes cover one 128-B line of C.
+  __syncthreads();                                   // every wave is done reading the last K-step
+  float* sC = lds + wave * 1024;
+  const bool vec = p.vec_ok;
+  auto sub = [&](auto i_, auto j_) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[i][j][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx >> 3, c4 = idx & 7;
+        const int m = m0 + wm * (BM / WM) + i * 32 + row, n = n0 + wn * (BN / WN) + j * 32 + c4 * 4;
+        if (m >= p.M || n >= p.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * 32 + c4 * 4);
+        if (p.ksplit > 1) {                            // raw partial -> workspace; the epilogue runs in the reduce pass
+          float* w = p.ws + (long)blockIdx.y * p.M * p.N + (long)m * p.N + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) w[e] = v[e];
+          continue;
+        }
+        const long rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+        const bool masked = p.rowmask != nullptr && p.rowmask[m];
+        if (vec && (n + 3 < p.N)) {
+          if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+          if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
+          if (p.res_first) v += rv;
+          if (p.act != MDQE_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (p.act_cols <= 0 || n + e < p.act_cols) v[e] = mdqe_act(v[e], p.act);
+          }
+          if (!p.res_first) v += rv;
+          if (masked) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.mask_cols) v[e] = 0.f;
+          }
+          *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) break;
+            float x = v[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f);
+            const float rv = p.residual != nullptr ? p.residual[rrow * p.ldr + n + e] : 0.f;
+            if (p.res_first) x += rv;
+            if (p.act != MDQE_ACT_NONE && (p.act_cols <= 0 || n + e < p.act_cols)) x = mdqe_act(x, p.act);
+            if (!p.res_first) x += rv;
+            if (masked && n + e < p.mask_cols) x = 0.f;
+            p.C[(long)m * p.ldc + n + e] = x;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  sub(I0{}, I0{});
+  if constexpr (NT > 1) sub(I0{}, I1{});
+  if constexpr (MT > 1) sub(I1{}, I0{});
+  if constexpr (MT > 1 && NT > 1) sub(I1{}, I1{});
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+static int launch_k16_(const GemmParams& p, hipStream_t st) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  size_t smem = 2 * (BM + BN) * 16 * sizeof(float);
+  if (smem < (size_t)WM * WN * 4096) smem = (size_t)WM * WN * 4096;        // per-wave epilogue slices
+  auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV>;
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(64 * WM * WN), smem, st, p);
+  return mdqe_launch_status();
+}
+
+// tile: 1 128x128, 2 128x64, 3 64x64 (as gemm.hip); the split-K reduce pass is launched by the caller
+int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
+  switch (tile) {
+    case 1: return p.conv ? launch_k16_<128, 128, 2, 2, true>(p, st) : launch_k16_<128, 128, 2, 2, false>(p, st);
+    case 2: return p.conv ? launch_k16_<128, 64, 2, 2, true>(p, st) : launch_k16_<128, 64, 2, 2, false>(p, st);
+    case 3: return p.conv ? launch_k16_<64, 64, 2, 2, true>(p, st) : launch_k16_<64, 64, 2, 2, false>(p, st);
+    default: return MDQE_EINVAL;
+  }
+}

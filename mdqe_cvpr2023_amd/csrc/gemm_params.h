@@ -26,5 +26,7 @@ struct GemmParams {
 
 // defined in gemm_f16x3.hip
 int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st);
+// defined in gemm_k16.hip (tile 1/2/3 as gemm.hip; the caller launches the split-K reduce pass)
+int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st);
 // defined in gemm_f16x3w.hip (bn = 256 or 128)
 int mdqe_launch_gemm_f16x3w(const GemmParams& p, int bn, hipStream_t st);
