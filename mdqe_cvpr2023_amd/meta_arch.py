@@ -50,7 +50,8 @@ class MDQE(nn.Module):
             t = sd[name] if name in sd else torch.zeros(shape)
             _register(self, name, t.detach().clone().float(), buffer=name.endswith(("running_mean", "running_var")))
         self._extra = {k: v for k, v in sd.items() if k not in man}      # e.g. custom-backbone weights
-        self.frame_batch = int(os.environ.get("MDQE_FRAME_BATCH", self.cfg.n_frames_window_test))    # frames per pass of the per-frame stages
+        # frames per pass of the per-frame stages: 0 = by resolution (~300k encoder tokens per pass: at most 40 frames: 40 at 360p, 20 at 640p)
+        self.frame_batch = int(os.environ.get("MDQE_FRAME_BATCH", "0"))
         self._trk_stream = None
         self._frame_stream = None
         self._copy_stream = None
@@ -135,7 +136,8 @@ class MDQE(nn.Module):
         geo = eng.geometry(h, w)
         n_local = frames_dev.shape[0]
         Tmax = max((c[1] - c[0] for c in clips), default=1)
-        cap = Tmax - 1 + self.frame_batch
+        fbatch = self.frame_batch if self.frame_batch > 0 else max(8, min(40, 306000 // max(geo.N, 1)))
+        cap = Tmax - 1 + fbatch
         cuda = frames_dev.is_cuda
         clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
         if cuda and self._frame_stream is None:
@@ -168,7 +170,7 @@ class MDQE(nn.Module):
                             v[:keep].copy_(rings[prev["slot"]][k][o:o + keep])
                         count = keep
                 while nxt < le:
-                    c1 = min(n_local, nxt + self.frame_batch)
+                    c1 = min(n_local, nxt + fbatch)
                     n_new = c1 - nxt
                     if rings[slot] is None:
                         first = self._frame_cache(frames_dev[nxt:c1], geo)
