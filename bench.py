@@ -308,10 +308,10 @@ def main():
                                 "achieved": g["tflops"],
                                 "peak": F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / (F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3),
-                                # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_gemm_ffn1_*.csv),
+                                # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv, KiB),
                                 # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, for the bench's largest
                                 # launch shape (encoder FFN1 of a 30-frame chunk); algorithmic bytes of that shape beside it
-                                "traffic": 2 * 104835.6 * 1024 + 612000.0 * 1024, "traffic_shape": "M=153000 N=1024 K=256",
+                                "traffic": 2 * 123909.0 * 1024 + 612000.0 * 1024, "traffic_shape": "M=153000 N=1024 K=256 (+GELU), K-step-16 kernel",
                                 "traffic_algorithmic": 4.0 * (153000 * 256 + 1024 * 256 + 153000 * 1024),
                                 "launches": g["launches"], "avg_launch_us": g["avg_us"],
                                 "note": "timed region: launches overlap with the clip-stream and tracker-stream kernels"}
