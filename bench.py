@@ -101,7 +101,7 @@ def synth_video(f0, f1, seed, h=360, w=640, n_obj=10):
     objs = []
     for _ in range(n_obj):
         r = torch.rand(8, generator=g).tolist()
-        ow, oh = int(40 + r[0] * 0.3 * w), int(40 + r[1] * 0.45 * h)
+        ow, oh = min(w - 2, max(4, int((0.07 + 0.3 * r[0]) * w))), min(h - 2, max(4, int((0.11 + 0.45 * r[1]) * h)))
         colour = torch.rand(3, generator=g).view(3, 1, 1) * 255.0
         tex = 0.5 * texture(0.15) + 0.5 * colour
         objs.append((ow, oh, r[2] * (w - ow), r[3] * (h - oh), (r[4] - 0.5) * 6.0, (r[5] - 0.5) * 3.0, tex))

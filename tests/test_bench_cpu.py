@@ -1,0 +1,41 @@
+"""bench.py pieces that do not need a GPU: the synthetic video is a pure function of (seed, frame) -- what lets every rank
+build only its shard -- and the chunk plan of the multi-GPU schedule covers the video."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_synth_video_is_a_function_of_seed_and_frame():
+    from bench import synth_video
+    whole = synth_video(0, 9, seed=0, h=72, w=128)
+    part = synth_video(4, 9, seed=0, h=72, w=128)
+    assert whole.dtype == torch.uint8 and whole.shape == (9, 3, 72, 128)
+    assert torch.equal(whole[4:], part)
+    assert not torch.equal(whole[0], whole[1])                    # objects move
+    other = synth_video(0, 2, seed=1, h=72, w=128)
+    assert not torch.equal(other[0], whole[0])
+    # spatial structure (not i.i.d. pixels): neighbouring pixels are strongly correlated
+    f = whole[0].float()
+    a, b = f[:, :, :-1].flatten(), f[:, :, 1:].flatten()
+    assert float(torch.corrcoef(torch.stack([a, b]))[0, 1]) > 0.8
+
+
+def test_bench_shards_reassemble_the_video():
+    from bench import synth_video
+    from mdqe_cvpr2023_amd import sharding
+    L, T, stride, win = 50, 4, 1, 10
+    plan = sharding.chunk_plan(L, T, stride, win)
+    video = synth_video(0, L, seed=0, h=40, w=64)
+    seen = set()
+    for world in (1, 2, 3):
+        for rank in range(world):
+            for g in sharding.owned_chunks(plan, world, rank):
+                clips, f0, f1 = plan[g]
+                assert torch.equal(synth_video(f0, f1, seed=0, h=40, w=64), video[f0:f1])
+                if world == 3:
+                    seen.update(c[0] for c in clips)
+    assert seen == {c[0] for c in __import__("mdqe_cvpr2023_amd.meta_arch", fromlist=["MDQE"]).MDQE.clip_schedule(L, T, stride)}

@@ -1,0 +1,109 @@
+"""The stream schedule, the early-mask path and the two fp32 GEMM kernel forms must not change results."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _small_model():
+    from mdqe_cvpr2023_amd.config import PRESETS
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    from mdqe_cvpr2023_amd.params import random_state
+    import dataclasses
+    cfg = dataclasses.replace(PRESETS["R50_ovis_360"], n_frames_window_test=6)
+    return cfg, MDQE(cfg, state_dict=random_state(cfg, seed=3)).eval()
+
+
+def _video(L, h=96, w=160):
+    from bench import synth_video
+    return synth_video(0, L, seed=1, h=h, w=w, n_obj=4)
+
+
+def _same(a, b):
+    assert a["image_size"] == b["image_size"]
+    assert a["pred_labels"] == b["pred_labels"]
+    assert torch.allclose(torch.tensor(a["pred_scores"]), torch.tensor(b["pred_scores"]), atol=0, rtol=0)
+    assert len(a["pred_masks"]) == len(b["pred_masks"])
+    for x, y in zip(a["pred_masks"], b["pred_masks"]):
+        assert x.dtype == torch.bool and x.shape == y.shape and bool((x == y).all())
+
+
+@pytest.mark.parametrize("frame_batch", [3, 6, 0])
+def test_two_stream_schedule_is_bit_identical_to_single_stream(frame_batch):
+    """Frame stages on their own stream + double-buffered caches + early masks vs everything on one stream: the kernels and
+    their inputs are the same, so every output bit is."""
+    cfg, model = _small_model()
+    frames = _video(17).cuda()
+    model.frame_batch = frame_batch
+    inp = [{"image": frames, "height": 96, "width": 160}]
+    model.overlap_streams = True
+    a = model(inp)
+    a2 = model(inp)                                    # a second call reuses streams / rings / pinned blocks
+    model.overlap_streams = False
+    b = model(inp)
+    _same(a, b)
+    _same(a, a2)
+    assert len(a["pred_masks"]) > 0 and a["pred_masks"][0].shape == (17, 96, 160)
+
+
+def test_early_masks_equal_the_direct_path():
+    """ClipMerger with n_frames (masks produced per window into pinned memory) vs without (one pass at the end)."""
+    cfg, model = _small_model()
+    frames = _video(15).cuda()
+    with torch.no_grad():
+        geo = model.engine.geometry(96, 160)
+        ms = cfg.match_stride
+        clips = model.clip_schedule(15, cfg.n_frames_test, cfg.clip_stride)
+        res = list(model.iter_clip_results(frames, clips, 0))
+        torch.cuda.synchronize()
+        outs = []
+        for n_frames in (15, None):
+            outs.append(model.merge_clips(iter(res), (96, 160), (80, 130), (geo.Hp // ms, geo.Wp // ms), n_frames=n_frames))
+    _same(outs[0], outs[1])
+    assert outs[0]["pred_masks"][0].shape == (15, 80, 130)
+
+
+def test_fp32_gemm_kernel_forms_agree():
+    """K-step 32 (gemm.hip) and K-step 16 (gemm_k16.hip) are the same fmaf chains in the same K order: bitwise equal."""
+    from mdqe_cvpr2023_amd import ops
+    from mdqe_cvpr2023_amd._lib import lib
+    g = torch.Generator().manual_seed(9)
+    try:
+        for (M, N, K, tile) in ((3000, 640, 256, 1), (777, 130, 48, 3), (5000, 64, 160, 2), (20000, 256, 1024, 0)):
+            x = torch.randn(M, K, generator=g).cuda(); w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(); b = torch.randn(N, generator=g).cuda()
+            r = torch.randn(M, N, generator=g).cuda()
+            outs = []
+            for v in (0, 1):
+                lib.mdqe_debug_gemm_variant(v)
+                outs.append(ops.linear(x, w, b, act="gelu", residual=r, tile=tile))
+            assert torch.equal(outs[0], outs[1]), (M, N, K, tile)
+            ref = F.gelu(x.double() @ w.double().t() + b.double()) + r.double()
+            assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+        xi = torch.randn(3, 24, 40, 128, generator=g).cuda(); wc = (torch.randn(96, 3, 3, 128, generator=g) / 34).cuda(); bc = torch.randn(96, generator=g).cuda()
+        outs = []
+        for v in (0, 1):
+            lib.mdqe_debug_gemm_variant(v)
+            outs.append(ops.conv2d_nhwc(xi, wc, bc, 2, 1, act="relu"))
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        lib.mdqe_debug_gemm_variant(2)
+
+
+def test_const_weight_registry():
+    from mdqe_cvpr2023_amd import ops
+    w = torch.randn(256, 256, device="cuda")
+    ops.const_weight(w)
+    assert ops._wsplit(w) is not None
+    assert ops._wsplit(w.view(256, 16, 16)) is not None          # a full reshaped view is the same weight
+    assert ops._wsplit(w[:128]) is None                          # a partial view at the same address is not
+    small = ops.const_weight(torch.randn(64, 256, device="cuda"))
+    assert ops._wsplit(small) is None                            # too narrow for the 128-wide tiles: left alone
+    ptr = w.data_ptr()
+    del w
+    assert ptr not in ops._split or ops._split[ptr][0]() is None  # a dead entry is dropped on its next lookup
