@@ -50,6 +50,13 @@ int mdqe_msda_forward_f32(const float* value, const int64_t* shapes, const int64
                           int B, int S, int M, int D, int L, int Q, int P,
                           float* out, void* stream);
 
+/* Backward of the same op (ms_deform_attn_cuda_backward, src/cuda/ms_deform_attn_cuda.cu:83-153; kernels
+ * ms_deform_im2col_cuda.cuh:87-234,301-920): grad_out [B,Q,M*D] -> grad_value [B,S,M,D] (zeroed here, then float
+ * atomics), grad_loc [B,Q,M,L,P,2], grad_attn [B,Q,M,L,P].  Not on the eval path; completes the extension's two exports. */
+int mdqe_msda_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc,
+                           const float* attn, const float* grad_out, int B, int S, int M, int D, int L, int Q, int P,
+                           float* grad_value, float* grad_loc, float* grad_attn, void* stream);
+
 /* Grouped form used for temporal_clip_forward (mdqe/models/ops/modules/ms_deform_attn.py:219-236):
  * the reference issues G (= #spatial levels) separate native calls that share loc/attn and averages
  * them.  Here: shapes/level_start are [G*L] tables into ONE value buffer, out = scale * sum_g (...). */

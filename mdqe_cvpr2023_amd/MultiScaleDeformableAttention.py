@@ -45,5 +45,30 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
-def ms_deform_attn_backward(*args, **kwargs):
-    raise RuntimeError("ms_deform_attn_backward: training is outside the eval-only hot path (SURVEY.md §8f.4)")
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight], as ms_deform_attn_cuda_backward
+    (src/cuda/ms_deform_attn_cuda.cu:83-153): same checks as the forward plus a contiguous CUDA grad_output."""
+    for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)):
+        _req(t.is_contiguous(), f"{name} tensor has to be contiguous")
+        _req(t.is_cuda, f"{name} must be a CUDA tensor")
+    _req(all(t.dtype == torch.float32 for t in (value, sampling_loc, attn_weight, grad_output)),
+         "ms_deform_attn_backward: only float32 is implemented on gfx950")
+    _req(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
+         "spatial_shapes / level_start_index must be int64")
+    B, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Q, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    _req(tuple(sampling_loc.shape) == (B, Q, M, L, P, 2), "sampling_loc must be [B,Q,M,L,P,2]")
+    _req(tuple(attn_weight.shape) == (B, Q, M, L, P), "attn_weight must be [B,Q,M,L,P]")
+    _req(tuple(grad_output.shape) == (B, Q, M * D), "grad_output must be [B,Q,M*D]")
+    step = min(B, int(im2col_step))
+    _req(B == 0 or (step > 0 and B % step == 0), f"batch({B}) must divide im2col_step({step})")
+    gv = torch.empty_like(value)
+    gl = torch.empty_like(sampling_loc)
+    ga = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        check(lib.mdqe_msda_backward_f32(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
+                                         ptr(attn_weight), ptr(grad_output), B, S, M, D, L, Q, P, ptr(gv), ptr(gl), ptr(ga),
+                                         cur_stream()), "ms_deform_attn_backward")
+    return [gv, gl, ga]

@@ -12,6 +12,7 @@ i, f, p, l = c_int, c_float, c_void_p, c_long
 # name -> argtypes; every function returns int status (include/mdqe_hip.h)
 SIGNATURES = {
     "mdqe_msda_forward_f32": [p, p, p, p, p, i, i, i, i, i, i, i, p, p],
+    "mdqe_msda_backward_f32": [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p],
     "mdqe_msda_forward_grouped_f32": [p, p, p, p, p, i, i, i, i, i, i, i, i, f, p, p],
     "mdqe_msda_fused_f32": [p, l, l, p, p, l, p, l, p, l, i, i, p, p, p, p, i, i, i, i, i, i, i, f, p, l, l, p],
     "mdqe_trk_siou_f32": [p, l, i, p, l, i, l, p, p],

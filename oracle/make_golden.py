@@ -402,10 +402,48 @@ def gen_layer256():
     save("enc_layer256", synth_seed=3, **arrs)
 
 
+def gen_msda_backward():
+    """Gradients of the native op through the reference's own pure-PyTorch core (func.py:45-65) in float64 -- the
+    function the reference's gradcheck script holds its CUDA backward to (mdqe/models/ops/test.py:63-86)."""
+    func = refshim.ref("mdqe.models.ops.functions.ms_deform_attn_func")
+    core = func.ms_deform_attn_core_pytorch
+    g = torch.Generator().manual_seed(17)
+    cases = {
+        "enc": dict(B=1, shapes=[(6, 10), (3, 5), (2, 3), (1, 2)], M=8, D=32, Q=None, P=4, spread=0.2),
+        "dec": dict(B=2, shapes=[(6, 10), (3, 5), (2, 3), (1, 2)], M=8, D=32, Q=21, P=4, spread=0.6),
+        "swin_d24": dict(B=1, shapes=[(8, 14), (4, 7)], M=4, D=24, Q=33, P=2, spread=0.3),
+        "tiny_d8": dict(B=1, shapes=[(5, 7), (3, 4)], M=4, D=8, Q=5, P=3, spread=1.0),
+    }
+    arrs = {}
+    for name, c in cases.items():
+        sh = torch.as_tensor(c["shapes"], dtype=torch.long)
+        S = int(sh.prod(1).sum())
+        Q = c["Q"] or S
+        L = len(c["shapes"])
+        value = torch.randn(c["B"], S, c["M"], c["D"], generator=g)
+        ref = torch.rand(c["B"], Q, 1, 1, 1, 2, generator=g)
+        loc = ref + torch.randn(c["B"], Q, c["M"], L, c["P"], 2, generator=g) * c["spread"]
+        attn = torch.softmax(torch.randn(c["B"], Q, c["M"], L * c["P"], generator=g), -1).view(c["B"], Q, c["M"], L, c["P"])
+        gout = torch.randn(c["B"], Q, c["M"] * c["D"], generator=g)
+        with torch.enable_grad():
+            v, lo, at = (t.double().requires_grad_(True) for t in (value, loc, attn))
+            out = core(v, sh, lo, at)
+            gv, gl, ga = torch.autograd.grad(out, (v, lo, at), gout.double())
+        st = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+        arrs.update({f"{name}::value": value, f"{name}::shapes": sh, f"{name}::level_start": st, f"{name}::loc": loc,
+                     f"{name}::attn": attn, f"{name}::grad_out": gout, f"{name}::grad_value": gv.float(),
+                     f"{name}::grad_loc": gl.float(), f"{name}::grad_attn": ga.float()})
+    save("msda_backward", **arrs)
+
+
 if __name__ == "__main__":
     refshim.install()
+    if len(sys.argv) > 1 and sys.argv[1] == "msda_backward":
+        gen_msda_backward()
+        sys.exit(0)
     with torch.no_grad():
         gen_msda()
+        gen_msda_backward()
         gen_misc()
         model, enc_out, enc_masks, shapes = gen_encoder()
         gen_decoder(model, enc_out, enc_masks, shapes)

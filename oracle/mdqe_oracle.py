@@ -143,6 +143,17 @@ def msda_forward(value: Tensor, shapes: Sequence[Tuple[int, int]], level_start: 
     return out.reshape(B, Q, M * D)
 
 
+def msda_backward(value: Tensor, shapes, level_start, loc: Tensor, attn: Tensor, grad_out: Tensor):
+    """Gradients of msda_forward w.r.t. (value, loc, attn) -- what ms_deform_attn_cuda_backward returns
+    (mdqe/models/ops/src/cuda/ms_deform_attn_cuda.cu:83-153; col2im kernels ms_deform_im2col_cuda.cuh:87-234).  The forward
+    above is differentiable as written (floor() carries no gradient, exactly like the kernel's h_low / w_low), so autograd
+    through it IS the restatement; the reference's own gradcheck (ops/test.py:63-86) pins its CUDA kernel the same way."""
+    with torch.enable_grad():
+        v, lo, at = (t.detach().clone().requires_grad_(True) for t in (value, loc, attn))
+        out = msda_forward(v, shapes, level_start, lo, at)
+        return list(torch.autograd.grad(out, (v, lo, at), grad_out))
+
+
 # --------------------------------------------------------------------------------------------
 # a8 / a13: MSDeformAttn module (mdqe/models/ops/modules/ms_deform_attn.py)
 # --------------------------------------------------------------------------------------------

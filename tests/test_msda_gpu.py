@@ -87,3 +87,42 @@ def test_full_size_properties():
     # oracle on a slice of queries
     ref = O.msda_forward(v1[:1], shapes, starts, loc[:1, :600], at[:1, :600])
     assert maxdiff(o1[:1, :600].cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", ["enc", "dec", "swin_d24", "tiny_d8"])
+def test_backward_vs_reference_core_gradients(case):
+    """ms_deform_attn_backward (HIP, fp32, float atomics) vs float64 autograd through the reference's own PyTorch core --
+    the check the reference's ops/test.py:63-86 applies to its CUDA kernel -- and vs the oracle."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    fx = Fixture("msda_backward")
+    g = lambda k: fx.t(f"{case}::{k}")
+    args = [g(k).cuda() for k in ("value", "shapes", "level_start", "loc", "attn", "grad_out")]
+    gv, gl, ga = MSDA.ms_deform_attn_backward(*args, 64)
+    ov, ol, oa = O.msda_backward(g("value"), fx.shapes(f"{case}::shapes"), [int(v) for v in g("level_start")], g("loc"), g("attn"),
+                                 g("grad_out"))
+    for got, name, orc in ((gv, "grad_value", ov), (gl, "grad_loc", ol), (ga, "grad_attn", oa)):
+        ref = g(name)
+        scale = max(1.0, float(ref.abs().max()))
+        assert got.shape == ref.shape and got.dtype == torch.float32
+        assert maxdiff(got.cpu(), ref) <= 3e-5 * scale, (case, name, maxdiff(got.cpu(), ref), scale)
+        assert maxdiff(got.cpu(), orc) <= 5e-5 * scale
+
+
+def test_backward_contract():
+    """Inputs are borrowed, outputs are new tensors, grad_value is fully overwritten (zero where nothing samples), wrong
+    inputs raise like the forward."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    B, S, M, D, Q, L, P = 1, 12, 2, 4, 3, 1, 2
+    value = torch.randn(B, S, M, D).cuda()
+    shapes = torch.tensor([[3, 4]]).cuda(); st = torch.tensor([0]).cuda()
+    loc = torch.full((B, Q, M, L, P, 2), 5.0).cuda()            # every sample outside the map
+    attn = torch.rand(B, Q, M, L, P).cuda()
+    go = torch.randn(B, Q, M * D).cuda()
+    v0 = value.clone()
+    gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, st, loc, attn, go, 64)
+    assert torch.equal(value, v0)
+    assert float(gv.abs().max()) == 0 and float(gl.abs().max()) == 0 and float(ga.abs().max()) == 0
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_backward(value, shapes, st, loc, attn, go.cpu(), 64)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_backward(value, shapes, st, loc.transpose(1, 2), attn, go, 64)

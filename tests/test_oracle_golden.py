@@ -36,6 +36,19 @@ def test_msda_cases(case):
     assert maxdiff(out, fx.t(f"{case}::out")) < 5e-6
 
 
+@pytest.mark.parametrize("case", ["enc", "dec", "swin_d24", "tiny_d8"])
+def test_msda_backward_cases(case):
+    """Oracle gradients vs the float64 gradients of the reference's own PyTorch core (fixture made by make_golden.py)."""
+    fx = Fixture("msda_backward")
+    g = lambda k: fx.t(f"{case}::{k}")
+    for dt, tol in ((torch.float64, 1e-6), (torch.float32, 2e-5)):
+        gv, gl, ga = O.msda_backward(g("value").to(dt), fx.shapes(f"{case}::shapes"), [int(v) for v in g("level_start")],
+                                     g("loc").to(dt), g("attn").to(dt), g("grad_out").to(dt))
+        for got, name in ((gv, "grad_value"), (gl, "grad_loc"), (ga, "grad_attn")):
+            ref = g(name)
+            assert maxdiff(got, ref) <= tol * max(1.0, float(ref.abs().max())), (case, name, dt)
+
+
 def test_misc():
     fx = Fixture("misc_small")
     assert maxdiff(O.aligned_bilinear(fx.t("ab_in"), 4), fx.t("ab_out4")) < 1e-6
