@@ -114,6 +114,8 @@ int mdqe_f16x3_split_f32(const float* w, long n, void* planes, void* stream);
 int mdqe_debug_gemm_stamps(void* buf);
 /* tools/ only: fp32 GEMM kernel form, 0 = K-step 32 (gemm.hip), 1 = K-step 16 (gemm_k16.hip), 2 = chosen by shape (default). */
 int mdqe_debug_gemm_variant(int v);
+/* tools/ only: window attention kernel form, 1 = MFMA where it applies (default), 0 = scalar everywhere. */
+int mdqe_debug_window_attn_variant(int v);
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
  * X [NI,H,W,Cin] (Cin % 32 == 0; images x_img_stride floats apart, <=0: dense), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,

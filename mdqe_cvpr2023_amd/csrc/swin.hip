@@ -172,6 +172,125 @@ window_attn_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o
     *reinterpret_cast<f32x4*>(o + (row0 + r) * ldo + h * D + c) = f32x4{acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv};
 }
 
+// MFMA form (head dim 32, N <= 192): one block of three waves per (window, head); normalised K and V of the window in LDS
+// (rows padded to 36 floats); wave w owns the 16-query row tiles w, w+3, ...  Both products run on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32, exact fp32 like the scalar form):
+//   S^T tile (16 keys x 16 queries) = Kn_tile . Qn_tile^T, the head dimension walked as d = 8*(lane>>4) + t, t = 0..7;
+//   the accumulator then holds, for query lane&15, the keys j0 + 4*(lane>>4) + r -- exactly the A-operand layout of the
+//   second product if ITS k index is taken as that same key order (B = V[key][d] is read from LDS in any order), so the
+//   probabilities never leave their registers;  O tile (16 queries x 16 d) += P . V.
+// Softmax statistics per query: 36 scores in-lane, then two cross-lane steps over the four 16-lane groups.
+__global__ void __launch_bounds__(192)
+window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o, long ldo, int N, int C, int nh,
+                        const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ mask, int nW) {
+  constexpr int D = 32, LDK = 36, MAXT = 12;         // up to 12 key tiles (N <= 192)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int NT = (N + 15) / 16, NP = NT * 16;
+  float* sK = sm;                                    // [NP][36] normalised keys (rows >= N zero)
+  float* sV = sm + NP * LDK;                         // [NP][36]
+  const int win = blockIdx.x / nh, h = blockIdx.x % nh;
+  const long row0 = (long)win * N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, g = lane >> 4;
+  for (int r = tid; r < NP; r += 192) {
+    f32x4 kk[8], vv[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      kk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; vv[c] = kk[c];
+      if (r < N) {
+        kk[c] = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * ld + C + h * D + c * 4);
+        vv[c] = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * ld + 2 * C + h * D + c * 4);
+      }
+      ss += kk[c][0] * kk[c][0] + kk[c][1] * kk[c][1] + kk[c][2] * kk[c][2] + kk[c][3] * kk[c][3];
+    }
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);              // F.normalize eps
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      *reinterpret_cast<f32x4*>(sK + r * LDK + c * 4) = kk[c] * inv;
+      *reinterpret_cast<f32x4*>(sV + r * LDK + c * 4) = vv[c];
+    }
+  }
+  __syncthreads();
+  const float L2E = 1.4426950408889634f;
+  const float sc = scale[h] * L2E;
+  for (int rt = wave; rt < NT; rt += 3) {
+    const int i0 = rt * 16;
+    const int qi = min(i0 + lc, N - 1);                              // padded query rows repeat the last one (never stored)
+    // Q fragment: d = 8g .. 8g+7 of query qi, normalised and pre-scaled by logit_scale * log2(e)
+    float q[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qkv + (row0 + qi) * ld + h * D + 8 * g);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(qkv + (row0 + qi) * ld + h * D + 8 * g + 4);
+      float ss = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+      ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+      const float inv = sc / fmaxf(sqrtf(ss), 1e-12f);
+      q[0] = a[0] * inv; q[1] = a[1] * inv; q[2] = a[2] * inv; q[3] = a[3] * inv;
+      q[4] = b[0] * inv; q[5] = b[1] * inv; q[6] = b[2] * inv; q[7] = b[3] * inv;
+    }
+    const float* bp = bias + ((long)h * N + qi) * N;
+    const float* mp = mask != nullptr ? mask + ((long)(win % nW) * N + qi) * N : nullptr;
+    f32x4 sT[MAXT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < MAXT; ++jt) {
+      if (jt < NT) {
+        const float* kr = sK + (jt * 16 + lc) * LDK + 8 * g;
+        const f32x4 ka = *reinterpret_cast<const f32x4*>(kr), kb = *reinterpret_cast<const f32x4*>(kr + 4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], q[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[t], q[4 + t], acc, 0, 0, 0);
+        const int j = jt * 16 + 4 * g;                               // this lane's four keys j .. j+3 (N % 4 == 0)
+        if (j < N) {
+          f32x4 bb = *reinterpret_cast<const f32x4*>(bp + j);
+          if (mp != nullptr) bb += *reinterpret_cast<const f32x4*>(mp + j);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { acc[r] = __builtin_fmaf(bb[r], L2E, acc[r]); mx = fmaxf(mx, acc[r]); }
+        } else {
+          acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+        sT[jt] = acc;
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float lsum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MAXT; ++jt)
+      if (jt < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float pv = __builtin_amdgcn_exp2f(sT[jt][r] - mx); sT[jt][r] = pv; lsum += pv; }
+      }
+    lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
+    const float linv = 1.f / lsum;                                   // of query lc, replicated over the four lane groups
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;                        // O[query 4g+r][d = lc] and [d = 16 + lc]
+#pragma unroll
+    for (int jt = 0; jt < MAXT; ++jt)
+      if (jt < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vr = sV + (jt * 16 + 4 * g + r) * LDK + lc;
+          o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], o1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float li = __shfl(linv, 4 * g + r);                      // 1/sum of query 4g+r lives in lanes with lc == 4g+r
+      const int qrow = i0 + 4 * g + r;
+      if (qrow < N) {
+        float* op = o + (row0 + qrow) * ldo + h * D + lc;
+        op[0] = o0[r] * li;
+        op[16] = o1[r] * li;
+      }
+    }
+  }
+}
+
+static int g_window_attn_variant = 1;   // 1: MFMA form where it applies, 0: scalar form everywhere (tools/ A/B)
+extern "C" int mdqe_debug_window_attn_variant(int v) { g_window_attn_variant = v; return MDQE_OK; }
+
 extern "C" int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int N, int C, int nh,
                                     const float* scale, const float* bias, const float* mask, int nW, void* stream) {
   MDQE_REQUIRE(n_windows >= 0 && N > 0 && N <= 256 && nh > 0 && C % nh == 0 && ld % 4 == 0 && ldo % 4 == 0 && nW > 0);
@@ -180,8 +299,13 @@ extern "C" int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ld
   if (n_windows == 0) return MDQE_OK;
   MDQE_CHECK_PTR(qkv); MDQE_CHECK_PTR(o); MDQE_CHECK_PTR(scale); MDQE_CHECK_PTR(bias);
   mdqe_clear_error();
-  const size_t smem = (size_t)2 * N * D * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  if (D == 32 && N <= 192 && N % 4 == 0 && g_window_attn_variant != 0) {
+    const size_t smem2 = (size_t)2 * ((N + 15) / 16 * 16) * 36 * sizeof(float);
+    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(n_windows * nh), dim3(192), smem2, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW);
+    return mdqe_launch_status();
+  }
+  const size_t smem = (size_t)2 * N * D * sizeof(float);
 #define L(DD) do { (void)hipFuncSetAttribute((const void*)window_attn_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL((window_attn_kernel<DD>), dim3(n_windows * nh), dim3(256), smem, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW); } while (0)
   if (D == 32) L(32); else if (D == 24) L(24); else if (D == 16) L(16); else L(8);

@@ -311,3 +311,34 @@ def test_gemm_f16x3_presplit_weights():
             assert float((out.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()) < 3e-6, (Cin, Cout, k, s)
     finally:
         ops.set_gemm_precision("f32")
+
+
+@pytest.mark.parametrize("N,nh,nW,shifted", [(144, 6, 12, True), (144, 3, 1, False), (36, 4, 6, True), (64, 2, 1, False)])
+def test_window_attention_mfma_vs_fp64_and_scalar_form(N, nh, nW, shifted):
+    """Cosine window attention (swin_transformer_v2.py:147-186) on the fp32 matrix cores vs an fp64 evaluation of the same
+    formula and vs the scalar kernel form."""
+    from mdqe_cvpr2023_amd import ops
+    from mdqe_cvpr2023_amd._lib import lib
+    g = torch.Generator().manual_seed(41)
+    C, nwin = 32 * nh, 2 * nW + 1
+    qkv = torch.randn(nwin * N, 3 * C, generator=g)
+    scale = torch.rand(nh, generator=g) * 20 + 1
+    bias = torch.randn(nh, N, N, generator=g)
+    mask = None
+    if shifted:
+        mask = torch.where(torch.rand(nW, N, N, generator=g) < 0.3, torch.tensor(-100.0), torch.tensor(0.0))
+    q, k, v = (qkv[:, i * C:(i + 1) * C].double().view(nwin, N, nh, 32).transpose(1, 2) for i in range(3))
+    att = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-1, -2) * scale.double().view(1, nh, 1, 1) + bias.double()[None]
+    if mask is not None:
+        att = att + mask.double()[torch.arange(nwin) % nW][:, None]
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(nwin * N, C)
+    outs = []
+    try:
+        for variant in (1, 0):
+            lib.mdqe_debug_window_attn_variant(variant)
+            outs.append(ops.window_attn(qkv.cuda(), nwin, N, C, nh, scale.cuda(), bias.cuda(), None if mask is None else mask.cuda(), nW).cpu())
+    finally:
+        lib.mdqe_debug_window_attn_variant(1)
+    for o in outs:
+        assert float((o.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5
