@@ -116,6 +116,7 @@ int mdqe_debug_gemm_stamps(void* buf);
 int mdqe_debug_gemm_variant(int v);
 /* tools/ only: window attention kernel form, 1 = MFMA where it applies (default), 0 = scalar everywhere. */
 int mdqe_debug_window_attn_variant(int v);
+int mdqe_debug_mha_variant(int v);   /* same for the 196-token decoder self-attention */
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
  * X [NI,H,W,Cin] (Cin % 32 == 0; images x_img_stride floats apart, <=0: dense), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,

@@ -61,6 +61,102 @@ mha_small_kernel(const float* __restrict__ qk, long ldqk, const float* __restric
     *reinterpret_cast<f32x4*>(o + (row0 + r) * ldo + h * D + c) = f32x4{acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv};
 }
 
+// MFMA form (D = 32 or 24, Q <= 208): the scheme of window_attn_mfma_kernel (swin.hip) without normalisation / bias:
+// three waves per (batch, head), K and V in LDS (rows padded to 36 floats), S^T tiles = K_tile . (q * D^-0.5)^T on
+// v_mfma_f32_16x16x4_f32 with the head dimension walked as d = (D/4)*(lane>>4) + t, probabilities kept in the
+// accumulator registers and fed straight into the P . V product (its k index follows the same key order).
+template <int D>
+__global__ void __launch_bounds__(192)
+mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __restrict__ v, long ldv, float* __restrict__ o,
+                      long ldo, int Q, int C, int nh) {
+  constexpr int LDK = 36, MAXT = 13, DG = D / 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int NT = (Q + 15) / 16, NP = NT * 16;
+  float* sK = sm;                                    // [NP][36] (rows >= Q zero)
+  float* sV = sm + NP * LDK;
+  const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+  const long row0 = (long)b * Q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, g = lane >> 4;
+  for (int i = tid; i < NP * 8; i += 192) {
+    const int r = i >> 3, c4 = i & 7;
+    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
+    if (r < Q && c4 * 4 < D) {
+      kk = *reinterpret_cast<const f32x4*>(qk + (row0 + r) * ldqk + C + h * D + c4 * 4);
+      vv = *reinterpret_cast<const f32x4*>(v + (row0 + r) * ldv + h * D + c4 * 4);
+    }
+    *reinterpret_cast<f32x4*>(sK + r * LDK + c4 * 4) = kk;
+    *reinterpret_cast<f32x4*>(sV + r * LDK + c4 * 4) = vv;
+  }
+  __syncthreads();
+  const float sc = rsqrtf((float)D) * 1.4426950408889634f;
+  for (int rt = wave; rt < NT; rt += 3) {
+    const int i0 = rt * 16;
+    const int qi = min(i0 + lc, Q - 1);
+    float q[DG];
+    {
+      const float* qp = qk + (row0 + qi) * ldqk + h * D + DG * g;
+#pragma unroll
+      for (int t = 0; t < DG; t += 2) { const f32x2 a = *reinterpret_cast<const f32x2*>(qp + t); q[t] = a[0] * sc; q[t + 1] = a[1] * sc; }
+    }
+    f32x4 sT[MAXT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < MAXT; ++jt) {
+      if (jt < NT) {
+        const float* kr = sK + (jt * 16 + lc) * LDK + DG * g;
+        float ka[DG];
+#pragma unroll
+        for (int t = 0; t < DG; t += 2) { const f32x2 a = *reinterpret_cast<const f32x2*>(kr + t); ka[t] = a[0]; ka[t + 1] = a[1]; }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < DG; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], q[t], acc, 0, 0, 0);
+        const int j = jt * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (j + r >= Q) acc[r] = -INFINITY;
+          mx = fmaxf(mx, acc[r]);
+        }
+        sT[jt] = acc;
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float lsum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MAXT; ++jt)
+      if (jt < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float pv = __builtin_amdgcn_exp2f(sT[jt][r] - mx); sT[jt][r] = pv; lsum += pv; }
+      }
+    lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
+    const float linv = 1.f / lsum;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+    for (int jt = 0; jt < MAXT; ++jt)
+      if (jt < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vr = sV + (jt * 16 + 4 * g + r) * LDK + lc;
+          o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], o1, 0, 0, 0);     // columns >= D are zero in LDS
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float li = __shfl(linv, 4 * g + r);
+      const int qrow = i0 + 4 * g + r;
+      if (qrow < Q) {
+        float* op = o + (row0 + qrow) * ldo + h * D + lc;
+        op[0] = o0[r] * li;
+        if (16 + lc < D) op[16] = o1[r] * li;
+      }
+    }
+  }
+}
+
+static int g_mha_variant = 1;   // 1: MFMA form where it applies, 0: scalar form everywhere (tools/ A/B)
+extern "C" int mdqe_debug_mha_variant(int v) { g_mha_variant = v; return MDQE_OK; }
+
 extern "C" int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, long ldv, float* o, long ldo, int B, int Q,
                                   int C, int nh, void* stream) {
   MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && nh > 0 && C % nh == 0 && ldqk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0);
@@ -69,8 +165,14 @@ extern "C" int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, lo
   if (B == 0) return MDQE_OK;
   MDQE_CHECK_PTR(qk); MDQE_CHECK_PTR(v); MDQE_CHECK_PTR(o);
   mdqe_clear_error();
-  const size_t smem = (size_t)2 * Q * D * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  if ((D == 32 || D == 24) && Q <= 208 && g_mha_variant != 0) {
+    const size_t smem2 = (size_t)2 * ((Q + 15) / 16 * 16) * 36 * sizeof(float);
+    if (D == 32) hipLaunchKernelGGL((mha_small_mfma_kernel<32>), dim3(B * nh), dim3(192), smem2, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh);
+    else hipLaunchKernelGGL((mha_small_mfma_kernel<24>), dim3(B * nh), dim3(192), smem2, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh);
+    return mdqe_launch_status();
+  }
+  const size_t smem = (size_t)2 * Q * D * sizeof(float);
 #define L(DD) do { (void)hipFuncSetAttribute((const void*)mha_small_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL((mha_small_kernel<DD>), dim3(B * nh), dim3(256), smem, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh); } while (0)
   if (D == 32) L(32); else if (D == 24) L(24); else if (D == 16) L(16); else L(8);

@@ -176,8 +176,14 @@ def test_mha_small():
         k = qk[:, C:].view(B, Q, nh, d).transpose(1, 2)
         vv = v.view(B, Q, nh, d).transpose(1, 2)
         ref = (torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), -1) @ vv).transpose(1, 2).reshape(B * Q, C)
-        out = ops.mha_small(qk.cuda(), v.cuda(), B, Q, C, nh).cpu()
-        assert float((out - ref).abs().max()) < 2e-5
+        from mdqe_cvpr2023_amd._lib import lib
+        try:
+            for variant in (1, 0):                     # fp32-MFMA form and scalar form
+                lib.mdqe_debug_mha_variant(variant)
+                out = ops.mha_small(qk.cuda(), v.cuda(), B, Q, C, nh).cpu()
+                assert float((out - ref).abs().max()) < 2e-5, (B, Q, C, variant)
+        finally:
+            lib.mdqe_debug_mha_variant(1)
 
 
 def test_query_select_and_sampling():
