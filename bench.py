@@ -226,7 +226,7 @@ def main():
     def step():
         if world == 1:
             return model([{"image": shard, "height": fh, "width": fw}])
-        return sharding.run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size=(fh, fw))
+        return sharding.run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), emit_masks=(rank == 0))
 
     def sync():
         if dist is not None:

@@ -247,7 +247,7 @@ class MDQE(nn.Module):
         return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace), (h, w), out_size,
                                 (geo.Hp // ms, geo.Wp // ms), n_frames=L)
 
-    def inference_video(self, image_size, cls_clips, windows, frame_hw, n_frames, early=None):
+    def inference_video(self, image_size, cls_clips, windows, frame_hw, n_frames, early=None, emit_masks=True):
         """mdqe/mdqe.py:430-471.  The x4 aligned-bilinear up-sampling, sigmoid, crop (:357-358), nearest resize to the
         original size and the 0.5 threshold (:458-462) run as ONE kernel per window; windows in which an instance did not
         exist yet stay zero (:442).  `early` (ClipMerger, CUDA): the masks of every tracked instance were already produced
@@ -263,16 +263,13 @@ class MDQE(nn.Module):
         inst = torch.div(ti, K, rounding_mode="floor").tolist()
         sel = sorted(set(inst))
         Ho, Wo = int(image_size[0]), int(image_size[1])
+        if not emit_masks:
+            return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels, "pred_masks": []}
         if early is not None:
-            host = early["host"]                                   # [cap, n_frames, Ho, Wo] uint8, pinned
             early["done"].synchronize()
-            for f_off, nf, n_w in early["windows"]:                # instances born after a window: zero there (:442)
-                for i in sel:
-                    if i >= n_w:
-                        host[i, f_off:f_off + nf].zero_()
-            hb = host.view(torch.bool)
+            hosts = early["host"]                                  # per instance: [n_frames, Ho, Wo] uint8, pinned
             return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels,
-                    "pred_masks": [hb[i, :n_frames] for i in inst]}
+                    "pred_masks": [hosts[i].view(torch.bool)[:n_frames] for i in inst]}
         out = torch.zeros(len(sel), n_frames, Ho, Wo, dtype=torch.uint8, device=self.device)
         sel_dev = torch.tensor(sel, dtype=torch.int32, device=self.device)
         for f_off, m in windows:
@@ -290,8 +287,9 @@ class ClipMerger:
     final video merge.  The tracker runs on its own HIP stream so that its small kernels and per-clip host syncs overlap
     with per-frame work the producer has already queued on the main stream."""
 
-    def __init__(self, model, frame_hw, out_size, mask_hw, n_frames=None):
+    def __init__(self, model, frame_hw, out_size, mask_hw, n_frames=None, emit_masks=True):
         self.model, self.frame_hw, self.out_size, self.mask_hw = model, frame_hw, out_size, mask_hw
+        self.emit_masks = emit_masks                # False: scores / labels only (ranks > 0 of a sharded video)
         self.n_frames = n_frames                    # total frames of the video when known: enables the early mask path
         self.early = None
         # MODEL.MDQE.MERGE_ON_CPU exists in the reference to fit 16-40 GB GPUs (mdqe/mdqe.py:185-186,354-355); with
@@ -326,7 +324,9 @@ class ClipMerger:
                 c, m = self.tracker.get_result(is_last_clip=last)   # m: mean logits [n, F, Hm, Wm] of this window
                 self.cls_clips.append(c)
                 m = m.contiguous()
-                if self.use_side and self.n_frames is not None:
+                if not self.emit_masks:
+                    self.windows.append((self.f_off, None))
+                elif self.use_side and self.n_frames is not None:
                     self._early_masks(m)
                     self.windows.append((self.f_off, None))
                 else:
@@ -339,7 +339,8 @@ class ClipMerger:
     def _early_masks(self, m):
         """Final masks of EVERY instance tracked so far for the window just flushed (m: [n, F, Hm, Wm] mean logits), copied to
         pinned host memory on a copy stream while later windows compute; finish() then only selects rows.  A few rows may
-        be produced in vain (instances that miss the final top-k)."""
+        be produced in vain (instances that miss the final top-k).  One pinned buffer per track (no re-allocation as tracks
+        appear; the caching host allocator recycles the blocks of the previous call)."""
         from . import ops
         model = self.model
         n, nf = int(m.shape[0]), int(m.shape[1])
@@ -347,14 +348,14 @@ class ClipMerger:
         if model._copy_stream is None:
             model._copy_stream = torch.cuda.Stream(self.dev)
         cs = model._copy_stream
-        if self.early is None or self.early["host"].shape[0] < n:
-            cap = max(16, 2 * n)
-            host = torch.empty(cap, self.n_frames, Ho, Wo, dtype=torch.uint8, pin_memory=True)
-            if self.early is not None:                  # grew past the capacity: keep what has been copied so far
-                self.early["done"].synchronize()
-                old = self.early["host"]
-                host[:old.shape[0]].copy_(old)
-            self.early = {"host": host, "windows": [] if self.early is None else self.early["windows"], "done": torch.cuda.Event()}
+        if self.early is None:
+            self.early = {"host": [], "windows": [], "done": torch.cuda.Event()}
+        hosts = self.early["host"]
+        while len(hosts) < n:                       # a new track: its own pinned [L, Ho, Wo] buffer, zero before its first window (:442)
+            hbuf = torch.empty(self.n_frames, Ho, Wo, dtype=torch.uint8, pin_memory=True)
+            if self.f_off > 0:
+                hbuf[:self.f_off].zero_()
+            hosts.append(hbuf)
         if n:
             dev = torch.empty(n, nf, Ho, Wo, dtype=torch.uint8, device=self.dev)
             idx = torch.arange(n, dtype=torch.int32, device=self.dev)
@@ -362,7 +363,7 @@ class ClipMerger:
             cs.wait_stream(self.side)
             with torch.cuda.stream(cs):
                 for i in range(n):
-                    self.early["host"][i, self.f_off:self.f_off + nf].copy_(dev[i], non_blocking=True)
+                    hosts[i][self.f_off:self.f_off + nf].copy_(dev[i], non_blocking=True)
                 dev.record_stream(cs)
                 self.early["done"].record(cs)
         self.early["windows"].append((self.f_off, nf, n))
@@ -373,7 +374,8 @@ class ClipMerger:
             for _, m in self.windows:
                 if m is not None:
                     m.record_stream(self.main)
-        return self.model.inference_video(self.out_size, self.cls_clips, self.windows, self.frame_hw, self.f_off, early=self.early)
+        return self.model.inference_video(self.out_size, self.cls_clips, self.windows, self.frame_hw, self.f_off, early=self.early,
+                                          emit_masks=self.emit_masks)
 
 
 try:                                              # drop-in registration when detectron2 is present

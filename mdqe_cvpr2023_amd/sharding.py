@@ -119,8 +119,9 @@ def owned_chunks(plan, world, rank):
     return [g for g in range(len(plan)) if g % world == rank]
 
 
-def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size):
-    """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns."""
+def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True):
+    """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
+    emit_masks=False (ranks that only keep the tracker in step): scores and labels are returned, masks are not produced."""
     from .meta_arch import ClipMerger
     cfg = model.cfg
     T = cfg.n_frames_test
@@ -131,7 +132,7 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size):
     mask_hw = (geo.Hp // ms, geo.Wp // ms)
     proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
              "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((T,) + tuple(mask_hw), torch.float32)}
-    merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan))
+    merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
     rounds = (len(plan) + world - 1) // world
 
     def start(q):
