@@ -755,7 +755,7 @@ def inference_video(hp: Hyper, out_size, cls_clips: List[Tensor], mask_clips: Li
         vids.append(torch.cat([m[i] if i < m.shape[0] else torch.zeros_like(m[0]) for m in mask_clips], 0))
     labels = torch.arange(hp.num_classes).unsqueeze(0).repeat(out_cls.shape[0], 1).flatten()
     flat = out_cls.flatten()
-    k = max(int(flat.gt(0.05).sum()), 10)
+    k = min(max(int(flat.gt(0.05).sum()), 10), flat.numel())     # clamp: the reference (:449-450) assumes >= 10 scores
     sc, ti = flat.topk(k, sorted=False)
     lab = labels[ti].tolist()
     inst = torch.div(ti, hp.num_classes, rounding_mode="floor")

@@ -69,3 +69,11 @@ def test_wrong_inputs_raise():
         model([{"image": video(2, 64, 96)}, {"image": video(2, 64, 96)}])      # one video per call (mdqe/mdqe.py:292)
     with pytest.raises(RuntimeError):
         model.train(True)
+
+
+def test_fewer_than_ten_scores(monkeypatch):
+    """instances x classes < 10: the final top-k (reference :449-450 asks for max(#>0.05, 10)) is clamped to what exists."""
+    import sys
+    monkeypatch.setitem(sys.modules[__name__].KW, "num_classes", 3)
+    out = run_both(video(5, 64, 96, seed=3), (64, 96), EV)
+    assert 1 <= len(out["pred_scores"]) <= 9
