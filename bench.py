@@ -226,7 +226,7 @@ def main():
     def step():
         if world == 1:
             return model([{"image": shard, "height": fh, "width": fw}])
-        return sharding.run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), emit_masks=(rank == 0))
+        return sharding.run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), root_only=True)
 
     def sync():
         if dist is not None:
@@ -299,8 +299,8 @@ def main():
                        "instances_out": len(out["pred_scores"]), "tracked_instances": len(set(m.data_ptr() for m in out["pred_masks"])),
                        "cls_bias_shift": round(bias_shift, 3),
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
-                       "parallelism": "1 process/GPU; 30-frame chunks dealt round-robin, per-round RCCL all-gather of clip results, "
-                                      "tracker replay overlapped with the next round" if world > 1 else "single GPU"},
+                       "parallelism": "1 process/GPU; 30-frame chunks dealt round-robin, per-round RCCL gather of the clip results "
+                                      "to rank 0, whose tracker replay runs on a worker thread under the next round" if world > 1 else "single GPU"},
         }
         if g:
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_k16_kernel<128,128,2,2> (+ gemm_nt_f32_kernel<128,128,2,2> for deep-K convs)" if args.precision == "f32" else

@@ -54,29 +54,43 @@ def pack(results, T, device):
     return out, nmax
 
 
-def all_gather_clips(local, T, dist, world, device, proto_shapes):
-    """Variable-length all-gather: sizes first, then payloads padded to the global maxima."""
+def all_gather_clips(local, T, dist, world, device, proto_shapes, root=None, rank=0):
+    """Variable-length gather: sizes first (all-gather, 16 B per rank), then payloads padded to the global maxima.
+    root=None: all-gather, every rank gets the merged list.  root=r: payloads go to rank r only (`dist.gather`; the other
+    ranks return None) -- 1/world of the all-gather's traffic into every non-root rank."""
     packed, nmax = pack(local, T, device)
     sizes = torch.tensor([len(local), nmax], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
     cmax = int(max(int(s[0]) for s in all_sizes))
     gmax = int(max(int(s[1]) for s in all_sizes))
+    mine = root is None or rank == root
+
+    def exchange(buf):
+        outs = [torch.zeros_like(buf) for _ in range(world)] if mine else None
+        if root is None:
+            dist.all_gather(outs, buf)
+        else:
+            dist.gather(buf, outs, dst=root)
+        return outs
+
     merged = []
     gathered = {}
     meta = torch.zeros(cmax, 4, dtype=torch.int64, device=device)
     meta[:len(local)] = packed["meta"]
-    bufs = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(bufs, meta)
-    gathered["meta"] = bufs
+    gathered["meta"] = exchange(meta)
     for f in FIELDS:
         shape, dtype = proto_shapes[f]
         buf = torch.zeros([cmax, gmax] + list(shape), dtype=dtype, device=device)
         if packed[f] is not None and packed[f].numel() > 0:
             buf[:packed[f].shape[0], :packed[f].shape[1]] = packed[f]
-        outs = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(outs, buf)
-        gathered[f] = outs
+        gathered[f] = exchange(buf)
+    if not mine:
+        return None
+    ready = None
+    if device.type == "cuda":
+        ready = torch.cuda.Event()
+        ready.record()                                 # the gathered payloads are complete once this event fires
     for r in range(world):
         nclips = int(all_sizes[r][0])
         m = gathered["meta"][r].cpu()
@@ -90,9 +104,48 @@ def all_gather_clips(local, T, dist, world, device, proto_shapes):
                     t = t[:, :e - s].contiguous()
                 res[f] = t
             res["host"] = {f: host[f][i, :n] for f in host}
+            res["ready"] = ready
             merged.append((s, e, bool(l), res))
     merged.sort(key=lambda c: c[0])
     return merged
+
+
+class ReplayThread:
+    """Tracker replay off the main thread (rank 0 of the root-only schedule): the Hungarian matching, the numpy bookkeeping
+    and the per-clip device->host sync of the tracker run while the main thread keeps queueing the next round's kernels
+    (the GIL is released during the syncs and inside the HIP / numpy calls)."""
+
+    def __init__(self, merger, device):
+        import queue
+        import threading
+        self.merger, self.device, self.err = merger, device, None
+        self.q = queue.Queue()
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        try:
+            if self.device.type == "cuda":
+                torch.cuda.set_device(self.device)
+            with torch.no_grad():
+                while True:
+                    items = self.q.get()
+                    if items is None:
+                        return
+                    for it in items:
+                        self.merger.feed(*it)
+        except BaseException as e:                     # surfaced by finish()
+            self.err = e
+
+    def put(self, items):
+        self.q.put(items)
+
+    def finish(self):
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            raise self.err
+        return self.merger.finish()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -119,9 +172,12 @@ def owned_chunks(plan, world, rank):
     return [g for g in range(len(plan)) if g % world == rank]
 
 
-def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True):
+def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False):
     """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
-    emit_masks=False (ranks that only keep the tracker in step): scores and labels are returned, masks are not produced."""
+    Default: every rank all-gathers each round and replays the tracker (all ranks return the video result;
+    emit_masks=False skips the mask production on ranks that only keep the tracker in step).
+    root_only=True (bench.py): the rounds are gathered to rank 0 only, which replays the tracker on a worker thread while
+    its main thread goes on with the next round; the other ranks only compute and send, and return None."""
     from .meta_arch import ClipMerger
     cfg = model.cfg
     T = cfg.n_frames_test
@@ -132,7 +188,12 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
     mask_hw = (geo.Hp // ms, geo.Wp // ms)
     proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
              "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((T,) + tuple(mask_hw), torch.float32)}
-    merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
+    is_root = rank == 0
+    merger = replay = None
+    if not root_only or is_root:
+        merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
+        if root_only:
+            replay = ReplayThread(merger, any_fr.device)
     rounds = (len(plan) + world - 1) // world
 
     def start(q):
@@ -146,11 +207,16 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
     cur = start(0)
     for q in range(rounds):
         local = [r for r in cur] if cur is not None else []        # decoder + clip inference of this rank's chunk
-        merged = all_gather_clips(local, T, dist, world, any_fr.device, proto)
+        merged = all_gather_clips(local, T, dist, world, any_fr.device, proto, root=0 if root_only else None, rank=rank)
         cur = start(q + 1)                         # next round's per-frame work is on the GPU before the replay starts
-        for item in merged:                        # global clip order within the round: chunk q*world, q*world+1, ...
-            merger.feed(*item)
-    return merger.finish()
+        if replay is not None:
+            replay.put(merged)                     # global clip order within the round: chunk q*world, q*world+1, ...
+        elif merger is not None:
+            for item in merged:
+                merger.feed(*item)
+    if replay is not None:
+        return replay.finish()
+    return merger.finish() if merger is not None else None
 
 
 def run_sharded(model, shard_frames, f0, L, rank, world, dist, out_size):

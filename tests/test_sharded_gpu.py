@@ -42,12 +42,15 @@ def worker(rank, world, port, outdir):
         else:
             plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, 4)       # 4-frame chunks -> 3 chunks, 2 rounds
             frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}
-            out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96))
+            out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96),
+                                           root_only=os.environ.get("MDQE_TEST_SHARDING") == "root_only")
+            if os.environ.get("MDQE_TEST_SHARDING") == "root_only":
+                assert (out is None) == (rank != 0)
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["round_robin", "contiguous"])
+@pytest.mark.parametrize("mode", ["round_robin", "root_only", "contiguous"])
 def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     os.environ["MDQE_TEST_SHARDING"] = mode
@@ -62,7 +65,7 @@ def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
     model = MDQE(_cfg(), seed=5).eval()
     with torch.no_grad():
         ref = model([{"image": _video(), "height": 64, "width": 96}])
-    for r in range(2):
+    for r in range(1 if mode == "root_only" else 2):
         out = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
         assert out["pred_labels"] == ref["pred_labels"]
         assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)

@@ -63,6 +63,12 @@ def worker(rank, world, port, outdir):
     proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((CFG.num_classes,), torch.float32),
              "query_embeds": ((CFG.hidden_dim,), torch.float32), "pred_masks": ((T,) + HW, torch.float32)}
     merged = sharding.all_gather_clips(local, T, dist, world, torch.device("cpu"), proto)
+    rooted = sharding.all_gather_clips(local, T, dist, world, torch.device("cpu"), proto, root=0, rank=rank)   # gather-to-root form
+    assert (rooted is None) == (rank != 0)
+    if rank == 0:
+        assert [(s, e, l) for s, e, l, _ in rooted] == [(s, e, l) for s, e, l, _ in merged]
+        for (_, _, _, a), (_, _, _, b) in zip(rooted, merged):
+            assert all(torch.equal(a[f], b[f]) for f in sharding.FIELDS)
     outs = replay(merged)
     torch.save((rank, [(s, e, l) for s, e, l, _ in merged], outs), os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
@@ -106,3 +112,28 @@ def test_round_robin_plan_covers_all_clips_in_order():
             assert all(f0 <= s and e <= f1 for s, e, _ in cl)       # halo covers every clip of the chunk
         owned = sorted(g for r in range(world) for g in sharding.owned_chunks(plan, world, r))
         assert owned == list(range(len(plan)))
+
+
+def test_replay_thread_keeps_order_and_surfaces_errors():
+    class Merger:
+        def __init__(self):
+            self.seen = []
+
+        def feed(self, s, e, last, res):
+            if res == "boom":
+                raise ValueError("boom")
+            self.seen.append(s)
+
+        def finish(self):
+            return self.seen
+
+    m = Merger()
+    t = sharding.ReplayThread(m, torch.device("cpu"))
+    t.put([(0, 3, False, None), (1, 4, False, None)])
+    t.put([(2, 5, True, None)])
+    assert t.finish() == [0, 1, 2]
+    t = sharding.ReplayThread(Merger(), torch.device("cpu"))
+    t.put([(0, 3, False, "boom")])
+    import pytest
+    with pytest.raises(ValueError):
+        t.finish()
