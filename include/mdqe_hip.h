@@ -199,6 +199,16 @@ int mdqe_final_masks_u8(const float* logits, int n_sel, const int* inst_idx_dev,
                         int h, int w, int Ho, int Wo, unsigned char* out, long out_inst_stride, int f_off,
                         void* stream);
 
+/* ---- COCO single-image branch, after the decoder (MDQE.inference_image, mdqe/mdqe.py:486-556), on the centre frame's
+ * low-resolution logits [n,Hm,Wm]; aligned_bilinear x`factor` in closed form, crop [:h,:w].
+ * stats[k] = {sum(sigmoid*[sigmoid>0.5]), count(sigmoid>0.5), xmin, ymin, xmax, ymax of (logit > 0)} (:512-516, :526;
+ * BitMasks.get_bounding_boxes = [xmin, ymin, xmax+1, ymax+1]; xmin > xmax for an empty mask).
+ * final masks: F.interpolate(bilinear, align_corners=False) of the cropped up-sampled logits to (Ho,Wo), > 0 (:545-547);
+ * row k of out (uint8 [n_sel,Ho,Wo]) takes mask idx_dev[k]. */
+int mdqe_image_mask_stats_f32(const float* logits, int n, int Hm, int Wm, int factor, int h, int w, float* stats, void* stream);
+int mdqe_image_final_masks_u8(const float* logits, int n_sel, const int* idx_dev, int Hm, int Wm, int factor, int h, int w,
+                              int Ho, int Wo, unsigned char* out, void* stream);
+
 /* ---- SwinV2 backbone (mdqe/backbone/swin_transformer_v2.py) --------------------------------------------
  * layernorm_post: y = LN(x)*gamma + beta + post (res-post-norm :287-288).
  * patch4_im2col: normalise + zero-pad + 4x4/s4 im2col, k = c*16+kh*4+kw -> [NI*Hp/4*Wp/4, 48] (PatchEmbed :466-479).

@@ -46,6 +46,8 @@ class MDQEConfig:
     pixel_mean: Tuple[float, ...] = (123.675, 116.280, 103.530)
     pixel_std: Tuple[float, ...] = (58.395, 57.120, 57.375)
     min_size_test: int = 360
+    is_coco: bool = False                     # DATASETS.TEST[0].startswith("coco") (mdqe/mdqe.py:70): single-image branch
+    multi_cls: bool = True                    # MODEL.MDQE.MULTI_CLS_ON (mdqe/mdqe.py:187)
     device: str = "cuda"
 
     @property
@@ -93,4 +95,5 @@ def from_d2_cfg(cfg) -> MDQEConfig:
         n_max_inst=m.MAX_NUM_INSTANCES, apply_cls_thres=m.APPLY_CLS_THRES,
         detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE, match_stride=m.MATCH_STRIDE,
         merge_on_cpu=m.MERGE_ON_CPU, pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(cfg.MODEL.PIXEL_STD),
-        device=str(cfg.MODEL.DEVICE))
+        is_coco=str(cfg.DATASETS.TEST[0]).startswith("coco") if len(getattr(cfg.DATASETS, "TEST", ())) else False,
+        multi_cls=bool(getattr(m, "MULTI_CLS_ON", True)), device=str(cfg.MODEL.DEVICE))

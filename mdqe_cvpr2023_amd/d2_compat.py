@@ -88,3 +88,53 @@ def add_swins_config(cfg):
 
 def add_swint_config(cfg):
     _add_swin(cfg, 96, [2, 2, 6, 2], [3, 6, 12, 24], 7, 0.2)
+
+
+# ---- result containers of the COCO single-image branch -----------------------------------------------------------------
+try:                                              # the real ones when detectron2 is installed
+    from detectron2.structures import Boxes, Instances
+except Exception:                                 # detectron2 absent in this image: attribute bags with the fields the evaluator reads
+    class Boxes:
+        def __init__(self, tensor):
+            self.tensor = tensor
+
+        def to(self, device):
+            return Boxes(self.tensor.to(device))
+
+        def __len__(self):
+            return self.tensor.shape[0]
+
+    class Instances:
+        def __init__(self, image_size, **fields):
+            object.__setattr__(self, "_image_size", tuple(image_size))
+            object.__setattr__(self, "_fields", dict(fields))
+
+        @property
+        def image_size(self):
+            return self._image_size
+
+        def __setattr__(self, k, v):
+            self._fields[k] = v
+
+        def __getattr__(self, k):
+            f = object.__getattribute__(self, "_fields")
+            if k in f:
+                return f[k]
+            raise AttributeError(k)
+
+        def has(self, k):
+            return k in self._fields
+
+        def get_fields(self):
+            return self._fields
+
+        def to(self, device):
+            r = Instances(self._image_size)
+            for k, v in self._fields.items():
+                r._fields[k] = v.to(device) if hasattr(v, "to") else v
+            return r
+
+        def __len__(self):
+            for v in self._fields.values():
+                return len(v)
+            return 0

@@ -90,6 +90,8 @@ class MDQE(nn.Module):
         if len(batched_inputs) != 1:
             raise RuntimeError("MDQE eval takes exactly one video per call (mdqe/mdqe.py:292)")
         with torch.autocast(device_type="cuda", enabled=False):           # neutralise ambient autocast
+            if self.cfg.is_coco:                                           # DATASETS.TEST[0] is a COCO set (mdqe/mdqe.py:213,233-236)
+                return self.inference_image(batched_inputs)
             return self.inference_vis(batched_inputs)
 
     def _frame_cache(self, frames, geo, ring=None, at=0):
@@ -246,6 +248,66 @@ class MDQE(nn.Module):
         clips = self.clip_schedule(L, cfg.n_frames_test, cfg.clip_stride)
         return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace), (h, w), out_size,
                                 (geo.Hp // ms, geo.Wp // ms), n_frames=L)
+
+    def inference_image(self, batched_inputs):
+        """COCO single-image branch: MDQE.forward :213-236 -> mdqe.forward (models/mdqe.py:62-70) -> decoder
+        eval branch `is_coco` (transformer_dec.py:247-255) -> MDQE.inference_image (mdqe/mdqe.py:486-556).  The pseudo clip
+        (cfg.n_frames images) goes through the same per-frame stages and decoder as a video clip; the centre frame's masks
+        are scored, box-IoU-suppressed and resized by two kernels that evaluate aligned_bilinear in closed form.
+        Returns [{"instances": Instances(scores, pred_classes, pred_masks, pred_boxes)}]."""
+        from . import ops
+        from .d2_compat import Boxes, Instances
+        cfg, eng = self.cfg, self.engine
+        item = batched_inputs[0]
+        frames = self.to_device_frames(item["image"])
+        T, h, w = int(frames.shape[0]), int(frames.shape[-2]), int(frames.shape[-1])
+        geo = eng.geometry(h, w)
+        cache = self._frame_cache(frames, geo)
+        out = eng.decode_clips(cache, [0], T, geo)
+        cls, coef = out["cls"][0], out["mask_coeff"][0]                      # [Q,K] (sigmoid), [Q,M] (tanh)
+        thr = cfg.apply_cls_thres
+        score = cls.max(-1)[0]
+        idx = torch.nonzero(score >= torch.clamp(score.max(), max=thr)).reshape(-1)       # :504
+        ct = int((cfg.n_frames - 1) / 2)
+        mf = cache["mf"][ct]                                                 # [Hm,Wm,M] channels-last
+        Hm, Wm, Md = mf.shape
+        lg = ops.linear(coef[idx].contiguous(), mf.reshape(-1, Md)).view(-1, Hm, Wm)     # einsum 'qm,mhw->qhw' of the centre frame
+        st = ops.image_mask_stats(lg, cfg.match_stride, h, w)
+        mc = cls[idx] * (st[:, 0] / (st[:, 1] + 1e-6))[:, None]             # mask-quality rescoring :512-516
+        n = int(idx.numel())
+        order = torch.arange(n, device=self.device)
+        if n > 0:                                                            # box-IoU NMS :519-531
+            order = mc.max(-1)[0].sort(descending=True)[1]
+            mc, sb = mc[order], st[order]
+            empty = sb[:, 2] > sb[:, 4]
+            bx = torch.stack([sb[:, 2], sb[:, 3], sb[:, 4] + 1, sb[:, 5] + 1], 1)
+            bx = torch.where(empty[:, None], torch.zeros_like(bx), bx) / torch.tensor([w, h, w, h], device=self.device, dtype=torch.float32)
+            area = (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1])
+            lt = torch.max(bx[:, None, :2], bx[None, :, :2])
+            rb = torch.min(bx[:, None, 2:], bx[None, :, 2:])
+            inter = (rb - lt).clamp(min=0).prod(-1)
+            iou = inter / (area[:, None] + area[None] - inter).clamp(min=1e-3)
+            mc = mc * (1 - torch.triu(iou, diagonal=1).max(0)[0])[:, None]
+        if cfg.multi_cls:                                                    # :534-540
+            ls = torch.nonzero(mc > thr)
+            ii, label = ls[:, 0], ls[:, 1]
+            sc = mc[ii, label]
+        else:
+            sc, label = mc.max(-1)
+            ii = torch.arange(n, device=self.device)
+        Ho, Wo = int(item.get("height", h)), int(item.get("width", w))
+        sel = order[ii].to(torch.int32).contiguous()                         # rows of lg, in output order
+        pm = ops.image_final_masks(lg, sel, cfg.match_stride, h, w, Ho, Wo).view(torch.bool)
+        # BitMasks(mask).get_bounding_boxes() of the final masks :554
+        xa, ya = pm.any(1), pm.any(2)
+        has = xa.any(1)
+        ar_x, ar_y = torch.arange(Wo, device=self.device), torch.arange(Ho, device=self.device)
+        x0 = torch.where(xa, ar_x, Wo).min(1)[0]; x1 = torch.where(xa, ar_x, -1).max(1)[0] + 1
+        y0 = torch.where(ya, ar_y, Ho).min(1)[0]; y1 = torch.where(ya, ar_y, -1).max(1)[0] + 1
+        boxes = torch.stack([x0, y0, x1, y1], 1).float() * has[:, None]
+        res = Instances((Ho, Wo))
+        res.scores, res.pred_classes, res.pred_masks, res.pred_boxes = sc, label, pm, Boxes(boxes)
+        return [{"instances": res}]
 
     def inference_video(self, image_size, cls_clips, windows, frame_hw, n_frames, early=None, emit_masks=True):
         """mdqe/mdqe.py:430-471.  The x4 aligned-bilinear up-sampling, sigmoid, crop (:357-358), nearest resize to the

@@ -354,3 +354,22 @@ def patch_merge_gather(x):
     out = torch.empty((B * ((H + 1) // 2) * ((W + 1) // 2), 4 * C), dtype=torch.float32, device=x.device)
     check(lib.mdqe_patch_merge_gather_f32(ptr(x), ptr(out), B, H, W, C, cur_stream()), "patch_merge_gather")
     return out
+
+
+def image_mask_stats(logits, factor, h, w):
+    """logits [n,Hm,Wm] -> [n,6] = (sum soft*hard, count hard, xmin, ymin, xmax, ymax of logit>0) over the x`factor` crop [:h,:w]."""
+    _chk(logits, "logits")
+    n, Hm, Wm = logits.shape
+    out = torch.empty(n, 6, device=logits.device)
+    check(lib.mdqe_image_mask_stats_f32(ptr(logits), n, Hm, Wm, factor, h, w, ptr(out), cur_stream()), "image_mask_stats")
+    return out
+
+
+def image_final_masks(logits, idx, factor, h, w, Ho, Wo):
+    """logits [n,Hm,Wm], idx int32 CUDA [k] -> uint8 [k,Ho,Wo]: bilinear resize of the cropped up-sampled logits, > 0."""
+    _chk(logits, "logits")
+    n, Hm, Wm = logits.shape
+    out = torch.empty(int(idx.numel()), Ho, Wo, dtype=torch.uint8, device=logits.device)
+    check(lib.mdqe_image_final_masks_u8(ptr(logits), int(idx.numel()), ptr(idx), Hm, Wm, factor, h, w, Ho, Wo, ptr(out), cur_stream()),
+          "image_final_masks")
+    return out

@@ -299,6 +299,44 @@ def gen_video():
     save("video_small", thr=THR, synth_seed=2, **arrs)
 
 
+def gen_coco_image():
+    """MDQE.forward on the COCO single-image branch (mdqe/mdqe.py:213-236 -> inference_image :486-556; decoder is_coco
+    branch transformer_dec.py:247-255): a 3-frame pseudo clip of 60x90 images, tiny pyramid backbone."""
+    top = refshim.ref("mdqe.mdqe")
+    g = torch.Generator().manual_seed(44)
+    refshim.BACKBONE_BUILDER["fn"] = lambda cfg: TinyPyramid()
+    arrs = {}
+    manifest = None
+    for tag, multi in (("multi", True), ("single", False)):
+        cfg = small_cfg(thr=THR)
+        cfg.DATASETS.TEST = ("coco_2017_val_fake",)
+        cfg.MODEL.MDQE.MULTI_CLS_ON = multi
+        model = top.MDQE(cfg).eval()
+        assert model.is_coco
+        manifest = apply_synth(model.detr, seed=4, prefix="detr.")
+        if tag == "multi":
+            base = torch.randint(0, 256, (3, 60, 90), generator=g, dtype=torch.uint8).float()
+            frames = [(0.9 * base + 0.1 * torch.randint(0, 256, (3, 60, 90), generator=g, dtype=torch.uint8).float()).round().to(torch.uint8)
+                      for _ in range(3)]
+            arrs["frames"] = torch.stack(frames)
+        log = {}
+        orig = model.inference_image
+
+        def wrapped(output, batched_inputs, images, log=log, orig=orig):
+            log["cls"], log["masks"] = output["cls"].clone(), output["masks"].clone()
+            return orig(output, batched_inputs, images)
+
+        model.inference_image = wrapped
+        with torch.no_grad():
+            res = model([{"image": frames, "height": 100, "width": 140}])[0]["instances"]
+        print("coco image", tag, ": instances", len(res.scores), "labels", res.pred_classes.tolist()[:8])
+        arrs.update({f"{tag}::cls": log["cls"], f"{tag}::masks": log["masks"], f"{tag}::scores": res.scores,
+                     f"{tag}::pred_classes": res.pred_classes, f"{tag}::pred_masks": res.pred_masks,
+                     f"{tag}::pred_boxes": res.pred_boxes.tensor})
+    arrs.update(manifest_to_arrays(manifest))
+    save("coco_image_small", thr=THR, synth_seed=4, **arrs)
+
+
 def gen_tracker():
     """Crafted clip sequence -> reference OverTracker (mdqe/tracking/OverTracker.py): persistent objects,
     one that appears late (new ID), one that disappears, and a duplicate detection."""
@@ -441,6 +479,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "msda_backward":
         gen_msda_backward()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "coco_image":
+        with torch.no_grad():
+            gen_coco_image()
+        sys.exit(0)
     with torch.no_grad():
         gen_msda()
         gen_msda_backward()
@@ -451,3 +493,4 @@ if __name__ == "__main__":
         gen_video()
         gen_tracker()
         gen_swin()
+        gen_coco_image()

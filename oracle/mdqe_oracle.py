@@ -767,6 +767,66 @@ def inference_video(hp: Hyper, out_size, cls_clips: List[Tensor], mask_clips: Li
 # --------------------------------------------------------------------------------------------
 # a1-a3, a19: driver (mdqe/mdqe.py:291-366, 473-484)
 # --------------------------------------------------------------------------------------------
+def mask_bounding_boxes(masks: Tensor) -> Tensor:
+    """detectron2 BitMasks.get_bounding_boxes (third-party, public algorithm; call sites mdqe/mdqe.py:526,554):
+    [x_min, y_min, x_max + 1, y_max + 1] of the non-zero pixels of each [H,W] mask, zeros for an empty mask."""
+    m = masks.to(torch.bool)
+    out = torch.zeros(m.shape[0], 4)
+    xa, ya = m.any(1), m.any(2)
+    for i in range(m.shape[0]):
+        x, y = torch.where(xa[i])[0], torch.where(ya[i])[0]
+        if len(x) and len(y):
+            out[i] = torch.tensor([float(x[0]), float(y[0]), float(x[-1] + 1), float(y[-1] + 1)])
+    return out
+
+
+def box_iou(a: Tensor, b: Tensor) -> Tensor:
+    """mdqe/util/box_ops.py:30-43 (union clamped at 1e-3)."""
+    area = lambda t: (t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    inter = (rb - lt).clamp(min=0).prod(-1)
+    return inter / (area(a)[:, None] + area(b)[None] - inter).clamp(min=1e-3)
+
+
+def inference_image(sd, hp: Hyper, frames: List[Tensor], backbone_fn, out_size=None, multi_cls=True):
+    """COCO single-image branch: MDQE.forward (mdqe/mdqe.py:213-236) -> mdqe.forward (models/mdqe.py:62-70) -> decoder
+    eval branch `is_coco` (transformer_dec.py:247-255) -> MDQE.inference_image (mdqe/mdqe.py:486-556).
+    frames: the pseudo clip (hp.n_frames images).  Returns dict(cls, masks, scores, pred_classes, pred_masks, pred_boxes)."""
+    video = preprocess(hp, frames)
+    images, sizes = pad_frames(video, hp.size_divisibility)
+    enc, mask, shapes, mf = frame_features(sd, hp, images, sizes, backbone_fn)        # mf [M,T,h,w]
+    out = transformer_dec(sd, hp, enc, mask, shapes)
+    cls = out["cls"][0]                                                                 # [Q,K] (sigmoid)
+    masks = torch.einsum("qm,mthw->qthw", out["mask_coeff"][0], mf)                    # [Q,T,h,w]
+    image_size = sizes[0]
+    ct = int((hp.n_frames - 1) / 2)
+    m = masks[:, ct]
+    score = cls.max(-1)[0]
+    idx = torch.nonzero(score >= min(hp.apply_cls_thres, float(score.max()))).reshape(-1)
+    mc, m = cls[idx], m[idx]
+    m = aligned_bilinear(m.unsqueeze(1), hp.match_stride).squeeze(1)[:, :image_size[0], :image_size[1]]
+    soft = m.sigmoid()
+    hard = soft > 0.5
+    mc = mc * ((soft.flatten(1) * hard.flatten(1)).sum(1) / (hard.flatten(1).sum(1) + 1e-6))[:, None]
+    if len(idx) > 0:                                                                    # box-IoU NMS, :519-531
+        order = mc.max(-1)[0].sort(descending=True)[1]
+        mc, m = mc[order], m[order]
+        norm = torch.tensor([image_size[1], image_size[0], image_size[1], image_size[0]], dtype=torch.float32).reshape(1, -1)
+        bx = mask_bounding_boxes(m.gt(0.)) / norm
+        mc = mc * (1 - torch.triu(box_iou(bx, bx), diagonal=1).max(0)[0])[:, None]
+    if multi_cls:
+        ls = torch.nonzero(mc > hp.apply_cls_thres)
+        ii, label = ls[:, 0], ls[:, 1]
+        score, m = mc[ii, label], m[ii]
+    else:
+        score, label = mc.max(-1)
+    oh, ow = out_size or image_size
+    pm = F.interpolate(m.float().unsqueeze(1), size=[oh, ow], mode="bilinear").squeeze(1) > 0.
+    return {"cls": cls, "masks": masks, "scores": score, "pred_classes": label, "pred_masks": pm,
+            "pred_boxes": mask_bounding_boxes(pm)}
+
+
 def preprocess(hp: Hyper, frames: List[Tensor]) -> List[Tensor]:
     mean = torch.tensor(hp.pixel_mean).view(3, 1, 1)
     std = torch.tensor(hp.pixel_std).view(3, 1, 1)

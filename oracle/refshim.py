@@ -138,11 +138,37 @@ def install():
 
     _mod("detectron2.modeling", META_ARCH_REGISTRY=META, build_backbone=build_backbone)
 
-    class _Dummy:
-        def __init__(self, *a, **k):
-            pass
+    class Boxes:
+        """detectron2.structures.Boxes stand-in: a [N,4] xyxy tensor holder."""
 
-    _mod("detectron2.structures", Instances=Instances, ImageList=ImageList, Boxes=_Dummy, BitMasks=_Dummy)
+        def __init__(self, tensor):
+            self.tensor = tensor
+
+        def to(self, device):
+            return Boxes(self.tensor.to(device))
+
+        def __len__(self):
+            return self.tensor.shape[0]
+
+    class BitMasks:
+        """detectron2.structures.BitMasks stand-in with the PUBLIC get_bounding_boxes algorithm (detectron2 v0.6,
+        structures/masks.py): tight box [x_min, y_min, x_max + 1, y_max + 1] of the non-zero pixels, zeros for empty masks."""
+
+        def __init__(self, tensor):
+            self.tensor = tensor.to(torch.bool)
+
+        def get_bounding_boxes(self):
+            boxes = torch.zeros(self.tensor.shape[0], 4, dtype=torch.float32)
+            x_any = torch.any(self.tensor, dim=1)
+            y_any = torch.any(self.tensor, dim=2)
+            for idx in range(self.tensor.shape[0]):
+                x = torch.where(x_any[idx, :])[0]
+                y = torch.where(y_any[idx, :])[0]
+                if len(x) > 0 and len(y) > 0:
+                    boxes[idx, :] = torch.as_tensor([x[0], y[0], x[-1] + 1, y[-1] + 1], dtype=torch.float32)
+            return Boxes(boxes)
+
+    _mod("detectron2.structures", Instances=Instances, ImageList=ImageList, Boxes=Boxes, BitMasks=BitMasks)
     _mod("detectron2.utils")
     _mod("detectron2.utils.memory", retry_if_cuda_oom=lambda f: f)
     _mod("detectron2.modeling.backbone", Backbone=nn.Module)

@@ -252,3 +252,21 @@ def test_swinv2_backbone():
         ref = fx.t(name)
         assert o.shape == ref.shape
         assert maxdiff(o, ref) < TOL
+
+
+@pytest.mark.parametrize("tag", ["multi", "single"])
+def test_coco_image_branch(tag):
+    """Oracle inference_image (COCO single-image branch, MULTI_CLS_ON on/off) vs the reference run of MDQE.forward."""
+    fx = Fixture("coco_image_small")
+    sd = fx.state()
+    hp = small_hyper(apply_cls_thres=fx.f("thr"), n_frames_test=3, n_frames_window_test=4, n_max_inst=40)
+    frames = list(fx.t("frames"))
+    with torch.no_grad():
+        got = O.inference_image(sd, hp, frames, tiny_pyramid(sd), out_size=(100, 140), multi_cls=(tag == "multi"))
+    assert maxdiff(got["cls"], fx.t(f"{tag}::cls")[0]) < 2e-5
+    assert maxdiff(got["masks"], fx.t(f"{tag}::masks")[0]) < 2e-4
+    assert got["pred_classes"].tolist() == fx.t(f"{tag}::pred_classes").tolist()
+    assert maxdiff(got["scores"], fx.t(f"{tag}::scores")) < 2e-5
+    ref_m = fx.t(f"{tag}::pred_masks")
+    assert got["pred_masks"].shape == ref_m.shape and float((got["pred_masks"] != ref_m).float().mean()) < 1e-4
+    assert maxdiff(got["pred_boxes"], fx.t(f"{tag}::pred_boxes")) <= 1.0

@@ -230,3 +230,26 @@ def test_swinl_ovis_runs_end_to_end():
     with torch.no_grad():
         res = model([{"image": frames, "height": 120, "width": 216}])
     assert len(res["pred_masks"]) == len(res["pred_scores"]) >= 10 and res["pred_masks"][0].shape == (3, 120, 216)
+
+
+@pytest.mark.parametrize("tag", ["multi", "single"])
+def test_coco_image_branch_vs_reference(tag):
+    """COCO single-image branch (MDQE.forward with a COCO test set -> inference_image) vs the reference run
+    (fixture coco_image_small: 3-frame pseudo clip, MULTI_CLS_ON on / off)."""
+    import dataclasses
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    fx = Fixture("coco_image_small")
+    sd = fx.state()
+    cfg = dataclasses.replace(small_cfg(apply_cls_thres=fx.f("thr"), n_frames_test=3, n_frames_window_test=4, n_max_inst=40),
+                              is_coco=True, multi_cls=(tag == "multi"))
+    model = MDQE(cfg, state_dict=sd, backbone_fn=tiny_pyramid_gpu(sd)).eval()
+    with torch.no_grad():
+        res = model([{"image": list(fx.t("frames")), "height": 100, "width": 140}])[0]["instances"]
+    assert res.pred_classes.tolist() == fx.t(f"{tag}::pred_classes").tolist()
+    assert maxdiff(res.scores.cpu(), fx.t(f"{tag}::scores")) < 1e-3
+    ref_m = fx.t(f"{tag}::pred_masks")
+    got_m = res.pred_masks.cpu()
+    assert got_m.dtype == torch.bool and got_m.shape == ref_m.shape
+    assert float((got_m != ref_m).float().mean()) < 1e-3
+    assert maxdiff(res.pred_boxes.tensor.cpu(), fx.t(f"{tag}::pred_boxes")) <= 2.0
+    assert res.image_size == (100, 140) and len(res) == len(ref_m)
