@@ -1,4 +1,4 @@
-// Multi-scale deformable attention sampling for gfx950 (MI355X), forward only.
+// Multi-scale deformable attention sampling for gfx950 (MI355X), forward (backward: msda_bwd.hip).
 //
 // Arithmetic follows the reference kernel (mdqe/models/ops/src/cuda/ms_deform_im2col_cuda.cuh
 // :33-84 bilinear, :237-299 main loop): pixel = loc*size - 0.5; a sample contributes only if
@@ -80,6 +80,103 @@ msda_fwd_kernel(const float* __restrict__ value, const int64_t* __restrict__ sha
   }
 }
 
+// ---- v2 (D == 32, L*P == 16): cooperative sample set-up (the scheme of msda_fused_v2_kernel) -------------------------
+// The 8 lanes that own the 32 channels of one (query, head) all need the same 16 sample descriptors; the kernel above
+// recomputes them in every lane (~60 VALU per sample) and is VALU-bound at 0.9 TB/s of compulsory traffic.  Here lane j of
+// the group prepares samples 2j and 2j+1 only -- location -> four corner byte offsets and four (bilinear x attention)
+// weights -- and publishes them in LDS; then every lane walks the 16 samples with two broadcast ds_read_b128 and four
+// bounds-checked buffer loads each (a corner outside the map carries an out-of-range offset and reads as 0: no branches).
+#define MSDA_OOB 0xF0000000u
+template <int L, int P>
+__global__ void __launch_bounds__(256)
+msda_fwd_v2_kernel(const float* __restrict__ value, unsigned value_bytes, const int64_t* __restrict__ shapes,
+                   const int64_t* __restrict__ level_start, const float* __restrict__ loc, const float* __restrict__ attn,
+                   int S, int M, int G, int Q, float scale, float* __restrict__ out, long total) {
+  constexpr int LP = L * P;                    // 16
+  constexpr int D = 32, DV = 8;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) unsigned soff[32][LP][4];     // [group in block][sample][corner byte offset]
+  __shared__ __attribute__((aligned(16))) float swgt[32][LP][4];        // [group in block][sample][corner weight]
+  __shared__ int sH[16], sW[16], sS[16];
+  if ((int)threadIdx.x < G * L) {
+    sH[threadIdx.x] = (int)shapes[threadIdx.x * 2]; sW[threadIdx.x] = (int)shapes[threadIdx.x * 2 + 1];
+    sS[threadIdx.x] = (int)level_start[threadIdx.x];
+  }
+  __syncthreads();
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
+  const int grp = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const long ldv = (long)M * D;
+  // XCD-aware block order: blocks p and p+8 share an XCD (round-robin dispatch).  The first 8*floor(B/8) batch elements are
+  // dealt one per XCD (element b entirely on XCD b mod 8: its value map, 5.2 MB at 360p, is fetched into ONE 4-MB L2 instead
+  // of all eight); the remainder -- and everything when B < 16 -- keeps the plain order so that no XCD idles.
+  const int per_b = Q * M * DV;                // lanes per batch element
+  const int nbq = (per_b + 255) / 256;         // blocks per batch element
+  const int Bn = (int)(total / per_b);
+  const int full = Bn >= 16 ? (Bn / 8) * 8 : 0;
+  int b, blk;
+  if ((int)blockIdx.x < full * nbq) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int fi = slot / nbq;
+    b = xcd + 8 * fi; blk = slot - fi * nbq;
+  } else {
+    const int r = (int)blockIdx.x - full * nbq;
+    b = full + r / nbq; blk = r - (r / nbq) * nbq;
+  }
+  {
+    const int within = blk * 256 + (int)threadIdx.x;
+    if (b >= Bn || within >= per_b) return;
+    long t = (long)b * Q + within / (M * DV);  // t = b*Q + q
+    const int m = (within / DV) % M;
+    const long samp = (t * M + m) * (long)LP;  // index of (b,q,m,0,0)
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(loc + (samp + 2 * j) * 2);       // (x,y) of samples 2j, 2j+1
+    const f32x2 a2 = *reinterpret_cast<const f32x2*>(attn + samp + 2 * j);
+    const unsigned lane_off = (unsigned)((m * D + j * 4) * 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = 2 * j + k;
+        const int l = i / P;
+        const float lx = l4[2 * k], ly = l4[2 * k + 1];
+        const float aw = a2[k];
+        const int H = sH[g * L + l], W = sW[g * L + l];
+        const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+        const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool h0 = in && h_low >= 0, h1 = in && h_low + 1 <= H - 1;
+        const bool w0 = w_low >= 0, w1 = w_low + 1 <= W - 1;
+        const long prow = (long)b * S + sS[g * L + l] + (long)h_low * W + w_low;       // pixel row of the (low, low) corner
+        const unsigned base = (unsigned)(prow * ldv * 4);
+        const unsigned dW = (unsigned)((long)W * ldv * 4), d1 = (unsigned)(ldv * 4);
+        u32x4 offv;
+        f32x4 wv;
+        offv[0] = (h0 && w0) ? base : MSDA_OOB;
+        offv[1] = (h0 && w1) ? base + d1 : MSDA_OOB;
+        offv[2] = (h1 && w0) ? base + dW : MSDA_OOB;
+        offv[3] = (h1 && w1) ? base + dW + d1 : MSDA_OOB;
+        wv[0] = hh * hw * aw; wv[1] = hh * lw * aw; wv[2] = lh * hw * aw; wv[3] = lh * lw * aw;
+        *reinterpret_cast<u32x4*>(&soff[grp][i][0]) = offv;
+        *reinterpret_cast<f32x4*>(&swgt[grp][i][0]) = wv;
+      }
+      __builtin_amdgcn_wave_barrier();         // the 8 lanes of a group sit in one wave: in-order LDS suffices
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const u32x4 offv = *reinterpret_cast<const u32x4*>(&soff[grp][i][0]);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&swgt[grp][i][0]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, offv[c] + lane_off, 0, 0));
+          acc += v * wv[c];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    *reinterpret_cast<f32x4*>(out + t * ldv + m * D + j * 4) = acc * scale;
+  }
+}
+
 template <int VEC>
 static int launch_msda(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc,
                        const float* attn, int B, int S, int M, int D, int G, int L, int Q, int P, float scale,
@@ -108,6 +205,17 @@ extern "C" int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* 
   hipStream_t st = (hipStream_t)stream;
   mdqe_clear_error();
   const bool al16 = (((uintptr_t)value | (uintptr_t)out) & 15) == 0;
+  const long vbytes = (long)B * S * M * D * 4;
+  if (D == 32 && L * P == 16 && (L == 4 || L == 2) && G * L <= 16 && al16 && vbytes > 0 && vbytes < 0xF0000000L &&
+      (((uintptr_t)loc | (uintptr_t)attn) & 15) == 0) {
+    const long total = (long)B * Q * M * 8;
+    const long nb = (long)B * (((long)Q * M * 8 + 255) / 256);                 // exact grid: blocks per batch element x B
+    if (L == 4) hipLaunchKernelGGL((msda_fwd_v2_kernel<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, value, (unsigned)vbytes, shapes,
+                                   level_start, loc, attn, S, M, G, Q, scale, out, total);
+    else hipLaunchKernelGGL((msda_fwd_v2_kernel<2, 8>), dim3((unsigned)nb), dim3(256), 0, st, value, (unsigned)vbytes, shapes,
+                            level_start, loc, attn, S, M, G, Q, scale, out, total);
+    return mdqe_launch_status();
+  }
   const bool al8 = (((uintptr_t)value | (uintptr_t)out) & 7) == 0;
   if (D % 4 == 0 && al16) return launch_msda<4>(value, shapes, level_start, loc, attn, B, S, M, D, G, L, Q, P, scale, out, st);
   if (D % 2 == 0 && al8) return launch_msda<2>(value, shapes, level_start, loc, attn, B, S, M, D, G, L, Q, P, scale, out, st);

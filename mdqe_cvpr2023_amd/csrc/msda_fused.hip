@@ -129,12 +129,28 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
   __syncthreads();
   const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
   const int grp = threadIdx.x >> 3, j = threadIdx.x & 7;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long t = idx / DV;
-    const int m = (int)(t % M);
-    t /= M;                                    // t = b*Q + q
-    const int b = (int)(t / Q);
-    const int q = (int)(t - (long)b * Q);
+  // XCD-aware block order: blocks p and p+8 share an XCD (round-robin dispatch).  The first 8*floor(B/8) batch elements are
+  // dealt one per XCD (element b entirely on XCD b mod 8: its value map, 5.2 MB at 360p, is fetched into ONE 4-MB L2 instead
+  // of all eight); the remainder -- and everything when B < 16 -- keeps the plain order so that no XCD idles.
+  const int per_b = Q * M * DV;                // lanes per batch element
+  const int nbq = (per_b + 255) / 256;         // blocks per batch element
+  const int Bn = B;
+  const int full = Bn >= 16 ? (Bn / 8) * 8 : 0;
+  int b, blk;
+  if ((int)blockIdx.x < full * nbq) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int fi = slot / nbq;
+    b = xcd + 8 * fi; blk = slot - fi * nbq;
+  } else {
+    const int r = (int)blockIdx.x - full * nbq;
+    b = full + r / nbq; blk = r - (r / nbq) * nbq;
+  }
+  {
+    const int within = blk * 256 + (int)threadIdx.x;
+    if (b >= B || within >= per_b) return;
+    const int q = within / (M * DV);
+    const int m = (within / DV) % M;
+    const long t = (long)b * Q + q;
     // ---- this lane's two samples: i0 = 2j, i1 = 2j+1
     const f32x4 o4 = *reinterpret_cast<const f32x4*>(offs + t * ldo + m * (2 * LP) + 4 * j);
     const f32x2 l2 = *reinterpret_cast<const f32x2*>(logits + t * ldl + m * LP + 2 * j);
@@ -229,7 +245,8 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
   // v2 (cooperative sample set-up, buffer loads): D == 32, 16 samples, value buffer addressable with 32-bit offsets
   const long vbytes = value_rows > 0 ? ((value_rows - 1) * ldv + (long)M * D) * 4 : 0;
   if (D == 32 && L * P == 16 && vbytes > 0 && vbytes < 0xF0000000L) {
-#define LAUNCH2(LL, PP) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP>), dim3((unsigned)nb), dim3(256), 0, st, value, (unsigned)vbytes, \
+    const long nb2 = (long)B * (((long)Q * M * 8 + 255) / 256);                // exact grid: blocks per batch element x B
+#define LAUNCH2(LL, PP) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP>), dim3((unsigned)nb2), dim3(256), 0, st, value, (unsigned)vbytes, \
       ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total)
     if (L == 4 && P == 4) { LAUNCH2(4, 4); return mdqe_launch_status(); }
     if (L == 2 && P == 8) { LAUNCH2(2, 8); return mdqe_launch_status(); }
