@@ -206,9 +206,10 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
 
     cur = start(0)
     for q in range(rounds):
-        local = [r for r in cur] if cur is not None else []        # decoder + clip inference of this rank's chunk
+        nxt = start(q + 1)                         # the next round's per-frame work goes to the frame stream first ...
+        local = [r for r in cur] if cur is not None else []        # ... and runs under this round's decoder + clip inference
         merged = all_gather_clips(local, T, dist, world, any_fr.device, proto, root=0 if root_only else None, rank=rank)
-        cur = start(q + 1)                         # next round's per-frame work is on the GPU before the replay starts
+        cur = nxt
         if replay is not None:
             replay.put(merged)                     # global clip order within the round: chunk q*world, q*world+1, ...
         elif merger is not None:
