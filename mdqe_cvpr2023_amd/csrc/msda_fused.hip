@@ -118,7 +118,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode,
                      const float* __restrict__ grid, MsdaLevels lv,
-                     int B, int M, int G, int Q, float scale, float* __restrict__ out, long ldout, long total) {
+                     int B, int M, int G, int Q, float scale, float* __restrict__ out, long ldout, long total, int xcd_order) {
   constexpr int LP = L * P;                    // 16
   constexpr int D = 32, DV = 8;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -135,7 +135,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
   const int per_b = Q * M * DV;                // lanes per batch element
   const int nbq = (per_b + 255) / 256;         // blocks per batch element
   const int Bn = B;
-  const int full = Bn >= 16 ? (Bn / 8) * 8 : 0;
+  const int full = (xcd_order && Bn >= 16) ? (Bn / 8) * 8 : 0;
   int b, blk;
   if ((int)blockIdx.x < full * nbq) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -221,6 +221,9 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
   }
 }
 
+static int g_msda_xcd_order = 1;   // tools/ A/B: 0 = plain block order in the fused kernel
+extern "C" int mdqe_debug_msda_xcd_order(int v) { g_msda_xcd_order = v; return MDQE_OK; }
+
 extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* vidx, const float* offs, long ldo,
                                    const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
                                    int mode, const float* grid, const int* lvH_host, const int* lvW_host,
@@ -247,7 +250,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
   if (D == 32 && L * P == 16 && vbytes > 0 && vbytes < 0xF0000000L) {
     const long nb2 = (long)B * (((long)Q * M * 8 + 255) / 256);                // exact grid: blocks per batch element x B
 #define LAUNCH2(LL, PP) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP>), dim3((unsigned)nb2), dim3(256), 0, st, value, (unsigned)vbytes, \
-      ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total)
+      ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total, g_msda_xcd_order)
     if (L == 4 && P == 4) { LAUNCH2(4, 4); return mdqe_launch_status(); }
     if (L == 2 && P == 8) { LAUNCH2(2, 8); return mdqe_launch_status(); }
 #undef LAUNCH2
