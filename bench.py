@@ -169,6 +169,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=120, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--init", choices=["workload", "reference"], default="workload",
+                    help="workload (default): synthetic weights tuned so that several instances per clip survive (DESIGN.md §5); "
+                         "reference: the reference's own initialisation, untouched (zero-init trap in place: one instance per clip)")
     ap.add_argument("--stages", action="store_true", help="print a per-stage time breakdown (extra untimed step)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
                     help="GEMM arithmetic of the headline number: exact fp32 MFMA (default) or split-precision f16x3")
@@ -205,9 +208,9 @@ def main():
 
     cfg = PRESETS[args.config]
     fh, fw = {"R50_ovis_360": (360, 640), "R50_ovis_720": (640, 1138), "swinl_ovis": (480, 853)}[args.config]
-    sd = random_state(cfg, seed=0)
+    sd = random_state(cfg, seed=0, remove_zero_init_trap=(args.init == "workload"))
     model = MDQE(cfg, state_dict=sd).eval()
-    bias_shift = calibrate_synthetic_scores(model, sd, cfg, fh, fw)
+    bias_shift = calibrate_synthetic_scores(model, sd, cfg, fh, fw) if args.init == "workload" else 0.0
     meter = GemmMeter()
     meter.install()
 
@@ -297,7 +300,7 @@ def main():
                                    % (args.config, args.frames, fh, fw, cfg.n_frames_test, cfg.n_frames_window_test),
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
                        "instances_out": len(out["pred_scores"]), "tracked_instances": len(set(m.data_ptr() for m in out["pred_masks"])),
-                       "cls_bias_shift": round(bias_shift, 3),
+                       "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
                        "parallelism": "1 process/GPU; 30-frame chunks dealt round-robin, per-round RCCL gather of the clip results "
                                       "to rank 0, whose tracker replay runs on a worker thread under the next round" if world > 1 else "single GPU"},
