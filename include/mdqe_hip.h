@@ -200,6 +200,13 @@ int mdqe_final_masks_u8(const float* logits, int n_sel, const int* inst_idx_dev,
                         int h, int w, int Ho, int Wo, unsigned char* out, long out_inst_stride, int f_off,
                         void* stream);
 
+/* Same masks, straight to COCO run-length form (the result writer's mask_util.encode, mdqe/data/ytvis_eval.py:307-312 ->
+ * cocoapi rleEncode): pos[(k*Fw+f)*cap + i] = i-th column-major pixel index at which mask (k,f) changes value (the value
+ * before the first pixel is 0), n_pos[k*Fw+f] = number of changes (may exceed cap: only the first cap are stored).
+ * Run lengths are the differences of consecutive positions; the dense mask is never written. */
+int mdqe_final_masks_rle(const float* logits, int n_sel, const int* inst_idx_dev, int Fw, int Hm, int Wm, int factor,
+                         int h, int w, int Ho, int Wo, int cap, int* pos, int* n_pos, void* stream);
+
 /* ---- COCO single-image branch, after the decoder (MDQE.inference_image, mdqe/mdqe.py:486-556), on the centre frame's
  * low-resolution logits [n,Hm,Wm]; aligned_bilinear x`factor` in closed form, crop [:h,:w].
  * stats[k] = {sum(sigmoid*[sigmoid>0.5]), count(sigmoid>0.5), xmin, ymin, xmax, ymax of (logit > 0)} (:512-516, :526;

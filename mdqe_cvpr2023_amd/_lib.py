@@ -22,6 +22,7 @@ SIGNATURES = {
     "mdqe_sample_levels_mean_f32": [p, i, l, i, p, i, p, p, p, i, p, p],
     "mdqe_image_mask_stats_f32": [p, i, i, i, i, i, i, p, p],
     "mdqe_image_final_masks_u8": [p, i, p, i, i, i, i, i, i, i, p, p],
+    "mdqe_final_masks_rle": [p, i, p, i, i, i, i, i, i, i, i, i, p, p, p],
     "mdqe_final_masks_u8": [p, i, p, i, i, i, i, i, i, i, i, p, l, i, p],
     "mdqe_set_gemm_precision": [i],
     "mdqe_layernorm_post_f32": [p, p, p, p, p, l, i, f, p],

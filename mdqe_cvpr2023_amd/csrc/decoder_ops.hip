@@ -308,6 +308,21 @@ extern "C" int mdqe_sample_levels_mean_f32(const float* tokens, int NI, long N, 
 // aligned_bilinear (util/misc.py:485-507) in closed form: pixel p reads source (max(p - f/2, 0))/f, clamped to the map.
 // logits [n, F, Hm, Wm] (mean logits of one tracker window); out uint8 [n, F_total, Ho, Wo] written at frame f_off.
 // ------------------------------------------------------------------------------------------------
+// one output pixel of the final mask (shared by the dense and the RLE form: identical arithmetic, identical bits)
+__device__ __forceinline__ int final_mask_pixel(const float* __restrict__ m, int Hm, int Wm, int factor, int h, int w, float sy_scale,
+                                                float sx_scale, int Y, int X) {
+  const int sy = min((int)floorf(Y * sy_scale), h - 1), sx = min((int)floorf(X * sx_scale), w - 1);
+  const float fy = (float)max(sy - factor / 2, 0) / (float)factor, fx = (float)max(sx - factor / 2, 0) / (float)factor;
+  const int y0 = min((int)fy, Hm - 1), x0 = min((int)fx, Wm - 1);
+  const int y1 = min(y0 + 1, Hm - 1), x1 = min(x0 + 1, Wm - 1);
+  const float ly = fy - y0, lx = fx - x0;
+  const float top = m[y0 * Wm + x0] * (1.f - lx) + m[y0 * Wm + x1] * lx;
+  const float bot = m[y1 * Wm + x0] * (1.f - lx) + m[y1 * Wm + x1] * lx;
+  const float v = top * (1.f - ly) + bot * ly;
+  const float p = 1.0f / (1.0f + expf(-v));
+  return p > 0.5f ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(256)
 final_mask_kernel(const float* __restrict__ lg, int Fw, int Hm, int Wm, int factor, int h, int w, int Ho, int Wo,
                   unsigned char* __restrict__ out, long out_inst_stride, int f_off, const int* __restrict__ inst_idx, long total) {
@@ -316,18 +331,66 @@ final_mask_kernel(const float* __restrict__ lg, int Fw, int Hm, int Wm, int fact
     const int X = (int)(i % Wo); long t = i / Wo;
     const int Y = (int)(t % Ho); t /= Ho;
     const int f = (int)(t % Fw); const int k = (int)(t / Fw);
-    const int sy = min((int)floorf(Y * sy_scale), h - 1), sx = min((int)floorf(X * sx_scale), w - 1);
-    const float fy = (float)max(sy - factor / 2, 0) / (float)factor, fx = (float)max(sx - factor / 2, 0) / (float)factor;
-    const int y0 = min((int)fy, Hm - 1), x0 = min((int)fx, Wm - 1);
-    const int y1 = min(y0 + 1, Hm - 1), x1 = min(x0 + 1, Wm - 1);
-    const float ly = fy - y0, lx = fx - x0;
     const float* m = lg + ((long)inst_idx[k] * Fw + f) * Hm * Wm;
-    const float top = m[y0 * Wm + x0] * (1.f - lx) + m[y0 * Wm + x1] * lx;
-    const float bot = m[y1 * Wm + x0] * (1.f - lx) + m[y1 * Wm + x1] * lx;
-    const float v = top * (1.f - ly) + bot * ly;
-    const float p = 1.0f / (1.0f + expf(-v));
-    out[(long)k * out_inst_stride + ((long)(f_off + f) * Ho + Y) * Wo + X] = p > 0.5f ? 1 : 0;
+    out[(long)k * out_inst_stride + ((long)(f_off + f) * Ho + Y) * Wo + X] = (unsigned char)final_mask_pixel(m, Hm, Wm, factor, h, w, sy_scale, sx_scale, Y, X);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final masks straight to COCO run-length form (the result writer's
+// mask_util.encode(np.array(mask[:, :, None], order="F")), mdqe/data/ytvis_eval.py:307-312, i.e. cocoapi rleEncode): the
+// mask of (instance k, frame f) is never materialised -- one block walks its pixels in COLUMN-major order, every thread a
+// contiguous segment, evaluating final_mask_pixel on the fly, and emits the positions p where the value differs from
+// p-1 (value before the first pixel = 0).  Runs are the differences of consecutive positions (host).  Two sweeps: count
+// per thread -> block scan -> write.  pos [n_sel*Fw, cap], n_pos [n_sel*Fw] (may exceed cap: the host then falls back).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+final_mask_rle_kernel(const float* __restrict__ lg, int Fw, int Hm, int Wm, int factor, int h, int w, int Ho, int Wo,
+                      const int* __restrict__ inst_idx, int cap, int* __restrict__ pos, int* __restrict__ n_pos) {
+  const int k = blockIdx.x / Fw, f = blockIdx.x - k * Fw;
+  const float* m = lg + ((long)inst_idx[k] * Fw + f) * Hm * Wm;
+  const float sy_scale = (float)h / (float)Ho, sx_scale = (float)w / (float)Wo;
+  const int total = Ho * Wo;
+  const int seg = (total + 255) / 256;
+  const int p0 = min((int)threadIdx.x * seg, total), p1 = min(p0 + seg, total);
+  int prev0 = 0;
+  if (p0 > 0 && p0 < total) prev0 = final_mask_pixel(m, Hm, Wm, factor, h, w, sy_scale, sx_scale, (p0 - 1) % Ho, (p0 - 1) / Ho);
+  int cnt = 0, prev = prev0;
+  for (int p = p0; p < p1; ++p) {
+    const int v = final_mask_pixel(m, Hm, Wm, factor, h, w, sy_scale, sx_scale, p % Ho, p / Ho);
+    cnt += (v != prev);
+    prev = v;
+  }
+  __shared__ int sc[256];
+  sc[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {                  // inclusive scan
+    const int add = (int)threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int off = sc[threadIdx.x] - cnt;
+  if (threadIdx.x == 255) n_pos[blockIdx.x] = sc[255];
+  int* out = pos + (long)blockIdx.x * cap;
+  prev = prev0;
+  for (int p = p0; p < p1; ++p) {
+    const int v = final_mask_pixel(m, Hm, Wm, factor, h, w, sy_scale, sx_scale, p % Ho, p / Ho);
+    if (v != prev) { if (off < cap) out[off] = p; ++off; }
+    prev = v;
+  }
+}
+
+extern "C" int mdqe_final_masks_rle(const float* logits, int n_sel, const int* inst_idx_dev, int Fw, int Hm, int Wm, int factor,
+                                    int h, int w, int Ho, int Wo, int cap, int* pos, int* n_pos, void* stream) {
+  MDQE_REQUIRE(n_sel >= 0 && Fw >= 0 && Hm > 0 && Wm > 0 && factor >= 1 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && cap > 0);
+  MDQE_REQUIRE(h <= Hm * factor && w <= Wm * factor && (long)Ho * Wo < 0x7FFFFFFFL);
+  if (n_sel == 0 || Fw == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(logits); MDQE_CHECK_PTR(inst_idx_dev); MDQE_CHECK_PTR(pos); MDQE_CHECK_PTR(n_pos);
+  mdqe_clear_error();
+  hipLaunchKernelGGL(final_mask_rle_kernel, dim3((unsigned)(n_sel * Fw)), dim3(256), 0, (hipStream_t)stream, logits, Fw, Hm, Wm, factor,
+                     h, w, Ho, Wo, inst_idx_dev, cap, pos, n_pos);
+  return mdqe_launch_status();
 }
 
 extern "C" int mdqe_final_masks_u8(const float* logits, int n_sel, const int* inst_idx_dev, int Fw, int Hm, int Wm, int factor,

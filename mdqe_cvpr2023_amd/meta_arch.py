@@ -55,6 +55,7 @@ class MDQE(nn.Module):
         self._trk_stream = None
         self._frame_stream = None
         self._copy_stream = None
+        self.rle_output = False                     # True: forward() returns per-frame COCO RLEs ("pred_rles") instead of dense masks
         self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.stage_times = None
 
@@ -327,6 +328,19 @@ class MDQE(nn.Module):
         Ho, Wo = int(image_size[0]), int(image_size[1])
         if not emit_masks:
             return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels, "pred_masks": []}
+        if early is not None and self.rle_output:
+            from . import rle as R
+            empty = {"size": [Ho, Wo], "counts": R.counts_to_strings([Ho * Wo], [1])[0].decode("utf-8")}
+            per_inst = {i: [dict(empty) for _ in range(n_frames)] for i in sel}     # before an instance's first window: empty masks (:442)
+            for f_off, nf, n_w, pos, n_pos in early["rle"]:
+                counts, lengths = R.positions_to_counts(pos, n_pos, Ho * Wo)
+                strs = R.counts_to_strings(counts, lengths)
+                for i in sel:
+                    if i < n_w:
+                        for f in range(nf):
+                            per_inst[i][f_off + f] = {"size": [Ho, Wo], "counts": strs[i * nf + f].decode("utf-8")}
+            return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels,
+                    "pred_rles": [per_inst[i] for i in inst]}
         if early is not None:
             early["done"].synchronize()
             hosts = early["host"]                                  # per instance: [n_frames, Ho, Wo] uint8, pinned
@@ -340,6 +354,10 @@ class MDQE(nn.Module):
                 ops.final_masks(m, sel_dev[:cnt], self.cfg.match_stride, frame_hw[0], frame_hw[1], Ho, Wo, out, f_off)
         host = out.cpu().view(torch.bool)
         pos = {i: p for p, i in enumerate(sel)}
+        if self.rle_output:                                        # no early path (CPU device / unknown length): encode on the host
+            from . import rle as R
+            enc = {i: [R.encode_dense(fm.numpy()) for fm in host[pos[i]]] for i in sel}
+            return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels, "pred_rles": [enc[i] for i in inst]}
         return {"image_size": (Ho, Wo), "pred_scores": sc.tolist(), "pred_labels": labels,
                 "pred_masks": [host[pos[i]] for i in inst]}
 
@@ -411,7 +429,20 @@ class ClipMerger:
             model._copy_stream = torch.cuda.Stream(self.dev)
         cs = model._copy_stream
         if self.early is None:
-            self.early = {"host": [], "windows": [], "done": torch.cuda.Event()}
+            self.early = {"host": [], "windows": [], "done": torch.cuda.Event(), "rle": []}
+        if model.rle_output:                        # run boundaries instead of dense masks: KBs instead of MBs per window
+            if n:
+                idx = torch.arange(n, dtype=torch.int32, device=self.dev)
+                cap = 4 * (Ho + Wo) + 64                # a blob crosses a column twice: generous for anything mask-like
+                while True:
+                    pos, n_pos = ops.final_masks_rle(m, idx, model.cfg.match_stride, self.frame_hw[0], self.frame_hw[1], Ho, Wo, cap)
+                    mx = int(n_pos.max())               # (sync on the tracker stream; the window's logits are final here)
+                    if mx <= cap:
+                        break
+                    cap = mx
+                self.early["rle"].append((self.f_off, nf, n, pos[:, :max(mx, 1)].cpu().numpy(), n_pos.cpu().numpy()))
+            self.early["windows"].append((self.f_off, nf, n))
+            return
         hosts = self.early["host"]
         while len(hosts) < n:                       # a new track: its own pinned [L, Ho, Wo] buffer, zero before its first window (:442)
             hbuf = torch.empty(self.n_frames, Ho, Wo, dtype=torch.uint8, pin_memory=True)

@@ -373,3 +373,16 @@ def image_final_masks(logits, idx, factor, h, w, Ho, Wo):
     check(lib.mdqe_image_final_masks_u8(ptr(logits), int(idx.numel()), ptr(idx), Hm, Wm, factor, h, w, Ho, Wo, ptr(out), cur_stream()),
           "image_final_masks")
     return out
+
+
+def final_masks_rle(logits, inst_idx, factor, h, w, Ho, Wo, cap):
+    """logits [n,Fw,Hm,Wm]; inst_idx int32 CUDA [n_sel] -> (pos int32 [n_sel*Fw, cap], n_pos int32 [n_sel*Fw]): column-major
+    positions at which each final mask changes value (ops.final_masks never materialised)."""
+    _chk(logits, "logits")
+    n, Fw, Hm, Wm = logits.shape
+    k = int(inst_idx.numel())
+    pos = torch.empty(k * Fw, cap, dtype=torch.int32, device=logits.device)
+    n_pos = torch.empty(k * Fw, dtype=torch.int32, device=logits.device)
+    check(lib.mdqe_final_masks_rle(ptr(logits), k, ptr(inst_idx), Fw, Hm, Wm, factor, h, w, Ho, Wo, cap, ptr(pos), ptr(n_pos),
+                                   cur_stream()), "final_masks_rle")
+    return pos, n_pos

@@ -107,3 +107,32 @@ def test_const_weight_registry():
     ptr = w.data_ptr()
     del w
     assert ptr not in ops._split or ops._split[ptr][0]() is None  # a dead entry is dropped on its next lookup
+
+
+def test_rle_output_equals_encoding_of_the_dense_masks():
+    """model.rle_output: run boundaries from the device (the dense masks are never written) -> the same COCO RLE strings as
+    encoding the dense output on the host (oracle restatement of cocoapi rleEncode/rleToString), and they decode back to
+    the dense masks; the drop-in result writer produces the reference's record layout."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import rle_oracle as RO
+    from mdqe_cvpr2023_amd import rle as R
+    cfg, model = _small_model()
+    frames = _video(14).cuda()
+    inp = [{"image": frames, "height": 90, "width": 150, "video_id": 7, "length": 14}]
+    dense = model(inp)
+    model.rle_output = True
+    out = model(inp)
+    model.rle_output = False
+    assert "pred_masks" not in out and out["pred_labels"] == dense["pred_labels"] and out["pred_scores"] == dense["pred_scores"]
+    assert len(out["pred_rles"]) == len(dense["pred_masks"]) > 0
+    for rl, dm in zip(out["pred_rles"], dense["pred_masks"]):
+        assert len(rl) == dm.shape[0] == 14
+        for f in range(14):
+            ref = RO.encode(dm[f].numpy())
+            assert rl[f]["size"] == ref["size"] == [90, 150]
+            assert rl[f]["counts"].encode() == ref["counts"]
+            assert (RO.rle_decode(RO.rle_from_string(rl[f]["counts"].encode()), 90, 150) == dm[f].numpy()).all()
+    recs = R.instances_to_coco_json_video(inp, out)
+    recs_dense = R.instances_to_coco_json_video(inp, dense)
+    assert recs == recs_dense and recs[0]["video_id"] == 7 and set(recs[0]) == {"video_id", "score", "category_id", "segmentations"}
