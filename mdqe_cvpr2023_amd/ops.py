@@ -37,8 +37,16 @@ def const_weight(w):
         return w
     planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=w.device)
     check(lib.mdqe_f16x3_split_f32(ptr(w), w.numel(), ptr(planes), cur_stream()), "f16x3_split")
-    _split[w.data_ptr()] = (weakref.ref(w), w._version, planes)
+    key = w.data_ptr()
+    _split[key] = (weakref.ref(w), w._version, planes)
+    weakref.finalize(w, _drop_split, key)               # the planes go when the weight tensor goes
     return w
+
+
+def _drop_split(key):
+    ent = _split.get(key)
+    if ent is not None and ent[0]() is None:            # (a newer tensor may have been registered at the same address)
+        del _split[key]
 
 
 def _wsplit(w):
