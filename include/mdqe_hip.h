@@ -128,6 +128,14 @@ int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, con
                          int act, const float* residual, long ldr, int res_first, int tile, const void* w_split,
                          void* stream);
 
+/* ---- eval-time frame resize (ResizeShortestEdgeClip -> ResizeTransform -> PIL Image.resize(BILINEAR) on uint8 frames,
+ * mdqe/data/augmentation.py:364-389, dataset_mapper.py:252-258), Pillow's two-pass fixed-point resampling bit for bit.
+ * in: NI images [C,H,W] u8, in_img_stride bytes apart; out [NI,C,oh,ow] u8.  Coefficient tables (DEVICE int32), built on the
+ * host: per output column X taps xmin[X] .. xmin[X]+xcnt[X]-1 with 22-bit weights xk[X*kxs + t]; same for rows. */
+int mdqe_resize_pil_bilinear_u8(const unsigned char* in, long in_img_stride, int NI, int C, int H, int W, int oh, int ow,
+                                const int* xmin, const int* xcnt, const int* xk, int kxs, const int* ymin, const int* ycnt,
+                                const int* yk, int kys, unsigned char* out, void* stream);
+
 /* ---- LayerNorm over the last dim: y = LN(x + res) * gamma + beta (res may be NULL) -----------------
  * nn.LayerNorm call sites transformer_enc.py:103-108,136; transformer_dec.py:345-358,394-408,466,492. */
 int mdqe_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,

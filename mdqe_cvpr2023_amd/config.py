@@ -45,7 +45,8 @@ class MDQEConfig:
     size_divisibility: int = 32
     pixel_mean: Tuple[float, ...] = (123.675, 116.280, 103.530)
     pixel_std: Tuple[float, ...] = (58.395, 57.120, 57.375)
-    min_size_test: int = 360
+    min_size_test: int = 360                  # INPUT.MIN_SIZE_TEST
+    max_size_test: int = 1333                 # INPUT.MAX_SIZE_TEST (detectron2 default; the configs do not set it)
     is_coco: bool = False                     # DATASETS.TEST[0].startswith("coco") (mdqe/mdqe.py:70): single-image branch
     multi_cls: bool = True                    # MODEL.MDQE.MULTI_CLS_ON (mdqe/mdqe.py:187)
     device: str = "cuda"
@@ -96,4 +97,5 @@ def from_d2_cfg(cfg) -> MDQEConfig:
         detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE, match_stride=m.MATCH_STRIDE,
         merge_on_cpu=m.MERGE_ON_CPU, pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(cfg.MODEL.PIXEL_STD),
         is_coco=str(cfg.DATASETS.TEST[0]).startswith("coco") if len(getattr(cfg.DATASETS, "TEST", ())) else False,
-        multi_cls=bool(getattr(m, "MULTI_CLS_ON", True)), device=str(cfg.MODEL.DEVICE))
+        multi_cls=bool(getattr(m, "MULTI_CLS_ON", True)), min_size_test=int(getattr(cfg.INPUT, "MIN_SIZE_TEST", 360)),
+        max_size_test=int(getattr(cfg.INPUT, "MAX_SIZE_TEST", 1333)), device=str(cfg.MODEL.DEVICE))

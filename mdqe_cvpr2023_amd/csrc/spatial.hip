@@ -183,3 +183,57 @@ extern "C" int mdqe_dwconv5x5_nhwc_f32(const float* x, const float* wt, const fl
                      tw, tb);
   return mdqe_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Eval-time frame resize on the device: ResizeShortestEdgeClip -> ResizeTransform -> for uint8 frames
+// PIL Image.resize(BILINEAR) (mdqe/data/augmentation.py:364-389, mdqe/data/dataset_mapper.py:252-258).  Pillow's separable
+// resampling, bit for bit: horizontal pass first, each pass = sum of uint8 taps x 22-bit fixed-point coefficients starting at
+// 1 << 21, >> 22, clipped to uint8; the coefficient tables (triangle filter stretched by max(scale, 1), normalised in double
+// precision, quantised) are built on the host.  One thread per output value; the horizontal pass is evaluated on the fly for
+// the few source rows a vertical tap window needs (no intermediate image).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+resize_pil_bilinear_kernel(const unsigned char* __restrict__ in, long in_img_stride, int C, int H, int W, int oh, int ow,
+                           const int* __restrict__ xmin, const int* __restrict__ xcnt, const int* __restrict__ xk, int kxs,
+                           const int* __restrict__ ymin, const int* __restrict__ ycnt, const int* __restrict__ yk, int kys,
+                           unsigned char* __restrict__ out, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % ow); long t = i / ow;
+    const int Y = (int)(t % oh); t /= oh;
+    const int c = (int)(t % C); const long img = t / C;
+    const unsigned char* src = in + img * in_img_stride + (long)c * H * W;
+    const int x0 = xmin[X], nx = xcnt[X], y0 = ymin[Y], ny = ycnt[Y];
+    const int* kx = xk + (long)X * kxs;
+    const int* ky = yk + (long)Y * kys;
+    int acc = 1 << 21;
+    for (int ty = 0; ty < ny; ++ty) {
+      const unsigned char* row = src + (long)(y0 + ty) * W + x0;
+      int hv;
+      if (ow == W) {
+        hv = row[X - x0];                            // no horizontal pass when the width is unchanged (Pillow skips it)
+      } else {
+        int hs = 1 << 21;
+        for (int tx = 0; tx < nx; ++tx) hs += (int)row[tx] * kx[tx];
+        hv = min(max(hs >> 22, 0), 255);
+      }
+      if (oh == H) { acc = hv; break; }              // no vertical pass when the height is unchanged
+      acc += hv * ky[ty];
+    }
+    out[i] = (unsigned char)(oh == H ? acc : min(max(acc >> 22, 0), 255));
+  }
+}
+
+extern "C" int mdqe_resize_pil_bilinear_u8(const unsigned char* in, long in_img_stride, int NI, int C, int H, int W, int oh, int ow,
+                                           const int* xmin, const int* xcnt, const int* xk, int kxs, const int* ymin,
+                                           const int* ycnt, const int* yk, int kys, unsigned char* out, void* stream) {
+  MDQE_REQUIRE(NI >= 0 && C > 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && kxs > 0 && kys > 0);
+  if (NI == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(in); MDQE_CHECK_PTR(out); MDQE_CHECK_PTR(xmin); MDQE_CHECK_PTR(xcnt); MDQE_CHECK_PTR(xk);
+  MDQE_CHECK_PTR(ymin); MDQE_CHECK_PTR(ycnt); MDQE_CHECK_PTR(yk);
+  mdqe_clear_error();
+  const long total = (long)NI * C * oh * ow;
+  long nb = (total + 255) / 256; if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(resize_pil_bilinear_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, in_img_stride, C, H, W, oh,
+                     ow, xmin, xcnt, xk, kxs, ymin, ycnt, yk, kys, out, total);
+  return mdqe_launch_status();
+}

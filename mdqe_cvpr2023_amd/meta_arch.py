@@ -55,6 +55,7 @@ class MDQE(nn.Module):
         self._trk_stream = None
         self._frame_stream = None
         self._copy_stream = None
+        self.resize_on_device = False               # True: frames arrive at native size and get the mapper's ResizeShortestEdge here
         self.rle_output = False                     # True: forward() returns per-frame COCO RLEs ("pred_rles") instead of dense masks
         self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.stage_times = None
@@ -242,8 +243,12 @@ class MDQE(nn.Module):
         cfg = self.cfg
         video = batched_inputs[0]
         frames_dev = self.to_device_frames(video["image"])
+        h0, w0 = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
+        if self.resize_on_device and frames_dev.dtype == torch.uint8:       # the mapper's eval augmentation, on the device
+            from .preprocess import resize_shortest_edge
+            frames_dev = resize_shortest_edge(frames_dev, cfg.min_size_test, cfg.max_size_test)
         L, h, w = frames_dev.shape[0], int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
-        out_size = (video.get("height", h), video.get("width", w))
+        out_size = (video.get("height", h0), video.get("width", w0))       # the mapper reports the ORIGINAL size as height/width
         geo = self.engine.geometry(h, w)
         ms = cfg.match_stride
         clips = self.clip_schedule(L, cfg.n_frames_test, cfg.clip_stride)

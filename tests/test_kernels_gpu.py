@@ -348,3 +348,19 @@ def test_window_attention_mfma_vs_fp64_and_scalar_form(N, nh, nW, shifted):
     for o in outs:
         assert float((o.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert float((outs[0] - outs[1]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(72, 128, 36, 64), (75, 133, 36, 64), (50, 80, 100, 160), (97, 61, 33, 20), (40, 40, 40, 57),
+                                   (123, 77, 123, 30), (720, 1280, 360, 640), (480, 853, 360, 640)])
+def test_device_resize_is_bit_identical_to_the_pillow_restatement(shape):
+    """preprocess.resize_frames (HIP) vs oracle/resize_oracle.py, which tests/test_resize_cpu.py pins to PIL bit for bit."""
+    import numpy as np
+    import resize_oracle as RO
+    from mdqe_cvpr2023_amd import preprocess as P
+    h, w, oh, ow = shape
+    rng = np.random.RandomState(h + w)
+    imgs = rng.randint(0, 256, (2, h, w, 3)).astype(np.uint8)
+    dev = torch.from_numpy(imgs).permute(0, 3, 1, 2).contiguous().cuda()
+    got = P.resize_frames(dev, oh, ow).cpu().permute(0, 2, 3, 1).numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], RO.resize_bilinear_u8(imgs[i], oh, ow)), (shape, i)

@@ -138,3 +138,22 @@ def test_rle_output_equals_encoding_of_the_dense_masks():
     recs = R.instances_to_coco_json_video(inp, out)
     recs_dense = R.instances_to_coco_json_video(inp, dense)
     assert recs == recs_dense and recs[0]["video_id"] == 7 and set(recs[0]) == {"video_id", "score", "category_id", "segmentations"}
+
+
+def test_resize_on_device_equals_resizing_on_the_host_first():
+    """model.resize_on_device: native-size frames in, the mapper's ResizeShortestEdge applied on the GPU == feeding frames the
+    oracle (== Pillow) resized on the host; height/width default to the ORIGINAL size like the mapper's dataset dict."""
+    import dataclasses
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import resize_oracle as RO
+    cfg, model = _small_model()
+    model.cfg = cfg = dataclasses.replace(cfg, min_size_test=48, max_size_test=100)
+    big = _video(9, h=120, w=200)                                       # -> 48 x 80
+    small = torch.stack([torch.from_numpy(RO.resize_bilinear_u8(f.permute(1, 2, 0).numpy(), 48, 80)).permute(2, 0, 1) for f in big])
+    ref = model([{"image": small.cuda(), "height": 120, "width": 200}])
+    model.resize_on_device = True
+    got = model([{"image": big.cuda()}])
+    model.resize_on_device = False
+    _same(got, ref)
+    assert got["image_size"] == (120, 200)
