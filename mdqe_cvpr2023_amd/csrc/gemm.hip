@@ -303,11 +303,15 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   p.stamps = g_gemm_stamps;
   p.vec_ok = ((((uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.residual) & 15) == 0) && (p.ldc % 4 == 0) &&
              (p.residual == nullptr || p.ldr % 4 == 0);
-  // tile: 0 = auto
+  // tile: 0 = auto.  Measured on the K-step-16 kernel (tools/tile_sweep*.py): the 128x128 tile only pays when the grid is
+  // many times the 1024 resident blocks AND the tile has depth or width to amortise (N >= 1024 or K >= 1024); mid-size
+  // problems -- the decoder's 21168-row GEMMs, res4/res5 3x3 convs -- run 15-30 % faster on 64x64 tiles (8 waves/SIMD).
   if (tile == 0) {
     const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
-    else if (b128 >= 192) tile = 1;
+    if (g_gemm_precision == 1 && p.Wh != nullptr && b128 >= 192 && p.N > 64) tile = 1;      // f16x3w has its own tiling
+    else if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
+    else if (b128 >= 2000 && (p.N >= 1024 || p.K >= 1024)) tile = 1;
+    else if (b128 >= 2000) tile = 2;
     else tile = 3;
   }
   if (tile == 1 && g_gemm_precision == 1 && p.Wh != nullptr && p.K % 32 == 0 && p.N >= 128 && p.N % 4 == 0 &&
@@ -329,8 +333,8 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
     return mdqe_launch_status();
   }
-  // K-step 16 (4 blocks per CU) wins wherever prologue/epilogue weigh (K <= ~1024); deep-K convs keep the 32-wide step
-  if (g_gemm_variant == 1 || (g_gemm_variant == 2 && !(p.conv && p.K >= 2048))) {
+  // K-step 16 (4+ blocks per CU) wins almost everywhere; very deep-K convs on few rows keep the 32-wide step
+  if (g_gemm_variant == 1 || (g_gemm_variant == 2 && !(p.conv && p.K >= 2048 && p.M <= 16384))) {
     int rc = mdqe_launch_gemm_k16(p, tile, st);
     if (rc || p.ksplit <= 1) return rc;
     long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
