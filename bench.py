@@ -58,7 +58,7 @@ class GemmMeter:
                 return rc
 
             def mdqe_conv2d_nhwc_f32(self_, *a):
-                NI, H, W, Cin, Cout, KH, KW, stride, pad, tile = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[19]
+                NI, H, W, Cin, Cout, KH, KW, stride, pad, tile = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[19]   # (include/mdqe_hip.h)
                 M = NI * ((H + 2 * pad - KH) // stride + 1) * ((W + 2 * pad - KW) // stride + 1)
                 big = (tile == 1) or (tile == 0 and Cout > 64 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 192)
                 if not (meter.enabled and big):

@@ -121,12 +121,13 @@ int mdqe_debug_mha_variant(int v);   /* same for the 196-token decoder self-atte
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
  * X [NI,H,W,Cin] (Cin % 32 == 0; images x_img_stride floats apart, <=0: dense), Wt [Cout,KH,KW,Cin], Y [NI*OH*OW, ldy] ; zero padding; fused bias,
- * activation and residual (ResNet bottlenecks -- detectron2 build_resnet_backbone, call site
+ * activation and residual; ksplit > 1: deterministic split-K as in mdqe_gemm_nt_f32 (workspace >= ksplit*NI*OH*OW*Cout floats)
+ * (ResNet bottlenecks -- detectron2 build_resnet_backbone, call site
  * mdqe/mdqe.py:27,33; input_proj 3x3 s2 models/mdqe.py:40-43; MaskHead 3x3 segmentation.py:42-57). */
 int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                          int NI, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                          int act, const float* residual, long ldr, int res_first, int tile, const void* w_split,
-                         void* stream);
+                         int ksplit, float* splitk_ws, void* stream);
 
 /* ---- eval-time frame resize (ResizeShortestEdgeClip -> ResizeTransform -> PIL Image.resize(BILINEAR) on uint8 frames,
  * mdqe/data/augmentation.py:364-389, dataset_mapper.py:252-258), Pillow's two-pass fixed-point resampling bit for bit.

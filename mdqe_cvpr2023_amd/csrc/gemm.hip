@@ -378,7 +378,7 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
 extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                                     int NI, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                     int act, const float* residual, long ldr, int res_first, int tile, const void* w_split,
-                                    void* stream) {
+                                    int ksplit, float* splitk_ws, void* stream) {
   MDQE_REQUIRE(NI >= 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MDQE_REQUIRE(Cin % 32 == 0);
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
@@ -396,7 +396,13 @@ extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const flo
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.res_mod = 0; p.res_first = res_first; p.img_stride = x_img_stride; p.rowmask = nullptr; p.mask_cols = 0;
   p.act = act; p.act_cols = 0; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
   p.ksplit = 1; p.kchunk = p.K; p.ws = nullptr;
-  if (w_split != nullptr) { p.Wh = w_split; p.Wl = (const char*)w_split + (long)Cout * p.K * 2; }
+  if (ksplit > 1) {                                  // deep-K conv on few output pixels: spread K over the CUs (chunks of whole taps x 32)
+    MDQE_CHECK_PTR(splitk_ws);
+    int kc = (p.K + ksplit - 1) / ksplit; kc = (kc + 31) / 32 * 32;
+    const int ks = (p.K + kc - 1) / kc;
+    if (ks > 1) { p.ksplit = ks; p.kchunk = kc; p.ws = splitk_ws; }
+  }
+  if (w_split != nullptr && p.ksplit <= 1) { p.Wh = w_split; p.Wl = (const char*)w_split + (long)Cout * p.K * 2; }
   mdqe_clear_error();
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }

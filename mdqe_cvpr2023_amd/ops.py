@@ -120,7 +120,7 @@ def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=Non
     return out
 
 
-def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None, out=None, tile=0, res_first=False):
+def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None, out=None, tile=0, res_first=False, ksplit=0):
     """x [NI,H,W,Cin] (dense, or a view whose images are x.stride(0) apart with dense pixels);
     w_packed [Cout,KH,KW,Cin]; returns [NI,OH,OW,Cout]."""
     _chk(w_packed, "w"); _chk(bias, "bias"); _chk(residual, "residual")
@@ -135,8 +135,15 @@ def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None
         out = torch.empty((NI, OH, OW, Cout), dtype=torch.float32, device=x.device)
     ldy = out.stride(-2)
     ldr = residual.stride(-2) if residual is not None else 0
+    M, K = NI * OH * OW, KH * KW * Cin
+    ws = None
+    if ksplit == 0 and K >= 4096 and ((M + 63) // 64) * ((Cout + 63) // 64) <= 256:
+        ksplit = min(16, K // 1024)                     # few output pixels, very deep K (input_proj's 3x3/s2 on res5)
+    if ksplit > 1:
+        ws = _workspace(ksplit * M * Cout * 4 + 64, x.device)
     check(lib.mdqe_conv2d_nhwc_f32(ptr(x), xis, ptr(w_packed), ptr(bias), ptr(out), ldy, NI, H, W, Cin, Cout, KH, KW, stride,
-                                   pad, ACT[act], ptr(residual), ldr, int(res_first), tile, ptr(_wsplit(w_packed)), cur_stream()),
+                                   pad, ACT[act], ptr(residual), ldr, int(res_first), tile, ptr(_wsplit(w_packed)), ksplit, ptr(ws),
+                                   cur_stream()),
           "conv2d_nhwc_f32")
     return out
 

@@ -364,3 +364,21 @@ def test_device_resize_is_bit_identical_to_the_pillow_restatement(shape):
     got = P.resize_frames(dev, oh, ow).cpu().permute(0, 2, 3, 1).numpy()
     for i in range(2):
         assert np.array_equal(got[i], RO.resize_bilinear_u8(imgs[i], oh, ow)), (shape, i)
+
+
+def test_conv_splitk_deep_k_few_pixels():
+    """input_proj's 3x3 / stride-2 conv on res5 (K = 18432, a few thousand output pixels): split-K spreads it over the CUs;
+    same result as the single-pass kernel (fixed summation order per chunk) and as fp64 within fp32 noise."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(13)
+    xi = torch.randn(6, 2048, 12, 20, generator=g); wc = torch.randn(256, 2048, 3, 3, generator=g) / 136; bc = torch.randn(256, generator=g)
+    ref = F.conv2d(xi.double(), wc.double(), bc.double(), 2, 1)
+    x, w = xi.permute(0, 2, 3, 1).contiguous().cuda(), wc.permute(0, 2, 3, 1).contiguous().cuda()
+    a = ops.conv2d_nhwc(x, w, bc.cuda(), 2, 1, ksplit=1).cpu().permute(0, 3, 1, 2).double()
+    b = ops.conv2d_nhwc(x, w, bc.cuda(), 2, 1).cpu().permute(0, 3, 1, 2).double()          # auto: split-K
+    c = ops.conv2d_nhwc(x, w, bc.cuda(), 2, 1, act="relu", ksplit=5).cpu().permute(0, 3, 1, 2).double()
+    s = float(ref.abs().max())
+    tol = 1e-5 * s                                     # an fp32 chain of 18432 terms
+    assert float((a - ref).abs().max()) < tol and float((b - ref).abs().max()) < tol
+    assert float((c - F.relu(ref)).abs().max()) < tol
+    assert float((a - b).abs().max()) < tol
