@@ -62,8 +62,8 @@ def all_gather_clips(local, T, dist, world, device, proto_shapes, root=None, ran
     sizes = torch.tensor([len(local), nmax], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
-    cmax = int(max(int(s[0]) for s in all_sizes))
-    gmax = int(max(int(s[1]) for s in all_sizes))
+    cmax = max(1, int(max(int(s[0]) for s in all_sizes)))     # never hand RCCL a zero-size buffer
+    gmax = max(1, int(max(int(s[1]) for s in all_sizes)))
     mine = root is None or rank == root
 
     def exchange(buf):
