@@ -155,6 +155,14 @@ int mdqe_groupnorm_nhwc_f32(const float* x, long ldx, long x_img_stride, float* 
 int mdqe_stem_im2col_f32(const void* frames, int is_u8, long frame_stride, int NI, int h, int w, int Hp, int Wp,
                          const float* mean3_host, const float* std3_host, float* out, void* stream);
 
+/* ---- the same stem as ONE kernel: normalise + zero pad + 7x7/s2/p3 conv (3->64) + bias (folded FrozenBN) + ReLU, frames ->
+ * NHWC activation [NI, Hp/2, Wp/2, 64]; no im2col buffer (mdqe/mdqe.py:473-484,318 + detectron2 BasicStem used by
+ * mdqe/models/backbone.py).  wk: DEVICE float[154*64], k-major with k = kh*22 + kw*3 + c and entry kh*22+21 zero;
+ * bias: DEVICE float[64]; mean/std HOST float[3]. */
+int mdqe_stem_conv_f32(const void* frames, int is_u8, long frame_stride, int NI, int h, int w, int Hp, int Wp,
+                       const float* mean3_host, const float* std3_host, const float* wk, const float* bias, float* out,
+                       void* stream);
+
 /* ---- 3x3/s2/p1 max pool NHWC (ResNet stem) */
 int mdqe_maxpool3x3s2_nhwc_f32(const float* x, float* y, int NI, int H, int W, int C, void* stream);
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mdqe_groupnorm_nhwc_f32": [p, l, l, p, l, l, i, i, i, i, p, p, f, i, p, p],
     "mdqe_resize_pil_bilinear_u8": [p, l, i, i, i, i, i, i, p, p, p, i, p, p, p, i, p, p],
     "mdqe_stem_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],
+    "mdqe_stem_conv_f32": [p, i, l, i, i, i, i, i, p, p, p, p, p, p],
     "mdqe_maxpool3x3s2_nhwc_f32": [p, p, i, i, i, i, p],
     "mdqe_upsample_nearest_add_nhwc_f32": [p, p, p, i, i, i, i, i, i, p],
     "mdqe_dwconv5x5_nhwc_f32": [p, p, p, p, i, i, i, i, i, p, p, p],

@@ -16,6 +16,7 @@ runs in libmdqe_hip.so (ops.*); `torch.*` calls below act on <=196-row index/sco
 device-side torch math still to be replaced by HIP kernels (tracked in DESIGN.md).
 """
 import math
+import os
 from types import SimpleNamespace as NS
 
 import numpy as np
@@ -35,6 +36,9 @@ def _fold_bn(sd, p, eps=1e-5):
     scale = sd[p + ".norm.weight"] * (sd[p + ".norm.running_var"] + eps).rsqrt()
     shift = sd[p + ".norm.bias"] - sd[p + ".norm.running_mean"] * scale
     return sd[p + ".weight"] * scale.view(-1, 1, 1, 1), shift
+
+
+STEM_FUSED = os.environ.get("MDQE_STEM_FUSED", "1") != "0"      # 0: im2col + GEMM (debug / A-B)
 
 
 def _krsc(w):
@@ -94,6 +98,7 @@ class Packed:
             wp = torch.zeros(64, 160)
             wp[:, :147] = _krsc(w).reshape(64, 147)
             bb.stem_w, bb.stem_b = up(wp), up(b)
+            bb.stem_wk = up(ops.stem_weight_kmajor(_krsc(w)))
             bb.stages = []
             for si, nb in enumerate(RESNET_BLOCKS[cfg.backbone]):
                 blocks = []
@@ -354,9 +359,12 @@ class Engine:
             return self.backbone_swin(frames, geo)
         bb, cfg = self.P.bb, self.cfg
         NI = frames.shape[0]
-        col = ops.stem_im2col(frames, geo.Hp, geo.Wp, cfg.pixel_mean, cfg.pixel_std)
-        x = ops.linear(col, bb.stem_w, bb.stem_b, act="relu").view(NI, geo.Hp // 2, geo.Wp // 2, 64)
-        del col
+        if STEM_FUSED:
+            x = ops.stem_conv(frames, geo.Hp, geo.Wp, cfg.pixel_mean, cfg.pixel_std, bb.stem_wk, bb.stem_b)
+        else:
+            col = ops.stem_im2col(frames, geo.Hp, geo.Wp, cfg.pixel_mean, cfg.pixel_std)
+            x = ops.linear(col, bb.stem_w, bb.stem_b, act="relu").view(NI, geo.Hp // 2, geo.Wp // 2, 64)
+            del col
         x = ops.maxpool3x3s2(x)
         outs = []
         for si, blocks in enumerate(bb.stages):

@@ -189,6 +189,30 @@ def stem_im2col(frames, Hp, Wp, mean, std):
     return out
 
 
+def stem_weight_kmajor(w_krsc):
+    """[64,7,7,3] (BN-folded, k = (kh,kw,c)) -> the [154,64] k-major layout of mdqe_stem_conv_f32 (row kh*22+21 zero)."""
+    wk = torch.zeros(7, 22, 64, dtype=torch.float32)
+    wk[:, :21] = w_krsc.reshape(64, 7, 21).permute(1, 2, 0)
+    return wk.reshape(154, 64).contiguous()
+
+
+def stem_conv(frames, Hp, Wp, mean, std, wk, bias):
+    """frames [NI,3,h,w] uint8 or fp32 CUDA -> relu(conv7x7/s2(pad(normalise(frames))) + bias) as NHWC [NI,Hp/2,Wp/2,64]."""
+    import ctypes
+    if not frames.is_cuda or not frames.is_contiguous() or frames.dtype not in (torch.uint8, torch.float32):
+        raise RuntimeError("stem_conv: frames must be contiguous CUDA uint8/float32 [NI,3,h,w]")
+    _chk(wk, "wk"); _chk(bias, "bias")
+    if tuple(wk.shape) != (154, 64) or bias.numel() != 64:
+        raise RuntimeError("stem_conv: wk must be [154,64] (stem_weight_kmajor) and bias [64]")
+    NI, _, h, w = frames.shape
+    out = torch.empty((NI, Hp // 2, Wp // 2, 64), dtype=torch.float32, device=frames.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(lib.mdqe_stem_conv_f32(ptr(frames), int(frames.dtype == torch.uint8), 3 * h * w, NI, h, w, Hp, Wp, m, s, ptr(wk),
+                                 ptr(bias), ptr(out), cur_stream()), "stem_conv")
+    return out
+
+
 def maxpool3x3s2(x):
     _chk(x, "x")
     NI, H, W, C = x.shape

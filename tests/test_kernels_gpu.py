@@ -115,6 +115,19 @@ def test_stem_maxpool_upsample_dw():
         wp = torch.zeros(64, 160); wp[:, :147] = w.permute(0, 2, 3, 1).reshape(64, 147)
         out = ops.linear(col, wp.cuda()).view(2, 32, 48, 64).cpu().permute(0, 3, 1, 2)
         assert rel(out, ref) < 2e-5
+        # the fused stem (no im2col buffer): same conv + bias + ReLU in one kernel
+        b = torch.randn(64, generator=g)
+        wk = ops.stem_weight_kmajor(w.permute(0, 2, 3, 1).contiguous())
+        out = ops.stem_conv(fr.cuda(), 64, 96, mean, std, wk.cuda(), b.cuda()).cpu().permute(0, 3, 1, 2)
+        assert rel(out, F.relu(ref + b.view(1, 64, 1, 1))) < 2e-5
+    # fused stem: ragged tiles (output 36 x 44 is not a multiple of the 8 x 16 tile), more tiles than one block walks
+    fr = torch.randint(0, 256, (3, 3, 70, 85), generator=g).to(torch.uint8)
+    xn = (fr.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    xp = torch.zeros(3, 3, 72, 88); xp[:, :, :70, :85] = xn
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12; b = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(xp, w, b, 2, 3))
+    out = ops.stem_conv(fr.cuda(), 72, 88, mean, std, ops.stem_weight_kmajor(w.permute(0, 2, 3, 1).contiguous()).cuda(), b.cuda())
+    assert rel(out.cpu().permute(0, 3, 1, 2), ref) < 2e-5
     x = torch.randn(2, 64, 31, 48, generator=g)
     out = ops.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().cuda()).cpu().permute(0, 3, 1, 2)
     assert torch.equal(out, F.max_pool2d(x, 3, 2, 1))
