@@ -88,7 +88,8 @@ int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* v
  * (transformer_dec.py:350,399), input_proj 1x1 (models/mdqe.py:34-37), dynamic mask product
  * (mdqe/mdqe.py:384).  K % 4 == 0, lda % 4 == 0, A/W 16-B aligned.  act applies to columns
  * < act_cols (<=0: all); rowmask (u8, 1 = zero the row) applies to columns < mask_cols
- * (the masked_fill of ms_deform_attn.py:137-138).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64.
+ * (the masked_fill of ms_deform_attn.py:137-138).  tile: 0 auto, 1 128x128, 2 128x64, 3 64x64
+ * (4 64x256 and 5 128x256 -- whole 256-wide rows per block -- are measured alternatives, not picked by auto).
  * ksplit > 1: K is cut into ksplit chunks over blockIdx.y, partial tiles go to splitk_ws (>= ksplit*M*N floats)
  * and a second pass sums them in fixed order and applies the epilogue (deterministic; for skinny large-K products). */
 int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,

@@ -311,8 +311,8 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     if (g_gemm_precision == 1 && p.Wh != nullptr && b128 >= 192 && p.N > 64) tile = 1;      // f16x3w has its own tiling
     else if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
     else if (b128 >= 2000 && (p.N >= 1024 || p.K >= 1024)) tile = 1;
-    else if (b128 >= 2000) tile = 2;
-    else tile = 3;
+    else if (b128 >= 2000 && (p.N > 256 || p.K > 256)) tile = 2;
+    else tile = 3;                                   // incl. the encoder's [204000,256]x[256,256] (64x64: 288 vs 329 us)
   }
   if (tile == 1 && g_gemm_precision == 1 && p.Wh != nullptr && p.K % 32 == 0 && p.N >= 128 && p.N % 4 == 0 &&
       p.vec_ok && p.ksplit <= 1) {

@@ -12,7 +12,7 @@
 #include <type_traits>
 
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ void __launch_bounds__(64 * WM * WN, (BM * BN >= 128 * 128) ? 4 : 4)
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN > 4) ? 2 : 4)
 gemm_nt_f32_k16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int BK = 16;
@@ -235,6 +235,8 @@ int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
     case 1: return p.conv ? launch_k16_<128, 128, 2, 2, true>(p, st) : launch_k16_<128, 128, 2, 2, false>(p, st);
     case 2: return p.conv ? launch_k16_<128, 64, 2, 2, true>(p, st) : launch_k16_<128, 64, 2, 2, false>(p, st);
     case 3: return p.conv ? launch_k16_<64, 64, 2, 2, true>(p, st) : launch_k16_<64, 64, 2, 2, false>(p, st);
+    case 4: return p.conv ? MDQE_EINVAL : launch_k16_<64, 256, 1, 4, false>(p, st);      // full 256-wide rows per block
+    case 5: return p.conv ? MDQE_EINVAL : launch_k16_<128, 256, 2, 4, false>(p, st);
     default: return MDQE_EINVAL;
   }
 }
