@@ -39,6 +39,7 @@ class GemmMeter:
         import ctypes
         raw = _lib.load_library().mdqe_gemm_nt_f32
         raw_conv = _lib.load_library().mdqe_conv2d_nhwc_f32
+        raw_ln = _lib.load_library().mdqe_gemm_ln_f32
         meter = self
 
         class Wrapped:
@@ -53,6 +54,17 @@ class GemmMeter:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = raw(*a)
+                e1.record()
+                meter.rec.append((e0, e1, 2.0 * M * N * K))
+                return rc
+
+            def mdqe_gemm_ln_f32(self_, *a):                  # same kernel template, LayerNorm epilogue (64x256 tile)
+                M, N, K = a[6], a[7], a[8]
+                if not (meter.enabled and ((M + 127) // 128) * ((N + 127) // 128) >= 192):
+                    return raw_ln(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = raw_ln(*a)
                 e1.record()
                 meter.rec.append((e0, e1, 2.0 * M * N * K))
                 return rc

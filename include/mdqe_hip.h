@@ -97,6 +97,12 @@ int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias
                      int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
                      float* splitk_ws, const void* w_split, void* stream);
 
+/* Linear + residual + LayerNorm in one kernel, for the encoder / decoder pattern  x = norm(x + dropout(linear(..)))
+ * (transformer_enc.py:100-110, transformer_dec.py:352-358,404-409; nn.LayerNorm over d_model = 256):
+ * C = LN(A W^T + bias + residual) * gamma + beta, N must be 256; C may alias the residual.  Exact fp32 MFMA. */
+int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
+                     const float* residual, long ldr, const float* gamma, const float* beta, float eps, void* stream);
+
 /* GEMM arithmetic of the 128x128 tile (process-wide): 0 = exact fp32 MFMA (default), 1 = "f16x3": operands split
  * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752). */
 int mdqe_set_gemm_precision(int mode);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "mdqe_mask_row_stats_f32": [p, i, i, i, i, i, p, p, p, p],
     "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p, i, p, p],
     "mdqe_layernorm_f32": [p, p, p, p, p, l, i, f, p],
+    "mdqe_gemm_ln_f32": [p, l, p, p, p, l, i, i, i, p, l, p, p, f, p],
     "mdqe_groupnorm_nhwc_f32": [p, l, l, p, l, l, i, i, i, i, p, p, f, i, p, p],
     "mdqe_resize_pil_bilinear_u8": [p, l, i, i, i, i, i, i, p, p, p, i, p, p, p, i, p, p],
     "mdqe_stem_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],

@@ -349,6 +349,28 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   }
 }
 
+// C = LayerNorm(A W^T + bias + residual) * gamma + beta over N == 256 columns, ONE kernel (64x256 tile: the block owns whole
+// rows, statistics in the epilogue).  Always exact fp32 MFMA.  C may alias the residual.
+extern "C" int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N,
+                                int K, const float* residual, long ldr, const float* gamma, const float* beta, float eps,
+                                void* stream) {
+  MDQE_REQUIRE(M >= 0 && N == 256 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N && ldc % 4 == 0);
+  if (M == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta);
+  MDQE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)gamma |
+                 (uintptr_t)beta) & 15) == 0);
+  MDQE_REQUIRE(residual == nullptr || (ldr >= N && ldr % 4 == 0));
+  const long ab = ((long)(M - 1) * lda + K) * 4, wb = (long)N * K * 4;
+  MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  GemmParams p = {};
+  p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
+  p.bias = bias; p.residual = residual; p.ldr = ldr; p.act = MDQE_ACT_NONE;
+  p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.ksplit = 1; p.kchunk = K; p.vec_ok = 1;
+  p.ln_g = gamma; p.ln_b = beta; p.ln_eps = eps;
+  mdqe_clear_error();
+  return mdqe_launch_gemm_k16(p, 6, (hipStream_t)stream);
+}
+
 extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                                 int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
                                 int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,

@@ -11,7 +11,7 @@
 #include "gemm_params.h"
 #include <type_traits>
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN > 4) ? 2 : 4)
 gemm_nt_f32_k16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
@@ -150,6 +150,94 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][s], b1[j][s], acc[i][j], 0, 0, 0);
   }
 
+  if constexpr (LN) {
+    // ---- LayerNorm epilogue (BN == N: the block owns whole rows): y = LN(acc + bias + residual) * gamma + beta.
+    // Sub-tiles are restaged as below (a lane gets 4 consecutive columns of 4 rows per sub-tile) but stay in registers;
+    // row sums go across the 8 lanes of a row, then across the WN waves through LDS; two passes (mean, then centred
+    // squares) as in layernorm_kernel.  C may alias the residual: a wave only rewrites the elements it read.
+    static_assert(!LN || (WM == 1 && BN == 256), "LN epilogue: one wave row, 256 columns");
+    __syncthreads();
+    float* sC = lds + wave * 1024;
+    float* red1 = lds + NW * 1024;
+    float* red2 = red1 + NW * BM;
+    f32x4 vv[MT][NT][4];
+    float rs[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) rs[i][it] = 0.f;
+    const int c4 = lane & 7, rsub = lane >> 3;
+    auto stage = [&](auto i_, auto j_) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[i][j][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int n = wn * 64 + j * 32 + c4 * 4;
+      const f32x4 bv = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rsub;
+        int m = m0 + i * 32 + row; if (m > p.M - 1) m = p.M - 1;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * 32 + c4 * 4) + bv;
+        if (p.residual != nullptr) v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
+        vv[i][j][it] = v;
+        rs[i][it] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    stage(I0{}, I0{}); stage(I0{}, I1{}); stage(I1{}, I0{}); stage(I1{}, I1{});
+    float mean[MT][4], rstd[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float x = rs[i][it];
+        x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4);
+        if (c4 == 0) red1[wave * BM + i * 32 + it * 8 + rsub] = x;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = i * 32 + it * 8 + rsub;
+        mean[i][it] = ((red1[row] + red1[BM + row]) + (red1[2 * BM + row] + red1[3 * BM + row])) * (1.f / 256.f);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f32x4 d = vv[i][j][it] - mean[i][it];
+          q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+        if (c4 == 0) red2[wave * BM + row] = q;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = i * 32 + it * 8 + rsub;
+        rstd[i][it] = rsqrtf(((red2[row] + red2[BM + row]) + (red2[2 * BM + row] + red2[3 * BM + row])) * (1.f / 256.f) + p.ln_eps);
+      }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = wn * 64 + j * 32 + c4 * 4;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_g + n);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + n);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + i * 32 + it * 8 + rsub;
+          if (m < p.M) *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
+        }
+    }
+    return;
+  }
+
   // ---- epilogue: per-wave restage of one 32x32 sub-tile at a time through the wave's own 4-KB LDS slice ----------------
   // acc[i][j][r] is C(row = (r&3) + 8*(r>>2) + 4*lh, col = lr) of the sub-tile; after the restage a lane owns 4 consecutive
   // columns of a row and 8 lanes cover one 128-B line of C.
@@ -219,12 +307,12 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   if constexpr (MT > 1 && NT > 1) sub(I1{}, I1{});
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
 static int launch_k16_(const GemmParams& p, hipStream_t st) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   size_t smem = 2 * (BM + BN) * 16 * sizeof(float);
   if (smem < (size_t)WM * WN * 4096) smem = (size_t)WM * WN * 4096;        // per-wave epilogue slices
-  auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV>;
+  auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV, LN>;
   hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(64 * WM * WN), smem, st, p);
   return mdqe_launch_status();
 }
@@ -237,6 +325,9 @@ int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
     case 3: return p.conv ? launch_k16_<64, 64, 2, 2, true>(p, st) : launch_k16_<64, 64, 2, 2, false>(p, st);
     case 4: return p.conv ? MDQE_EINVAL : launch_k16_<64, 256, 1, 4, false>(p, st);      // full 256-wide rows per block
     case 5: return p.conv ? MDQE_EINVAL : launch_k16_<128, 256, 2, 4, false>(p, st);
+    case 6:                                             // 64x256 with the LayerNorm epilogue (mdqe_gemm_ln_f32)
+      if (p.conv || p.N != 256 || p.ksplit > 1 || !p.vec_ok || p.ln_g == nullptr || p.ln_b == nullptr) return MDQE_EINVAL;
+      return launch_k16_<64, 256, 1, 4, false, true>(p, st);
     default: return MDQE_EINVAL;
   }
 }

@@ -20,6 +20,7 @@ struct GemmParams {
   float* ws;                // [ksplit][M][N] partial sums (deterministic two-pass reduction)
   unsigned long long* stamps;   // debug: per-block s_memtime stamps (mdqe_debug_gemm_stamps), null in production
   const void* Wh; const void* Wl;   // pre-split f16 planes of W ([N][K] each; gemm_f16x3w.hip) or null
+  const float* ln_g; const float* ln_b; float ln_eps;   // tile 6: LayerNorm over the 256 columns in the epilogue
 };
 
 #define OOB_OFF 0xFFFFFFF0u

@@ -453,11 +453,9 @@ class Engine:
             ops.linear(x2, lyr.wcat, lyr.bcat, residual=geo.pos_tables[li], res_mod=N, rowmask=rowmask, mask_cols=C, out=proj)
             ops.msda_fused(proj[:, :C], proj[:, C:C + 2 * nh * LP], proj[:, C + 2 * nh * LP:], geo.ref, levels, NI, N, nh, D,
                            cfg.n_levels, cfg.enc_points, mode=0, v_brows=N, out=attn)
-            ops.linear(attn, lyr.wo, lyr.bo, residual=x2, out=y)
-            ops.layernorm(y, *lyr.n1, out=x2)
+            ops.linear_ln(attn, lyr.wo, lyr.bo, x2, *lyr.n1, out=x2, scratch=y)     # norm1(x + out_proj(..))
             ops.linear(x2, lyr.w1, lyr.b1, act="gelu", out=hid)
-            ops.linear(hid, lyr.w2, lyr.b2, residual=x2, out=y)
-            ops.layernorm(y, *lyr.n2, out=x2)
+            ops.linear_ln(hid, lyr.w2, lyr.b2, x2, *lyr.n2, out=x2, scratch=y)       # norm2(x + linear2(..))
         return ops.layernorm(x2, *P.enc_norm).view(NI, N, C)
 
     # ---- a10: mask-feature head -------------------------------------------------------------------
@@ -582,12 +580,12 @@ class Engine:
             a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * LP], pr[:, 2 * nh * LP:], boxes.view(BT, Q, 4), lv_sp,
                                BT, Q, nh, D, cfg.n_levels, cfg.dec_points, mode=1, grid=P.grid_sp, v_brows=N, vidx=vidx_sp)
             vi += 1
-            x = ops.layernorm(ops.linear(a, L.ca.wo, L.ca.bo, residual=x), *L.norm2)
+            x = ops.linear_ln(a, L.ca.wo, L.ca.bo, x, *L.norm2)
             sx = x
             o, sa = self._mha(L.sa, (x + x_pos).view(BT, Q, C), x.view(BT, Q, C), nh)
-            x = ops.layernorm(ops.linear(o, sa.wo, sa.bo, residual=x), *L.norm1)
+            x = ops.linear_ln(o, sa.wo, sa.bo, x, *L.norm1)
             hdn = ops.linear(x, *L.linear1, act="gelu")
-            x = ops.layernorm(ops.linear(hdn, *L.linear2, residual=x), *L.norm3)
+            x = ops.linear_ln(hdn, *L.linear2, x, *L.norm3)
             # ---- instance level (transformer_dec.py:361-409)
             tw = ops.linear(x, *L.time_weights).view(Bc, T, Q, 1)
             fused = (torch.softmax(tw, 1) * sx.view(Bc, T, Q, C)).sum(1).reshape(Bc * Q, C)

@@ -3,6 +3,8 @@
 All tensors are CUDA fp32 contiguous unless stated; images are NHWC.  Nothing here falls back to
 torch arithmetic: a missing library or an unsupported shape raises.
 """
+import os
+
 import torch
 
 from ._lib import check, cur_stream, lib, ptr
@@ -146,6 +148,27 @@ def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None
                                    cur_stream()),
           "conv2d_nhwc_f32")
     return out
+
+
+LINEAR_LN_FUSED = os.environ.get("MDQE_LINEAR_LN_FUSED", "1") != "0"     # 0: GEMM then LayerNorm kernel (debug / A-B)
+
+
+def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratch=None):
+    """out = LayerNorm(x @ weight^T + bias + residual) * gamma + beta over N == 256 columns; `out` may be `residual`.
+    One kernel (64x256 tile, statistics in the epilogue) in exact-fp32 mode with enough rows to fill the chip; otherwise
+    the GEMM (own tile / f16x3 arithmetic) into `scratch` followed by the LayerNorm kernel."""
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if LINEAR_LN_FUSED and N == 256 and M >= 16384 and get_gemm_precision() == "f32" and x.stride(1) == 1:
+        _chk(weight, "weight"); _chk(bias, "bias"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(residual, "residual"); _chk(out, "out")
+        check(lib.mdqe_gemm_ln_f32(ptr(x), x.stride(0) if M > 1 else K, ptr(weight), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                                   ptr(residual), residual.stride(0) if residual is not None else 0, ptr(gamma), ptr(beta), eps,
+                                   cur_stream()), "gemm_ln_f32")
+        return out
+    y = linear(x, weight, bias, residual=residual, out=scratch)
+    return layernorm(y, gamma, beta, eps=eps, out=out)
 
 
 def layernorm(x, gamma, beta, res=None, eps=1e-5, out=None):

@@ -395,3 +395,22 @@ def test_conv_splitk_deep_k_few_pixels():
     assert float((a - ref).abs().max()) < tol and float((b - ref).abs().max()) < tol
     assert float((c - F.relu(ref)).abs().max()) < tol
     assert float((a - b).abs().max()) < tol
+
+
+def test_linear_layernorm_fused():
+    """mdqe_gemm_ln_f32: LN(x W^T + b + residual) in the GEMM epilogue (64x256 tile) against torch fp32; ragged row count,
+    output aliasing the residual, both K of the encoder (256 attention out-proj, 1024 FFN)."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for M, K in ((16384 + 37, 256), (20000, 1024)):
+        x = torch.randn(M, K, generator=g); w = torch.randn(256, K, generator=g) / K ** 0.5; b = torch.randn(256, generator=g)
+        r = torch.randn(M, 256, generator=g) * 3 + 0.5
+        ga = torch.randn(256, generator=g); be = torch.randn(256, generator=g)
+        ref = F.layer_norm(x.double() @ w.double().t() + b.double() + r.double(), (256,), ga.double(), be.double(), 1e-5).float()
+        rc = r.cuda()
+        out = ops.linear_ln(x.cuda(), w.cuda(), b.cuda(), rc, ga.cuda(), be.cuda())
+        assert float((out.cpu() - ref).abs().max()) < 2e-5
+        two = ops.layernorm(ops.linear(x.cuda(), w.cuda(), b.cuda(), residual=rc), ga.cuda(), be.cuda())
+        assert float((out - two).abs().max()) < 1e-5
+        out2 = ops.linear_ln(x.cuda(), w.cuda(), b.cuda(), rc, ga.cuda(), be.cuda(), out=rc)      # in place over the residual
+        assert out2.data_ptr() == rc.data_ptr() and torch.equal(out2, out)
