@@ -323,7 +323,7 @@ def main():
                                       "to rank 0, whose tracker replay runs on a worker thread under the next round" if world > 1 else "single GPU"},
         }
         if g:
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_k16_kernel<128,128,2,2> (+ gemm_nt_f32_kernel<128,128,2,2> for deep-K convs)" if args.precision == "f32" else
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_k16_kernel (fp32 MFMA GEMM / implicit-GEMM conv incl. its LayerNorm-epilogue form; every launch worth >= 192 tiles of 128x128, in whichever tile shape the dispatcher picks)" if args.precision == "f32" else
                                 "gemm_nt_f16x3w_kernel<256|128> (+ gemm_nt_f16x3_kernel<128,128> where B is not a constant weight)",
                                 "achieved": g["tflops"],
                                 "peak": F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3, "unit": "TFLOP/s",
