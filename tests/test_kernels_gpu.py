@@ -151,6 +151,30 @@ def test_stem_maxpool_upsample_dw():
     ref = F.conv2d(up, dw, db, padding=2, groups=C)
     out = ops.dwconv5x5(xg, wt, db.cuda(), up2=True, tw=tw.view(C).cuda(), tb=tb.cuda()).cpu().permute(0, 3, 1, 2)
     assert out.shape == ref.shape and rel(out, ref) < 1e-5
+    # C == 256: the register-tap depthwise kernel (odd width: the pair loop's tail) and the fused
+    # ConvTranspose x2 -> depthwise 5x5 -> pointwise 256 -> 8 (tiny images: every quad is a border quad; and a larger one)
+    C = 256
+    for (H, W) in ((2, 3), (7, 9), (12, 20)):
+        x = torch.randn(2, C, H, W, generator=g)
+        dw = torch.randn(C, 1, 5, 5, generator=g) / 5; db = torch.randn(C, generator=g)
+        xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+        wt = dw.view(C, 25).t().contiguous().cuda()
+        out = ops.dwconv5x5(xg, wt, db.cuda()).cpu().permute(0, 3, 1, 2)
+        assert rel(out, F.conv2d(x, dw, db, padding=2, groups=C)) < 1e-5
+        tw = torch.randn(C, 1, 1, 1, generator=g); tb = torch.randn(C, generator=g)
+        pw = torch.randn(8, C, generator=g) / 16; pb = torch.randn(8, generator=g)
+        up = F.conv_transpose2d(x, tw, tb, stride=2, output_padding=1, groups=C)
+        ref = F.conv2d(F.conv2d(up, dw, db, padding=2, groups=C), pw.view(8, C, 1, 1), pb)
+        out = ops.dwconv5x5_up2_pw(xg, wt, db.cuda(), tw.view(C).cuda(), tb.cuda(), pw.cuda(), pb.cuda())
+        assert tuple(out.shape) == (2, 2 * H, 2 * W, 8)
+        assert rel(out.cpu().permute(0, 3, 1, 2), ref) < 2e-5
+        # the two-kernel form (other channel counts / mask dims take it) agrees
+        ops.DW_FAST = False
+        try:
+            two = ops.dwconv5x5_up2_pw(xg, wt, db.cuda(), tw.view(C).cuda(), tb.cuda(), pw.cuda(), pb.cuda())
+        finally:
+            ops.DW_FAST = True
+        assert rel(out, two) < 2e-5
 
 
 def test_gemm_splitk_and_mask_stats():
