@@ -184,12 +184,12 @@ int mdqe_dwconv5x5_nhwc_f32(const float* x, const float* wt, const float* bias, 
                             int up2, const float* tw, const float* tb, void* stream);
 
 /* The same two layers for C == 256 (one wave = the 64 float4 channel groups of a pixel; filter taps in registers):
- * mdqe_dwconv5x5_c256_f32 = the plain depthwise 5x5; mdqe_dwconv5x5_up2_pw8_f32 = ConvTranspose2d(k=1,s=2,output_padding=1,
- * groups=C) -> depthwise 5x5 -> pointwise 256 -> 8 (+ bias) in one pass over x [NI,Hs,Ws,256] -> y [NI,2Hs,2Ws,8]
- * (segmentation.py:28-29,59-60,92-98: out_lay2 of the mask-feature head); wt [25,256] tap-major, pw [8,256]. */
+ * mdqe_dwconv5x5_c256_f32 = the plain depthwise 5x5 on x [NI,H,W,256]; mdqe_dwconv5x5_up2_c256_f32 = ConvTranspose2d(k=1,s=2,
+ * output_padding=1,groups=C) -> depthwise 5x5 in one pass, x [NI,Hs,Ws,256] -> y [NI,2Hs,2Ws,256], evaluated per 2x2
+ * output quad (segmentation.py:28-29,59,92-98 of the mask-feature head); wt [25,256] tap-major. */
 int mdqe_dwconv5x5_c256_f32(const float* x, const float* wt, const float* bias, float* y, int NI, int H, int W, void* stream);
-int mdqe_dwconv5x5_up2_pw8_f32(const float* x, const float* wt, const float* bias, const float* tw, const float* tb,
-                               const float* pw, const float* pb, float* y, int NI, int Hs, int Ws, void* stream);
+int mdqe_dwconv5x5_up2_c256_f32(const float* x, const float* wt, const float* bias, const float* tw, const float* tb, float* y,
+                                int NI, int Hs, int Ws, void* stream);
 
 /* ---- tracker, device half (mdqe/tracking/OverTracker.py) ------------------------------------------
  * siou: out3[i,j,:] = (|A_i & B_j|, |A_i|, |B_j|) with A_i = saved[i*saved_stride + k] > 0, B_j = inp[j*inp_stride + k] > 0,

@@ -49,7 +49,7 @@ SIGNATURES = {
     "mdqe_upsample_nearest_add_nhwc_f32": [p, p, p, i, i, i, i, i, i, p],
     "mdqe_dwconv5x5_nhwc_f32": [p, p, p, p, i, i, i, i, i, p, p, p],
     "mdqe_dwconv5x5_c256_f32": [p, p, p, p, i, i, i, p],
-    "mdqe_dwconv5x5_up2_pw8_f32": [p, p, p, p, p, p, p, p, i, i, i, p],
+    "mdqe_dwconv5x5_up2_c256_f32": [p, p, p, p, p, p, i, i, i, p],
 }
 
 

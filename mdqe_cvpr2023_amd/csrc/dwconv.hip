@@ -3,12 +3,11 @@
 //
 //  * dw5_c256_kernel: plain depthwise 5x5 (DepthwiseSeparableConv2d.depthwise, segmentation.py:92-98,112), two
 //    horizontally adjacent outputs per step (30 loads for 2 outputs instead of 50).
-//  * dw5_up2_pw_kernel: ConvTranspose2d(k=1, s=2, output_padding=1, groups=C) -> depthwise 5x5 -> pointwise C -> 8
-//    (segmentation.py:28-29,59 + out_lay2) in ONE pass.  The upsampled tensor is virtual: up[2i,2j] = x[i,j]*tw + tb,
-//    every other position = tb.  A 2x2 output quad (2a+dy, 2b+dx) touches only x[a-1..a+1][b-1..b+1] and uses each of the
-//    25 taps exactly once:  out = bias + tb * (sum of the in-bounds taps) + tw * (sum over the even-even taps of w * x).
-//    The pointwise product is reduced across the wave with a 5-stage exchange-and-halve (32 values per lane -> 1) plus one
-//    final add: 32 lane exchanges per quad; the [.., 256] depthwise output never exists in HBM.
+//  * dw5_up2_c256_kernel: ConvTranspose2d(k=1, s=2, output_padding=1, groups=C) -> depthwise 5x5 (segmentation.py:28-29,59)
+//    in one pass.  The upsampled tensor is virtual: up[2i,2j] = x[i,j]*tw + tb, every other position = tb.  A 2x2 output
+//    quad (2a+dy, 2b+dx) touches only x[a-1..a+1][b-1..b+1] and uses each of the 25 taps exactly once:
+//    out = bias + tb * (sum of the in-bounds taps) + tw * (sum over the even-even taps of w * x)
+//    -- 9 loads and 25 float4 FMAs per quad instead of 100 tap visits.
 #include "common.h"
 
 namespace {
@@ -52,31 +51,21 @@ dw5_c256_kernel(const float* __restrict__ x, const float* __restrict__ wt, const
   }
 }
 
-template <int MD>
-__global__ void __launch_bounds__(256, 3)
-dw5_up2_pw_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
-                  const float* __restrict__ tw, const float* __restrict__ tb, const float* __restrict__ pw,
-                  const float* __restrict__ pb, float* __restrict__ y, int NI, int Hs, int Ws) {
-  static_assert(MD == 8, "the lane exchange below is laid out for 4 pixels x 8 outputs");
+__global__ void __launch_bounds__(256, 2)
+dw5_up2_c256_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                    const float* __restrict__ tw, const float* __restrict__ tb, float* __restrict__ y, int NI, int Hs, int Ws) {
   constexpr int C = 256;
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
   const int H = 2 * Hs, W = 2 * Ws;
-  // the taps go through LDS ([tap][lane] float4, lane-contiguous: conflict-free ds_read_b128, the same for the 4 waves):
-  // 100 registers less than holding them, which is what lets the 32 pointwise partials live in registers without spilling
-  __shared__ f32x4 sW[25 * 64];
-  for (int t = threadIdx.x; t < 25 * 64; t += 256) sW[t] = ld4(wt + (t >> 6) * C + (t & 63) * 4);
-  __syncthreads();
-  const f32x4* w = sW + lane;                          // tap t of this lane: w[t * 64]
-  f32x4 pwv[MD];
+  f32x4 w[25];
 #pragma unroll
-  for (int o = 0; o < MD; ++o) pwv[o] = ld4(pw + o * C + lane * 4);
+  for (int t = 0; t < 25; ++t) w[t] = ld4(wt + t * C + lane * 4);
   const f32x4 bv = ld4(bias + lane * 4), twv = ld4(tw + lane * 4), tbv = ld4(tb + lane * 4);
   f32x4 wall = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < 25; ++t) wall += w[t * 64];
+  for (int t = 0; t < 25; ++t) wall += w[t];
   const f32x4 cin = bv + tbv * wall;                  // constant part of an interior output
-  const float pbv = pb[(lane >> 1) & 7];
 
   const long total = (long)NI * Hs * Ws;
   for (long i = wid; i < total; i += nw) {
@@ -96,14 +85,14 @@ dw5_up2_pw_kernel(const float* __restrict__ x, const float* __restrict__ wt, con
       }
       // output (dy,dx) of the quad uses taps kh = 2r - dy, kw = 2c - dx
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o00 += X[c] * w[((2 * r) * 5 + 2 * c) * 64];
+      for (int c = 0; c < 3; ++c) o00 += X[c] * w[(2 * r) * 5 + 2 * c];
 #pragma unroll
-      for (int c = 1; c < 3; ++c) o01 += X[c] * w[((2 * r) * 5 + 2 * c - 1) * 64];
+      for (int c = 1; c < 3; ++c) o01 += X[c] * w[(2 * r) * 5 + 2 * c - 1];
       if (r >= 1) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o10 += X[c] * w[((2 * r - 1) * 5 + 2 * c) * 64];
+        for (int c = 0; c < 3; ++c) o10 += X[c] * w[(2 * r - 1) * 5 + 2 * c];
 #pragma unroll
-        for (int c = 1; c < 3; ++c) o11 += X[c] * w[((2 * r - 1) * 5 + 2 * c - 1) * 64];
+        for (int c = 1; c < 3; ++c) o11 += X[c] * w[(2 * r - 1) * 5 + 2 * c - 1];
       }
     }
     f32x4 c00 = cin, c01 = cin, c10 = cin, c11 = cin;
@@ -117,40 +106,18 @@ dw5_up2_pw_kernel(const float* __restrict__ x, const float* __restrict__ wt, con
 #pragma unroll
           for (int kw = 0; kw < 5; ++kw) {
             const int iw = ww - 2 + kw;
-            if (iw >= 0 && iw < W) s += w[(kh * 5 + kw) * 64];
+            if (iw >= 0 && iw < W) s += w[kh * 5 + kw];
           }
         }
         return bv + tbv * s;
       };
       c00 = cst(2 * a, 2 * b); c01 = cst(2 * a, 2 * b + 1); c10 = cst(2 * a + 1, 2 * b); c11 = cst(2 * a + 1, 2 * b + 1);
     }
-    const f32x4 d[4] = {c00 + twv * o00, c01 + twv * o01, c10 + twv * o10, c11 + twv * o11};
-    // pointwise partials of this lane's 4 channels: v[px*8 + o]
-    float v[32];
-#pragma unroll
-    for (int px = 0; px < 4; ++px)
-#pragma unroll
-      for (int o = 0; o < MD; ++o) {
-        const f32x4 m = d[px] * pwv[o];
-        v[px * 8 + o] = (m[0] + m[1]) + (m[2] + m[3]);
-      }
-    // exchange-and-halve over lane bits 5..1: afterwards lane l holds the sum over 32 lanes of value index l >> 1
-#pragma unroll
-    for (int st = 0; st < 5; ++st) {
-      const int m = 32 >> st, n = 16 >> st;
-      const bool up = (lane & m) != 0;
-#pragma unroll
-      for (int k = 0; k < n; ++k) {
-        const float send = up ? v[k] : v[k + n];
-        const float keep = up ? v[k + n] : v[k];
-        v[k] = keep + __shfl_xor(send, m);
-      }
-    }
-    const float tot = v[0] + __shfl_xor(v[0], 1) + pbv;
-    if ((lane & 1) == 0) {
-      const int idx = lane >> 1, px = idx >> 3, o = idx & 7;
-      y[(((long)img * H + 2 * a + (px >> 1)) * W + 2 * b + (px & 1)) * MD + o] = tot;
-    }
+    float* o = y + (((long)img * H + 2 * a) * W + 2 * b) * C + lane * 4;
+    *reinterpret_cast<f32x4*>(o) = c00 + twv * o00;
+    *reinterpret_cast<f32x4*>(o + C) = c01 + twv * o01;
+    *reinterpret_cast<f32x4*>(o + (long)W * C) = c10 + twv * o10;
+    *reinterpret_cast<f32x4*>(o + (long)W * C + C) = c11 + twv * o11;
   }
 }
 
@@ -166,18 +133,15 @@ extern "C" int mdqe_dwconv5x5_c256_f32(const float* x, const float* wt, const fl
   return mdqe_launch_status();
 }
 
-// x [NI,Hs,Ws,256] -> y [NI,2Hs,2Ws,8] = pointwise(depthwise5x5(transposed-conv-x2(x))) ; wt [25,256], bias/tw/tb [256],
-// pw [8,256], pb [8]
-extern "C" int mdqe_dwconv5x5_up2_pw8_f32(const float* x, const float* wt, const float* bias, const float* tw, const float* tb,
-                                          const float* pw, const float* pb, float* y, int NI, int Hs, int Ws, void* stream) {
+// x [NI,Hs,Ws,256] -> y [NI,2Hs,2Ws,256] = depthwise5x5(transposed-conv-x2(x)); wt [25,256], bias/tw/tb [256]
+extern "C" int mdqe_dwconv5x5_up2_c256_f32(const float* x, const float* wt, const float* bias, const float* tw, const float* tb,
+                                           float* y, int NI, int Hs, int Ws, void* stream) {
   MDQE_REQUIRE(NI >= 0 && Hs > 0 && Ws > 0);
   if (NI == 0) return MDQE_OK;
-  MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(wt); MDQE_CHECK_PTR(bias); MDQE_CHECK_PTR(tw); MDQE_CHECK_PTR(tb); MDQE_CHECK_PTR(pw);
-  MDQE_CHECK_PTR(pb); MDQE_CHECK_PTR(y);
+  MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(wt); MDQE_CHECK_PTR(bias); MDQE_CHECK_PTR(tw); MDQE_CHECK_PTR(tb); MDQE_CHECK_PTR(y);
   mdqe_clear_error();
   const long total = (long)NI * Hs * Ws;
   long nb = (total + 3) / 4; if (nb > 256 * 8) nb = 256 * 8;
-  hipLaunchKernelGGL((dw5_up2_pw_kernel<8>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, wt, bias, tw, tb, pw, pb, y,
-                     NI, Hs, Ws);
+  hipLaunchKernelGGL(dw5_up2_c256_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, wt, bias, tw, tb, y, NI, Hs, Ws);
   return mdqe_launch_status();
 }

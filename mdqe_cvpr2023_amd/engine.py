@@ -475,8 +475,9 @@ class Engine:
         y = ops.dwconv5x5(x, o1.dw, o1.db)
         y = ops.linear(y.view(-1, C), o1.pw, o1.pb).view(x.shape)
         y = ops.groupnorm_nhwc(y, 32, o1.g, o1.beta, act="relu", out=y).view(x.shape)
+        z = ops.dwconv5x5(y, o2.dw, o2.db, up2=True, tw=mh.tw, tb=mh.tb)
         Md = o2.pw.shape[0]
-        z2 = ops.dwconv5x5_up2_pw(y, o2.dw, o2.db, mh.tw, mh.tb, o2.pw, o2.pb)        # x2 upsample -> depthwise -> pointwise
+        z2 = ops.linear(z.view(-1, C), o2.pw, o2.pb).view(NI, z.shape[1], z.shape[2], Md)
         return ops.groupnorm_nhwc(z2, 32 if Md % 32 == 0 else 24, o2.g, o2.beta, act="relu", out=z2).view(z2.shape)
 
     # ---- a11 (per-frame part): grid-guided query selection + content sampling ---------------------

@@ -260,30 +260,20 @@ def dwconv5x5(x, wt, bias, up2=False, tw=None, tb=None):
     NI, H, W, C = x.shape
     OH, OW = (2 * H, 2 * W) if up2 else (H, W)
     out = torch.empty((NI, OH, OW, C), dtype=torch.float32, device=x.device)
-    if C == 256 and not up2 and DW_FAST:
-        check(lib.mdqe_dwconv5x5_c256_f32(ptr(x), ptr(wt), ptr(bias), ptr(out), NI, H, W, cur_stream()), "dwconv5x5_c256")
+    if C == 256 and DW_FAST:                              # wave = the 64 channel groups of a pixel, taps in registers
+        if up2:
+            _chk(tw, "tw"); _chk(tb, "tb")
+            check(lib.mdqe_dwconv5x5_up2_c256_f32(ptr(x), ptr(wt), ptr(bias), ptr(tw), ptr(tb), ptr(out), NI, H, W, cur_stream()),
+                  "dwconv5x5_up2_c256")
+        else:
+            check(lib.mdqe_dwconv5x5_c256_f32(ptr(x), ptr(wt), ptr(bias), ptr(out), NI, H, W, cur_stream()), "dwconv5x5_c256")
         return out
     check(lib.mdqe_dwconv5x5_nhwc_f32(ptr(x), ptr(wt), ptr(bias), ptr(out), NI, OH, OW, C, int(up2), ptr(tw), ptr(tb),
                                       cur_stream()), "dwconv5x5")
     return out
 
 
-DW_FAST = os.environ.get("MDQE_DW_FAST", "1") != "0"        # 0: generic depthwise kernel + separate pointwise GEMM (debug / A-B)
-
-
-def dwconv5x5_up2_pw(x, wt, bias, tw, tb, pw, pb):
-    """x [NI,H,W,C] -> pointwise(depthwise5x5(ConvTranspose x2 (x))) as [NI,2H,2W,Md] (segmentation.py:59-60, out_lay2).
-    C == 256 and Md == 8: one kernel, the [NI,2H,2W,C] depthwise output never exists; otherwise two kernels."""
-    _chk(x, "x"); _chk(wt, "wt"); _chk(bias, "bias"); _chk(tw, "tw"); _chk(tb, "tb"); _chk(pw, "pw"); _chk(pb, "pb")
-    NI, H, W, C = x.shape
-    Md = pw.shape[0]
-    if C == 256 and Md == 8 and DW_FAST:
-        out = torch.empty((NI, 2 * H, 2 * W, Md), dtype=torch.float32, device=x.device)
-        check(lib.mdqe_dwconv5x5_up2_pw8_f32(ptr(x), ptr(wt), ptr(bias), ptr(tw), ptr(tb), ptr(pw), ptr(pb), ptr(out), NI, H, W,
-                                             cur_stream()), "dwconv5x5_up2_pw8")
-        return out
-    z = dwconv5x5(x, wt, bias, up2=True, tw=tw, tb=tb)
-    return linear(z.view(-1, C), pw, pb).view(NI, 2 * H, 2 * W, Md)
+DW_FAST = os.environ.get("MDQE_DW_FAST", "1") != "0"        # 0: generic depthwise kernel (debug / A-B)
 
 
 def msda(value, shapes_dev, starts_dev, loc, attn, groups=1, scale=1.0, out=None):

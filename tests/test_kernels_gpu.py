@@ -151,8 +151,8 @@ def test_stem_maxpool_upsample_dw():
     ref = F.conv2d(up, dw, db, padding=2, groups=C)
     out = ops.dwconv5x5(xg, wt, db.cuda(), up2=True, tw=tw.view(C).cuda(), tb=tb.cuda()).cpu().permute(0, 3, 1, 2)
     assert out.shape == ref.shape and rel(out, ref) < 1e-5
-    # C == 256: the register-tap depthwise kernel (odd width: the pair loop's tail) and the fused
-    # ConvTranspose x2 -> depthwise 5x5 -> pointwise 256 -> 8 (tiny images: every quad is a border quad; and a larger one)
+    # C == 256: the register-tap depthwise kernel (odd width: the pair loop's tail) and the quad form of
+    # ConvTranspose x2 -> depthwise 5x5 (tiny images: every quad is a border quad; and a larger one)
     C = 256
     for (H, W) in ((2, 3), (7, 9), (12, 20)):
         x = torch.randn(2, C, H, W, generator=g)
@@ -162,19 +162,17 @@ def test_stem_maxpool_upsample_dw():
         out = ops.dwconv5x5(xg, wt, db.cuda()).cpu().permute(0, 3, 1, 2)
         assert rel(out, F.conv2d(x, dw, db, padding=2, groups=C)) < 1e-5
         tw = torch.randn(C, 1, 1, 1, generator=g); tb = torch.randn(C, generator=g)
-        pw = torch.randn(8, C, generator=g) / 16; pb = torch.randn(8, generator=g)
         up = F.conv_transpose2d(x, tw, tb, stride=2, output_padding=1, groups=C)
-        ref = F.conv2d(F.conv2d(up, dw, db, padding=2, groups=C), pw.view(8, C, 1, 1), pb)
-        out = ops.dwconv5x5_up2_pw(xg, wt, db.cuda(), tw.view(C).cuda(), tb.cuda(), pw.cuda(), pb.cuda())
-        assert tuple(out.shape) == (2, 2 * H, 2 * W, 8)
-        assert rel(out.cpu().permute(0, 3, 1, 2), ref) < 2e-5
-        # the two-kernel form (other channel counts / mask dims take it) agrees
-        ops.DW_FAST = False
+        ref = F.conv2d(up, dw, db, padding=2, groups=C)
+        out = ops.dwconv5x5(xg, wt, db.cuda(), up2=True, tw=tw.view(C).cuda(), tb=tb.cuda())
+        assert tuple(out.shape) == (2, 2 * H, 2 * W, C)
+        assert rel(out.cpu().permute(0, 3, 1, 2), ref) < 1e-5
+        ops.DW_FAST = False                                  # the generic kernel (other channel counts take it) agrees
         try:
-            two = ops.dwconv5x5_up2_pw(xg, wt, db.cuda(), tw.view(C).cuda(), tb.cuda(), pw.cuda(), pb.cuda())
+            two = ops.dwconv5x5(xg, wt, db.cuda(), up2=True, tw=tw.view(C).cuda(), tb=tb.cuda())
         finally:
             ops.DW_FAST = True
-        assert rel(out, two) < 2e-5
+        assert rel(out, two) < 1e-5
 
 
 def test_gemm_splitk_and_mask_stats():
