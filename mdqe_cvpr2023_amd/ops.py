@@ -151,6 +151,7 @@ def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None
 
 
 LINEAR_LN_FUSED = os.environ.get("MDQE_LINEAR_LN_FUSED", "1") != "0"     # 0: GEMM then LayerNorm kernel (debug / A-B)
+LINEAR_LN_MIN_ROWS = 16384        # below this the 64x256 tile leaves CUs idle: 64x64 GEMM + LayerNorm kernel is faster
 
 
 def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratch=None):
@@ -161,7 +162,7 @@ def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratc
     N = weight.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    if LINEAR_LN_FUSED and N == 256 and M >= 16384 and get_gemm_precision() == "f32" and x.stride(1) == 1:
+    if LINEAR_LN_FUSED and N == 256 and M >= LINEAR_LN_MIN_ROWS and get_gemm_precision() == "f32" and x.stride(1) == 1:
         _chk(weight, "weight"); _chk(bias, "bias"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(residual, "residual"); _chk(out, "out")
         check(lib.mdqe_gemm_ln_f32(ptr(x), x.stride(0) if M > 1 else K, ptr(weight), ptr(bias), ptr(out), out.stride(0), M, N, K,
                                    ptr(residual), residual.stride(0) if residual is not None else 0, ptr(gamma), ptr(beta), eps,

@@ -33,7 +33,7 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().cuda()
 
 
-def test_encoder_and_mask_head_vs_reference():
+def test_encoder_and_mask_head_vs_reference(ln_rows):
     from mdqe_cvpr2023_amd.engine import Engine
     fx = Fixture("encoder_small")
     eng = Engine(small_cfg(), fx.state())
@@ -48,8 +48,19 @@ def test_encoder_and_mask_head_vs_reference():
     assert maxdiff(mf.cpu(), ref) < 5e-4
 
 
+@pytest.fixture(params=["default", "ln_epilogue_everywhere"])
+def ln_rows(request):
+    """The encoder/decoder `norm(x + linear(..))` steps take the LayerNorm-epilogue GEMM only from 16384 rows up; the second
+    setting forces it for every row count, so the small fixtures go through it too (ragged 64-row tiles)."""
+    from mdqe_cvpr2023_amd import ops
+    old = ops.LINEAR_LN_MIN_ROWS
+    ops.LINEAR_LN_MIN_ROWS = old if request.param == "default" else 0
+    yield request.param
+    ops.LINEAR_LN_MIN_ROWS = old
+
+
 @pytest.mark.parametrize("T", [3, 2, 1])
-def test_decoder_vs_reference(T):
+def test_decoder_vs_reference(T, ln_rows):
     from mdqe_cvpr2023_amd.engine import Engine
     enc_fx, fx = Fixture("encoder_small"), Fixture("decoder_small")
     eng = Engine(small_cfg(), enc_fx.state())
