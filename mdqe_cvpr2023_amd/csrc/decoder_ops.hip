@@ -62,11 +62,11 @@ mha_small_kernel(const float* __restrict__ qk, long ldqk, const float* __restric
 }
 
 // MFMA form (D = 32 or 24, Q <= 208): the scheme of window_attn_mfma_kernel (swin.hip) without normalisation / bias:
-// three waves per (batch, head), K and V in LDS (rows padded to 36 floats), S^T tiles = K_tile . (q * D^-0.5)^T on
+// NWV waves per (batch, head) (7 for D = 32, 4 for D = 24, by measurement), K and V in LDS (rows padded to 36 floats), S^T tiles = K_tile . (q * D^-0.5)^T on
 // v_mfma_f32_16x16x4_f32 with the head dimension walked as d = (D/4)*(lane>>4) + t, probabilities kept in the
 // accumulator registers and fed straight into the P . V product (its k index follows the same key order).
-template <int D>
-__global__ void __launch_bounds__(192)
+template <int D, int NWV>
+__global__ void __launch_bounds__(64 * NWV)
 mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __restrict__ v, long ldv, float* __restrict__ o,
                       long ldo, int Q, int C, int nh) {
   constexpr int LDK = 36, MAXT = 13, DG = D / 4;
@@ -78,7 +78,7 @@ mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __re
   const long row0 = (long)b * Q;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, g = lane >> 4;
-  for (int i = tid; i < NP * 8; i += 192) {
+  for (int i = tid; i < NP * 8; i += 64 * NWV) {
     const int r = i >> 3, c4 = i & 7;
     f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
     if (r < Q && c4 * 4 < D) {
@@ -90,7 +90,7 @@ mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __re
   }
   __syncthreads();
   const float sc = rsqrtf((float)D) * 1.4426950408889634f;
-  for (int rt = wave; rt < NT; rt += 3) {
+  for (int rt = wave; rt < NT; rt += NWV) {
     const int i0 = rt * 16;
     const int qi = min(i0 + lc, Q - 1);
     float q[DG];
@@ -130,17 +130,23 @@ mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __re
       }
     lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
     const float linv = 1.f / lsum;
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, p0 = o0, p1 = o0;      // even / odd key tiles: four independent MFMA chains
 #pragma unroll
     for (int jt = 0; jt < MAXT; ++jt)
       if (jt < NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float* vr = sV + (jt * 16 + 4 * g + r) * LDK + lc;
-          o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], o1, 0, 0, 0);     // columns >= D are zero in LDS
+          if (jt & 1) {
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], p1, 0, 0, 0);
+          } else {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], o1, 0, 0, 0);   // columns >= D are zero in LDS
+          }
         }
       }
+    o0 += p0; o1 += p1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float li = __shfl(linv, 4 * g + r);
@@ -168,8 +174,13 @@ extern "C" int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, lo
   hipStream_t st = (hipStream_t)stream;
   if ((D == 32 || D == 24) && Q <= 208 && g_mha_variant != 0) {
     const size_t smem2 = (size_t)2 * ((Q + 15) / 16 * 16) * 36 * sizeof(float);
-    if (D == 32) hipLaunchKernelGGL((mha_small_mfma_kernel<32>), dim3(B * nh), dim3(192), smem2, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh);
-    else hipLaunchKernelGGL((mha_small_mfma_kernel<24>), dim3(B * nh), dim3(192), smem2, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh);
+    // 13 row tiles of 16 queries over NWV waves.  Measured (tools/attn_bench.py, B = 148): D = 32: 3 waves 117 us, 4: 100, 7: 86,
+    // 13: 100; D = 24: 4 waves win.  g_mha_variant 1 = that choice; 2 -> 3 waves, 3 -> 7, 4 -> 13, 5 -> 4 (A/B)
+#define LM(DD, NW_) hipLaunchKernelGGL((mha_small_mfma_kernel<DD, NW_>), dim3(B * nh), dim3(64 * NW_), smem2, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh)
+    const int nwv = g_mha_variant == 2 ? 3 : g_mha_variant == 3 ? 7 : g_mha_variant == 4 ? 13 : g_mha_variant == 5 ? 4 : (D == 32 ? 7 : 4);
+    if (D == 32) { if (nwv == 3) LM(32, 3); else if (nwv == 7) LM(32, 7); else if (nwv == 13) LM(32, 13); else LM(32, 4); }
+    else         { if (nwv == 3) LM(24, 3); else if (nwv == 7) LM(24, 7); else if (nwv == 13) LM(24, 13); else LM(24, 4); }
+#undef LM
     return mdqe_launch_status();
   }
   const size_t smem = (size_t)2 * Q * D * sizeof(float);

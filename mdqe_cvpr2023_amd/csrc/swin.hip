@@ -180,7 +180,8 @@ window_attn_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o
 //   second product if ITS k index is taken as that same key order (B = V[key][d] is read from LDS in any order), so the
 //   probabilities never leave their registers;  O tile (16 queries x 16 d) += P . V.
 // Softmax statistics per query: 36 scores in-lane, then two cross-lane steps over the four 16-lane groups.
-__global__ void __launch_bounds__(192)
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV)
 window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o, long ldo, int N, int C, int nh,
                         const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ mask, int nW) {
   constexpr int D = 32, LDK = 36, MAXT = 12;         // up to 12 key tiles (N <= 192)
@@ -192,7 +193,7 @@ window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restric
   const long row0 = (long)win * N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, g = lane >> 4;
-  for (int r = tid; r < NP; r += 192) {
+  for (int r = tid; r < NP; r += 64 * NWV) {
     f32x4 kk[8], vv[8];
     float ss = 0.f;
 #pragma unroll
@@ -214,7 +215,7 @@ window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restric
   __syncthreads();
   const float L2E = 1.4426950408889634f;
   const float sc = scale[h] * L2E;
-  for (int rt = wave; rt < NT; rt += 3) {
+  for (int rt = wave; rt < NT; rt += NWV) {
     const int i0 = rt * 16;
     const int qi = min(i0 + lc, N - 1);                              // padded query rows repeat the last one (never stored)
     // Q fragment: d = 8g .. 8g+7 of query qi, normalised and pre-scaled by logit_scale * log2(e)
@@ -264,17 +265,23 @@ window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restric
       }
     lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
     const float linv = 1.f / lsum;                                   // of query lc, replicated over the four lane groups
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;                        // O[query 4g+r][d = lc] and [d = 16 + lc]
-#pragma unroll
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, p0 = o0, p1 = o0;      // O[query 4g+r][d = lc] and [d = 16 + lc]; even / odd key
+#pragma unroll                                                       // tiles accumulate apart: four independent MFMA chains
     for (int jt = 0; jt < MAXT; ++jt)
       if (jt < NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float* vr = sV + (jt * 16 + 4 * g + r) * LDK + lc;
-          o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], o1, 0, 0, 0);
+          if (jt & 1) {
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], p1, 0, 0, 0);
+          } else {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], o1, 0, 0, 0);
+          }
         }
       }
+    o0 += p0; o1 += p1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float li = __shfl(linv, 4 * g + r);                      // 1/sum of query 4g+r lives in lanes with lc == 4g+r
@@ -302,7 +309,11 @@ extern "C" int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ld
   hipStream_t st = (hipStream_t)stream;
   if (D == 32 && N <= 192 && N % 4 == 0 && g_window_attn_variant != 0) {
     const size_t smem2 = (size_t)2 * ((N + 15) / 16 * 16) * 36 * sizeof(float);
-    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(n_windows * nh), dim3(192), smem2, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW);
+    // 9 row tiles of 16 queries (N = 144) over NWV waves; g_window_attn_variant: 1 = the measured best, 2 -> 3 waves, 3 -> 5, 4 -> 9
+#define LW(NW_) hipLaunchKernelGGL((window_attn_mfma_kernel<NW_>), dim3(n_windows * nh), dim3(64 * NW_), smem2, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW)
+    const int nwv = g_window_attn_variant == 2 ? 3 : g_window_attn_variant == 3 ? 5 : g_window_attn_variant == 4 ? 9 : 3;
+    if (nwv == 5) LW(5); else if (nwv == 9) LW(9); else LW(3);
+#undef LW
     return mdqe_launch_status();
   }
   const size_t smem = (size_t)2 * N * D * sizeof(float);
