@@ -77,3 +77,10 @@ def test_fewer_than_ten_scores(monkeypatch):
     monkeypatch.setitem(sys.modules[__name__].KW, "num_classes", 3)
     out = run_both(video(5, 64, 96, seed=3), (64, 96), EV)
     assert 1 <= len(out["pred_scores"]) <= 9
+
+
+def test_class_threshold_above_every_score():
+    """No query passes the class threshold: the reference still keeps the best-scoring queries of a clip, so tiny-score
+    instances flow through NMS, the tracker and the final top-k -- product and oracle must agree on that path too."""
+    out = run_both(video(6, 64, 96, seed=5), (64, 96), dict(EV, apply_cls_thres=0.9999))
+    assert len(out["pred_scores"]) >= 1 and max(out["pred_scores"]) < 0.5
