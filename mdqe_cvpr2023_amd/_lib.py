@@ -111,6 +111,18 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
-def cur_stream(device=None):
+def raw_stream(device=None):
+    """hipStream_t (int) of torch's current stream.  Every kernel launch asks for it, so it takes the raw accessor
+    (~0.3 us) instead of building a torch.cuda.Stream object (~8 us)."""
     import torch
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if device is None:
+        idx = torch._C._cuda_getDevice()
+    else:
+        idx = device if isinstance(device, int) else torch.device(device).index
+        if idx is None:
+            idx = torch._C._cuda_getDevice()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
+def cur_stream(device=None):
+    return c_void_p(raw_stream(device))

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from ._lib import check, cur_stream, lib, ptr
+from ._lib import check, cur_stream, lib, ptr, raw_stream
 
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "tanh": 4}
 
@@ -69,7 +69,7 @@ def _workspace(nbytes, device):
     """Scratch buffer (split-K partials, GroupNorm statistics), one per (device, stream): the per-frame stages and the
     per-clip stages run on different streams and must not share it."""
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev, torch.cuda.current_stream(device).cuda_stream)
+    key = (dev, raw_stream(dev))
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
