@@ -119,14 +119,18 @@ class ReplayThread:
         import queue
         import threading
         self.merger, self.device, self.err = merger, device, None
+        # the device a new thread starts on is 0, not the creator's: pin it ("cuda" without an index = the creator's current one)
+        self.dev_index = None
+        if device.type == "cuda":
+            self.dev_index = device.index if device.index is not None else torch.cuda.current_device()
         self.q = queue.Queue()
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
     def _run(self):
         try:
-            if self.device.type == "cuda":
-                torch.cuda.set_device(self.device)
+            if self.dev_index is not None:
+                torch.cuda.set_device(self.dev_index)
             with torch.no_grad():
                 while True:
                     items = self.q.get()
@@ -146,6 +150,11 @@ class ReplayThread:
         if self.err is not None:
             raise self.err
         return self.merger.finish()
+
+    def abort(self):
+        """The producer failed: stop the worker, keep the producer's exception."""
+        self.q.put(None)
+        self.t.join()
 
 
 # ------------------------------------------------------------------------------------------------
