@@ -38,6 +38,7 @@ def _fold_bn(sd, p, eps=1e-5):
     return sd[p + ".weight"] * scale.view(-1, 1, 1, 1), shift
 
 
+GEO_CACHE = max(1, int(os.environ.get("MDQE_GEO_CACHE", "16")))     # resolutions whose constants stay resident
 STEM_FUSED = os.environ.get("MDQE_STEM_FUSED", "1") != "0"      # 0: im2col + GEMM (debug / A-B)
 
 
@@ -344,10 +345,17 @@ class Engine:
         self._geo = {}
 
     def geometry(self, h, w) -> Geometry:
+        """Per-resolution constants, least-recently-used cache (GEO_CACHE entries: an eval set has a few dozen frame sizes and
+        one entry holds ~80 MB of position tables at 360p; a Geometry still in use by queued work stays alive through its
+        references)."""
         k = (h, w)
-        if k not in self._geo:
-            self._geo[k] = Geometry(self.P, h, w)
-        return self._geo[k]
+        g = self._geo.pop(k, None)
+        if g is None:
+            g = Geometry(self.P, h, w)
+            while len(self._geo) >= GEO_CACHE:
+                self._geo.pop(next(iter(self._geo)))
+        self._geo[k] = g                                  # (re)insert as most recent
+        return g
 
     # ---- a1, a2, a4: normalise + pad + ResNet ------------------------------------------------------
     def backbone(self, frames, geo):

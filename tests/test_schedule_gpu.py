@@ -159,10 +159,14 @@ def test_resize_on_device_equals_resizing_on_the_host_first():
     assert got["image_size"] == (120, 200)
 
 
-def test_videos_of_different_sizes_back_to_back():
+@pytest.mark.parametrize("geo_cache", [16, 1])
+def test_videos_of_different_sizes_back_to_back(geo_cache, monkeypatch):
     """An eval loop feeds one model videos of varying resolution and length: the per-resolution constants, cache rings,
     workspaces and pinned blocks of one video must not leak into the next.  A (96x160) -> B (72x104, other length, other
-    output size) -> A again: both A results and a fresh model's are bit-identical."""
+    output size) -> A again: both A results and a fresh model's are bit-identical -- also when the per-resolution cache
+    holds a single entry and every switch rebuilds the constants."""
+    import mdqe_cvpr2023_amd.engine as E
+    monkeypatch.setattr(E, "GEO_CACHE", geo_cache)
     cfg, model = _small_model()
     A = [{"image": _video(11).cuda(), "height": 96, "width": 160}]
     B = [{"image": _video(7, h=72, w=104).cuda(), "height": 144, "width": 208}]
@@ -170,6 +174,7 @@ def test_videos_of_different_sizes_back_to_back():
     b1 = model(B)
     a2 = model(A)
     _same(a1, a2)
+    assert len(model.engine._geo) == min(2, geo_cache)
     assert b1["image_size"] == (144, 208) and all(m.shape == (7, 144, 208) for m in b1["pred_masks"])
     _, fresh = _small_model()
     _same(fresh(B), b1)
