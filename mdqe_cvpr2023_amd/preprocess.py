@@ -53,6 +53,8 @@ def pil_bilinear_coeffs(in_size, out_size):
 def _dev_tables(in_size, out_size, device):
     key = (in_size, out_size, str(device))
     if key not in _tables:
+        while len(_tables) >= 64:                        # a few KB each; bounded all the same (oldest first)
+            _tables.pop(next(iter(_tables)))
         x0, n, k = pil_bilinear_coeffs(in_size, out_size)
         _tables[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in (x0, n, k)) + (int(k.shape[1]),)
     return _tables[key]
