@@ -127,7 +127,7 @@ class MDQE(nn.Module):
                 break
         return clips
 
-    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False):
+    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
@@ -193,10 +193,19 @@ class MDQE(nn.Module):
             return {"slot": slot, "base": base, "count": count, "ready": ready, "covered": nxt,
                     "cache": {k: v[:count] for k, v in rings[slot].items()}}
 
+        def frames_queued():
+            """Once, when the LAST frame of this video has been queued on the frame stream: a caller that streams videos
+            queues the next video's first pass now, under this video's remaining clip / tracker work."""
+            nonlocal on_frames_queued
+            if on_frames_queued is not None and nxt >= n_local:
+                cb, on_frames_queued = on_frames_queued, None
+                cb()
+
         i, k = 0, 0
         cur = prepare(0, 0, None) if clips else None
         if primed:
             yield None                            # per-frame work of the first chunk is queued; the caller resumes later
+        frames_queued()
         while i < len(clips):
             cache, base, covered = cur["cache"], cur["base"], cur["covered"]
             ls, le = clips[i][0] - frame_offset, clips[i][1] - frame_offset
@@ -208,6 +217,7 @@ class MDQE(nn.Module):
                 j += 1
             group = clips[i:j]
             nxt_state = prepare(j, (k + 1) % 2, cur) if j < len(clips) else None     # queued BEFORE this group's clip work
+            frames_queued()
             if cuda:
                 clip_stream.wait_event(cur["ready"])
             outs = eng.decode_clips(cache, [c[0] - frame_offset - base for c in group], T, geo)
@@ -254,6 +264,76 @@ class MDQE(nn.Module):
         clips = self.clip_schedule(L, cfg.n_frames_test, cfg.clip_stride)
         return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace), (h, w), out_size,
                                 (geo.Hp // ms, geo.Wp // ms), n_frames=L)
+
+    def forward_stream(self, batches):
+        """An eval loop over videos: yields `forward(b)` for every b of the iterable `batches`, in order, bit-identical to
+        separate calls -- but with one video of look-ahead: as soon as the last frame of video k is on the frame stream,
+        the first pass of the per-frame stages of video k+1 is queued behind it, so it runs under video k's last decoder
+        batch, tracker updates and mask read-back instead of after them (the chip is half idle there).  The reference's
+        evaluator (`inference_on_dataset`) hands videos over one by one; this is that loop with the hand-over moved
+        forward.  COCO image sets and CPU runs fall back to plain calls."""
+        it = iter(batches)
+
+        def start(b):
+            """Frames to the device, geometry, clip schedule; queues the first pass (the generator is primed)."""
+            if len(b) != 1:
+                raise RuntimeError("MDQE eval takes exactly one video per call (mdqe/mdqe.py:292)")
+            cfg = self.cfg
+            video = b[0]
+            frames_dev = self.to_device_frames(video["image"])
+            h0, w0 = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
+            if self.resize_on_device and frames_dev.dtype == torch.uint8:
+                from .preprocess import resize_shortest_edge
+                frames_dev = resize_shortest_edge(frames_dev, cfg.min_size_test, cfg.max_size_test)
+            L, h, w = frames_dev.shape[0], int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
+            st = {"done_frames": False, "out_size": (video.get("height", h0), video.get("width", w0)), "hw": (h, w), "L": L}
+            geo = self.engine.geometry(h, w)
+            st["mask_hw"] = (geo.Hp // cfg.match_stride, geo.Wp // cfg.match_stride)
+            clips = self.clip_schedule(L, cfg.n_frames_test, cfg.clip_stride)
+
+            def cb():
+                st["done_frames"] = True
+                look_ahead(st)
+            st["gen"] = self.iter_clip_results(frames_dev, clips, 0, None, primed=True, on_frames_queued=cb)
+            next(st["gen"])
+            return st
+
+        state = {"cur": None, "next": None}
+
+        def look_ahead(st):
+            # only the video being consumed may pull the next one in (a short video whose frames are all queued by its own
+            # start() must not cascade through the whole stream)
+            if st is state["cur"] and state["next"] is None:
+                b = next(it, None)
+                if b is not None:
+                    state["next"] = start(b)
+
+        first = next(it, None)
+        if first is None:
+            return
+        if self.cfg.is_coco or self.device.type != "cuda":
+            yield self.forward(first)
+            for b in it:
+                yield self.forward(b)
+            return
+
+        def guarded(fn):                                   # no context manager is held across a yield
+            with torch.autocast(device_type="cuda", enabled=False), torch.no_grad():
+                return fn()
+
+        def step():
+            st = state["cur"]
+            if st["done_frames"]:
+                look_ahead(st)
+            out = self.merge_clips(st["gen"], st["hw"], st["out_size"], st["mask_hw"], n_frames=st["L"])
+            if state["next"] is None:
+                look_ahead(st)                             # (the generator ends only after its callback; belt and braces)
+            state["cur"], state["next"] = state["next"], None
+            return out
+
+        state["cur"] = guarded(lambda: start(first))
+        while state["cur"] is not None:
+            yield guarded(step)
 
     def inference_image(self, batched_inputs):
         """COCO single-image branch: MDQE.forward :213-236 -> mdqe.forward (models/mdqe.py:62-70) -> decoder

@@ -179,3 +179,21 @@ def test_videos_of_different_sizes_back_to_back(geo_cache, monkeypatch):
     _, fresh = _small_model()
     _same(fresh(B), b1)
     _same(fresh(A), a1)
+
+
+def test_forward_stream_equals_separate_calls():
+    """forward_stream (the next video's first pass queued under the current video's tail) over videos of different length and
+    resolution -- one of them shorter than a clip, one a single pass -- against one forward() per video: bit-identical, in order."""
+    cfg, model = _small_model()
+    vids = [[{"image": _video(11).cuda(), "height": 96, "width": 160}],
+            [{"image": _video(2, h=72, w=104).cuda(), "height": 72, "width": 104}],
+            [{"image": _video(7, h=72, w=104).cuda(), "height": 144, "width": 208}],
+            [{"image": _video(25).cuda(), "height": 96, "width": 160}]]
+    model.frame_batch = 6
+    ref = [model(v) for v in vids]
+    got = list(model.forward_stream(iter(vids)))
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        _same(a, b)
+    assert list(model.forward_stream(iter([]))) == []
+    assert torch.is_grad_enabled()                     # the generator leaves no no_grad / autocast state behind
