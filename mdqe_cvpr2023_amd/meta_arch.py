@@ -306,7 +306,10 @@ class MDQE(nn.Module):
             if st is state["cur"] and state["next"] is None:
                 b = next(it, None)
                 if b is not None:
-                    state["next"] = start(b)
+                    try:
+                        state["next"] = start(b)
+                    except Exception as e:                 # belongs to the NEXT video: raised when its turn comes
+                        state["next"] = {"error": e}
 
         first = next(it, None)
         if first is None:
@@ -323,6 +326,9 @@ class MDQE(nn.Module):
 
         def step():
             st = state["cur"]
+            if "error" in st:
+                state["cur"] = None
+                raise st["error"]
             if st["done_frames"]:
                 look_ahead(st)
             out = self.merge_clips(st["gen"], st["hw"], st["out_size"], st["mask_hw"], n_frames=st["L"])

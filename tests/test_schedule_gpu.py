@@ -197,3 +197,9 @@ def test_forward_stream_equals_separate_calls():
         _same(a, b)
     assert list(model.forward_stream(iter([]))) == []
     assert torch.is_grad_enabled()                     # the generator leaves no no_grad / autocast state behind
+    # a bad input in the stream surfaces at ITS position: the video before it is still delivered
+    bad = [{"image": _video(5).cuda(), "height": 96, "width": 160}, {"image": _video(5).cuda(), "height": 96, "width": 160}]
+    gen = model.forward_stream(iter([vids[0], bad, vids[2]]))
+    _same(next(gen), ref[0])
+    with pytest.raises(RuntimeError):
+        next(gen)
