@@ -187,46 +187,94 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
     emit_masks=False skips the mask production on ranks that only keep the tracker in step).
     root_only=True (bench.py): the rounds are gathered to rank 0 only, which replays the tracker on a worker thread while
     its main thread goes on with the next round; the other ranks only compute and send, and return None."""
-    from .meta_arch import ClipMerger
-    cfg = model.cfg
-    T = cfg.n_frames_test
-    any_fr = next(iter(chunk_frames.values()))
-    h, w = int(any_fr.shape[-2]), int(any_fr.shape[-1])
-    geo = model.engine.geometry(h, w)
-    ms = cfg.match_stride
-    mask_hw = (geo.Hp // ms, geo.Wp // ms)
-    proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
-             "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((T,) + tuple(mask_hw), torch.float32)}
-    is_root = rank == 0
-    merger = replay = None
-    if not root_only or is_root:
-        merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
-        if root_only:
-            replay = ReplayThread(merger, any_fr.device)
-    rounds = (len(plan) + world - 1) // world
+    return next(run_round_robin_stream(model, [(chunk_frames, plan)], rank, world, dist, out_size, emit_masks=emit_masks,
+                                       root_only=root_only))
 
-    def start(q):
-        g = q * world + rank
-        if q >= rounds or g >= len(plan):
+
+class _Job:
+    """One video of the round-robin schedule on this rank: its chunks, its merger and (root-only form) its replay thread."""
+
+    def __init__(self, model, chunk_frames, plan, rank, world, out_size, emit_masks, root_only, like=None):
+        from .meta_arch import ClipMerger
+        cfg = model.cfg
+        self.model, self.chunk_frames, self.plan, self.rank, self.world = model, chunk_frames, plan, rank, world
+        self.T = cfg.n_frames_test
+        any_fr = next(iter(chunk_frames.values()), like)
+        if any_fr is None:
+            raise ValueError("a rank that owns no chunk of a video must pass `like` (any [.., h, w] tensor on the frames' device)")
+        self.device = any_fr.device
+        h, w = int(any_fr.shape[-2]), int(any_fr.shape[-1])
+        geo = model.engine.geometry(h, w)
+        ms = cfg.match_stride
+        mask_hw = (geo.Hp // ms, geo.Wp // ms)
+        self.proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
+                      "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((self.T,) + tuple(mask_hw), torch.float32)}
+        self.merger = self.replay = None
+        if not root_only or rank == 0:
+            self.merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
+            if root_only:
+                self.replay = ReplayThread(self.merger, self.device)
+        self.rounds = (len(plan) + world - 1) // world
+
+    def start(self, q):
+        """Queue the per-frame work of this rank's chunk of round q (async); the returned generator yields its clip results."""
+        g = q * self.world + self.rank
+        if q >= self.rounds or g >= len(self.plan):
             return None
-        gen = model.iter_clip_results(chunk_frames[g], plan[g][0], plan[g][1], primed=True)
-        next(gen)                                  # queues the chunk's per-frame work (async) and returns
+        gen = self.model.iter_clip_results(self.chunk_frames[g], self.plan[g][0], self.plan[g][1], primed=True)
+        next(gen)
         return gen
 
-    cur = start(0)
-    for q in range(rounds):
-        nxt = start(q + 1)                         # the next round's per-frame work goes to the frame stream first ...
-        local = [r for r in cur] if cur is not None else []        # ... and runs under this round's decoder + clip inference
-        merged = all_gather_clips(local, T, dist, world, any_fr.device, proto, root=0 if root_only else None, rank=rank)
-        cur = nxt
-        if replay is not None:
-            replay.put(merged)                     # global clip order within the round: chunk q*world, q*world+1, ...
-        elif merger is not None:
+    def feed(self, merged):
+        if self.replay is not None:
+            self.replay.put(merged)                # global clip order within the round: chunk q*world, q*world+1, ...
+        elif self.merger is not None:
             for item in merged:
-                merger.feed(*item)
-    if replay is not None:
-        return replay.finish()
-    return merger.finish() if merger is not None else None
+                self.merger.feed(*item)
+
+    def finish(self):
+        if self.replay is not None:
+            return self.replay.finish()
+        return self.merger.finish() if self.merger is not None else None
+
+
+def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False):
+    """Videos as a stream through the round-robin schedule.  jobs: iterable of (chunk_frames, plan[, like]) as for
+    run_round_robin (`like`: any [.., h, w] tensor on the device, for a rank that owns no chunk of a short video); yields each video's result in order (None on the ranks that do not replay).  Within a video the next round's per-frame
+    work is queued before this round's clip work; ACROSS videos the first round of video k+1 is queued before the last round's
+    clip work of video k, and video k's result is handed out only after that first round has been gathered -- so the replay of
+    video k's last round (N x clips of a chunk on rank 0, which has no next round of its own to hide under) and its mask
+    read-back run under video k+1's compute.  Every rank walks the same sequence of collectives."""
+    it = iter(jobs)
+
+    def open_next():
+        j = next(it, None)
+        return None if j is None else _Job(model, j[0], j[1], rank, world, out_size, emit_masks, root_only,
+                                           like=j[2] if len(j) > 2 else None)
+
+    job = open_next()
+    gen = job.start(0) if job is not None else None
+    pending = None                                 # the previous video: all rounds fed, result not yet collected
+    while job is not None:
+        nxt_job = None
+        for q in range(job.rounds):
+            if q + 1 < job.rounds:
+                nxt_gen = job.start(q + 1)         # the next round's per-frame work goes to the frame stream first ...
+            else:
+                nxt_job = open_next()              # ... or the first round of the next video
+                nxt_gen = nxt_job.start(0) if nxt_job is not None else None
+            local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
+            merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank)
+            job.feed(merged)
+            if q == 0 and pending is not None:     # the previous video's tail has had this whole round to finish
+                yield pending.finish()
+                pending = None
+            gen = nxt_gen
+        if pending is not None:                    # (a video without rounds cannot occur: a plan has at least one chunk)
+            yield pending.finish()
+        pending, job = job, nxt_job
+    if pending is not None:
+        yield pending.finish()
 
 
 def run_sharded(model, shard_frames, f0, L, rank, world, dist, out_size):

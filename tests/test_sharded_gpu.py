@@ -16,11 +16,14 @@ def _cfg():
                       num_queries=16, query_embed_dim=16, n_max_inst=40, apply_cls_thres=0.12)
 
 
-def _video():
-    g = torch.Generator().manual_seed(2)
+def _video(L=11, seed=2):
+    g = torch.Generator().manual_seed(seed)
     base = torch.randint(0, 256, (3, 64, 96), generator=g, dtype=torch.uint8).float()
-    fr = torch.randint(0, 256, (11, 3, 64, 96), generator=g, dtype=torch.uint8).float()
+    fr = torch.randint(0, 256, (L, 3, 64, 96), generator=g, dtype=torch.uint8).float()
     return (0.8 * base[None] + 0.2 * fr).round().to(torch.uint8)
+
+
+STREAM = ((11, 2), (5, 3), (14, 4))        # (frames, seed) of the videos of the stream test: 3, 1 and 4 chunks of 4 frames
 
 
 def worker(rank, world, port, outdir):
@@ -36,7 +39,16 @@ def worker(rank, world, port, outdir):
     video = _video()
     L = video.shape[0]
     with torch.no_grad():
-        if os.environ.get("MDQE_TEST_SHARDING") == "contiguous":
+        if os.environ.get("MDQE_TEST_SHARDING", "").startswith("stream"):
+            root_only = os.environ["MDQE_TEST_SHARDING"] == "stream_root_only"
+            jobs = []
+            for Lv, seed in STREAM:
+                v = _video(Lv, seed)
+                plan = sharding.chunk_plan(Lv, cfg.n_frames_test, cfg.clip_stride, 4)
+                jobs.append(({g: v[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}, plan, v[:0].cuda()))
+            out = list(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (64, 96), root_only=root_only))
+            assert len(out) == len(STREAM) and (not root_only or all((o is None) == (rank != 0) for o in out))
+        elif os.environ.get("MDQE_TEST_SHARDING") == "contiguous":
             f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
             out = sharding.run_sharded(model, video[f0:f1].cuda(), f0, L, rank, world, dist, (64, 96))
         else:
@@ -48,6 +60,31 @@ def worker(rank, world, port, outdir):
                 assert (out is None) == (rank != 0)
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["stream", "stream_root_only"])
+def test_two_rank_stream_of_videos_equals_single_gpu(tmp_path, mode):
+    """run_round_robin_stream over three videos of 3, 1 and 4 chunks (a rank sits out a last round, or a whole video): every video's
+    result equals the single-process one, in order, on both ranks (all-ranks form) or on rank 0 (root-only form)."""
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    os.environ["MDQE_TEST_SHARDING"] = mode
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    model = MDQE(_cfg(), seed=5).eval()
+    with torch.no_grad():
+        refs = [model([{"image": _video(Lv, seed), "height": 64, "width": 96}]) for Lv, seed in STREAM]
+    for r in range(1 if mode == "stream_root_only" else 2):
+        outs = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
+        for out, ref in zip(outs, refs):
+            assert out["pred_labels"] == ref["pred_labels"]
+            assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
+            assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
 
 
 @pytest.mark.parametrize("mode", ["round_robin", "root_only", "contiguous"])
