@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--stages", action="store_true", help="print a per-stage time breakdown (extra untimed step)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
                     help="GEMM arithmetic of the headline number: exact fp32 MFMA (default) or split-precision f16x3")
+    ap.add_argument("--chunk-windows", type=int, default=2,
+                    help="N > 1: frames per chunk, in tracker windows (a chunk carries a T-1 frame halo that is computed twice: "
+                         "10 %% of a 30-frame chunk, 5 %% of a 60-frame one; the stream hides the longer replay tail)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra passes reported as `fast_mode` (f16x3 GEMMs) and `independent_steps`")
     ap.add_argument("--config", choices=["R50_ovis_360", "R50_ovis_720", "swinl_ovis"], default="R50_ovis_360",
                     help="R50_ovis_360 is BASELINE.json's metric config; R50_ovis_720 = 640x1138 frames (configs[2]); "
@@ -236,7 +239,7 @@ def main():
         shard = video.cuda()                               # the whole video, resident in HBM
     else:
         # chunks of one tracker window dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ...
-        plan = sharding.chunk_plan(L, T, cfg.clip_stride, cfg.n_frames_window_test)
+        plan = sharding.chunk_plan(L, T, cfg.clip_stride, cfg.n_frames_window_test * args.chunk_windows)
         chunk_frames = {g: synth_video(plan[g][1], plan[g][2], seed=0, h=fh, w=fw).cuda() for g in sharding.owned_chunks(plan, world, rank)}
         shard = next(iter(chunk_frames.values()))
     torch.cuda.synchronize()
@@ -341,8 +344,9 @@ def main():
                        "output": "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
-                       "parallelism": "1 process/GPU; 30-frame chunks dealt round-robin, per-round RCCL gather of the clip results "
-                                      "to rank 0, whose tracker replay runs on a worker thread under the next round" if world > 1 else "single GPU"},
+                       "parallelism": ("1 process/GPU; %d-frame chunks dealt round-robin, per-round RCCL gather of the clip results "
+                                       "to rank 0, whose tracker replay runs on a worker thread under the next round (of this or the "
+                                       "next video)" % (cfg.n_frames_window_test * args.chunk_windows)) if world > 1 else "single GPU"},
         }
         if g:
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_f32_k16_kernel (fp32 MFMA GEMM / implicit-GEMM conv incl. its LayerNorm-epilogue form; every launch worth >= 192 tiles of 128x128, in whichever tile shape the dispatcher picks)" if args.precision == "f32" else

@@ -44,7 +44,8 @@ def worker(rank, world, port, outdir):
             jobs = []
             for Lv, seed in STREAM:
                 v = _video(Lv, seed)
-                plan = sharding.chunk_plan(Lv, cfg.n_frames_test, cfg.clip_stride, 4)
+                chunk = 8 if os.environ["MDQE_TEST_SHARDING"] == "stream_two_window_chunks" else 4     # tracker window = 4 frames
+                plan = sharding.chunk_plan(Lv, cfg.n_frames_test, cfg.clip_stride, chunk)
                 jobs.append(({g: v[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}, plan, v[:0].cuda()))
             out = list(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (64, 96), root_only=root_only))
             assert len(out) == len(STREAM) and (not root_only or all((o is None) == (rank != 0) for o in out))
@@ -62,7 +63,7 @@ def worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["stream", "stream_root_only"])
+@pytest.mark.parametrize("mode", ["stream", "stream_root_only", "stream_two_window_chunks"])
 def test_two_rank_stream_of_videos_equals_single_gpu(tmp_path, mode):
     """run_round_robin_stream over three videos of 3, 1 and 4 chunks (a rank sits out a last round, or a whole video): every video's
     result equals the single-process one, in order, on both ranks (all-ranks form) or on rank 0 (root-only form)."""
