@@ -30,4 +30,4 @@ with torch.no_grad():
             pr.disable()
         print("replay %.2f ms for %d clips" % (1e3 * (time.perf_counter() - t0), len(res)))
         m.finish()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(34)
