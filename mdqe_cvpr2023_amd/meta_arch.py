@@ -471,6 +471,7 @@ class ClipMerger:
         if self.use_side and model._trk_stream is None:
             model._trk_stream = torch.cuda.Stream(self.dev)
         self.side = model._trk_stream if self.use_side else None
+        self.side_is_current = False                # set by sharding.ReplayThread in its own thread
         self.saved, self.tracker = 0, None
         self.cls_clips, self.windows, self.f_off = [], [], 0
         self.done = False
@@ -479,7 +480,8 @@ class ClipMerger:
         """Returns True once the last clip has been consumed."""
         cfg = self.model.cfg
         T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
-        ctx = torch.cuda.stream(self.side) if self.use_side else contextlib.nullcontext()
+        # (a replay thread makes the tracker stream its current stream once instead of entering a stream context per clip)
+        ctx = torch.cuda.stream(self.side) if self.use_side and not self.side_is_current else contextlib.nullcontext()
         with ctx:
             if self.use_side:
                 if res.get("ready") is not None:

@@ -131,6 +131,10 @@ class ReplayThread:
         try:
             if self.dev_index is not None:
                 torch.cuda.set_device(self.dev_index)
+                side = getattr(self.merger, "side", None)
+                if side is not None:               # this thread only ever feeds this merger: its tracker stream becomes the
+                    torch.cuda.set_stream(side)    # thread's current stream once (a stream context per clip costs ~30 us)
+                    self.merger.side_is_current = True
             with torch.no_grad():
                 while True:
                     items = self.q.get()
@@ -147,6 +151,8 @@ class ReplayThread:
     def finish(self):
         self.q.put(None)
         self.t.join()
+        if hasattr(self.merger, "side_is_current"):
+            self.merger.side_is_current = False    # finish() runs on the caller's thread and stream
         if self.err is not None:
             raise self.err
         return self.merger.finish()

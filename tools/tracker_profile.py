@@ -30,4 +30,15 @@ with torch.no_grad():
             pr.disable()
         print("replay %.2f ms for %d clips" % (1e3 * (time.perf_counter() - t0), len(res)))
         m.finish()
+    from mdqe_cvpr2023_amd.sharding import ReplayThread
+    for rep in range(2):
+        m = ClipMerger(model, (360, 640), (360, 640), (geo.Hp // ms, geo.Wp // ms))
+        t0 = time.perf_counter()
+        rt = ReplayThread(m, m.dev)
+        rt.put(res)
+        rt.t.join(0)                                   # (finish() below joins)
+        rt.q.put(None); rt.t.join(); torch.cuda.synchronize()
+        print("replay on a ReplayThread %.2f ms for %d clips" % (1e3 * (time.perf_counter() - t0), len(res)))
+        m.side_is_current = False
+        m.finish()
     pstats.Stats(pr).sort_stats("tottime").print_stats(34)
