@@ -91,19 +91,23 @@ def all_gather_clips(local, T, dist, world, device, proto_shapes, root=None, ran
     if device.type == "cuda":
         ready = torch.cuda.Event()
         ready.record()                                 # the gathered payloads are complete once this event fires
+    sizes_h = [int(s_[0]) for s_ in all_sizes]
     for r in range(world):
-        nclips = int(all_sizes[r][0])
-        m = gathered["meta"][r].cpu()
+        nclips = sizes_h[r]
+        if nclips == 0:
+            continue
+        m = gathered["meta"][r].cpu().tolist()
         host = {f: gathered[f][r].cpu().numpy() for f in ("scores", "cls_probs", "query_embeds")}   # one copy per rank buffer
+        dev = [gathered[f][r] for f in FIELDS]         # (root of N ranks walks N x clips here: keep the per-clip work small)
         for i in range(nclips):
-            s, e, l, n = [int(v) for v in m[i]]
+            s, e, l, n = m[i]
             res = {}
-            for f in FIELDS:
-                t = gathered[f][r][i, :n]
-                if f == "pred_masks":
-                    t = t[:, :e - s].contiguous()
+            for f, g_ in zip(FIELDS, dev):
+                t = g_[i, :n]
+                if f == "pred_masks" and e - s != T:
+                    t = t[:, :e - s].contiguous()      # the short last clip was padded in time
                 res[f] = t
-            res["host"] = {f: host[f][i, :n] for f in host}
+            res["host"] = {f: v[i, :n] for f, v in host.items()}
             res["ready"] = ready
             merged.append((s, e, bool(l), res))
     merged.sort(key=lambda c: c[0])
