@@ -137,3 +137,109 @@ def test_replay_thread_keeps_order_and_surfaces_errors():
     import pytest
     with pytest.raises(ValueError):
         t.finish()
+
+
+# ---- run_round_robin_stream with a stand-in model (the schedule, the collectives and the hand-out order; no kernels) ----------
+class _FakeGeo:
+    Hp, Wp = HW[0] * 4, HW[1] * 4
+
+
+class _FakeEngine:
+    def geometry(self, h, w):
+        return _FakeGeo()
+
+
+class _FakeModel:
+    cfg = CFG
+    engine = _FakeEngine()
+
+    def __init__(self, log):
+        self.log = log
+
+    def iter_clip_results(self, frames, clips, f0, trace=None, primed=False, on_frames_queued=None):
+        self.log.append(("frames_queued", clips[0][0]))
+        if primed:
+            yield None
+        for s, e, l in clips:
+            yield s, e, l, fake_result(s, e)
+
+
+class _FakeMerger:
+    """Stands in for meta_arch.ClipMerger: records the clip order it is fed and replays the tracker on the CPU."""
+    use_side = False
+
+    def __init__(self, model, frame_hw, out_size, mask_hw, n_frames=None, emit_masks=True):
+        self.items, self.dev = [], torch.device("cpu")
+
+    def feed(self, s, e, l, res):
+        self.items.append((s, e, l, res))
+        return bool(l)
+
+    def finish(self):
+        return [(s, e, l) for s, e, l, _ in self.items], replay(self.items)
+
+
+STREAM_L = (13, 5, 22)            # 4, 1 and 6 chunks of 4 frames
+
+
+def stream_worker(rank, world, port, outdir, root_only):
+    import torch.distributed as dist
+    import mdqe_cvpr2023_amd.meta_arch as MA
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    MA.ClipMerger = _FakeMerger
+    log = []
+    model = _FakeModel(log)
+    jobs = []
+    for Lv in STREAM_L:
+        plan = sharding.chunk_plan(Lv, CFG.n_frames_test, 1, 4)
+        frames = {g: torch.zeros(plan[g][2] - plan[g][1], 3, HW[0] * 4, HW[1] * 4) for g in sharding.owned_chunks(plan, world, rank)}
+        jobs.append((frames, plan, torch.zeros(0, 3, HW[0] * 4, HW[1] * 4)))
+    outs, order = [], []
+    for k, out in enumerate(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (HW[0] * 4, HW[1] * 4), root_only=root_only)):
+        outs.append(out)
+        order.append((k, len(log)))               # how much per-frame work had been queued when video k's result came out
+    torch.save((outs, order, log), os.path.join(outdir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _run_stream(tmp_path, root_only):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=stream_worker, args=(r, 2, port, str(tmp_path), root_only)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    return [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(2)]
+
+
+def test_round_robin_stream_two_ranks_all_replay(tmp_path):
+    got = _run_stream(tmp_path, False)
+    for outs, order, log in got:
+        assert len(outs) == len(STREAM_L)
+        for Lv, (clip_order, tracks) in zip(STREAM_L, outs):
+            clips = clip_schedule(Lv, CFG.n_frames_test, 1)
+            assert clip_order == clips                                  # global clip order on every rank
+            ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clips])
+            assert len(tracks) == len(ref)
+            for (c, m), (cr, mr) in zip(tracks, ref):
+                assert torch.allclose(c, cr) and torch.equal(m, mr)
+    # look-ahead: when video 0's result is handed out, this rank has already queued per-frame work of video 1 (rank 0 owns
+    # its only chunk) or of video 2 (rank 1 owns nothing of video 1 and moves straight on)
+    outs, order, log = got[0]
+    n_video0 = len(sharding.owned_chunks(sharding.chunk_plan(STREAM_L[0], CFG.n_frames_test, 1, 4), 2, 0))
+    assert order[0][1] > n_video0
+
+
+def test_round_robin_stream_two_ranks_root_only(tmp_path):
+    got = _run_stream(tmp_path, True)
+    outs0, outs1 = got[0][0], got[1][0]
+    assert all(o is None for o in outs1) and len(outs1) == len(STREAM_L)
+    for Lv, (clip_order, tracks) in zip(STREAM_L, outs0):
+        assert clip_order == clip_schedule(Lv, CFG.n_frames_test, 1)
+        ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clip_schedule(Lv, CFG.n_frames_test, 1)])
+        for (c, m), (cr, mr) in zip(tracks, ref):
+            assert torch.allclose(c, cr) and torch.equal(m, mr)
