@@ -7,6 +7,8 @@ variable-length all-gather (RCCL over xGMI; `gloo` in the CPU tests) of the per-
 padded to the global maximum instance count; every rank then replays the tracker in global clip
 order, which is bit-identical to the single-GPU schedule.
 """
+import contextlib
+
 import torch
 
 FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
@@ -256,35 +258,42 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     video k's last round (N x clips of a chunk on rank 0, which has no next round of its own to hide under) and its mask
     read-back run under video k+1's compute.  Every rank walks the same sequence of collectives."""
     it = iter(jobs)
+    ws = getattr(model, "work_stream", contextlib.nullcontext)      # the model's high-priority stream (no context is held across a yield)
 
     def open_next():
         j = next(it, None)
         return None if j is None else _Job(model, j[0], j[1], rank, world, out_size, emit_masks, root_only,
                                            like=j[2] if len(j) > 2 else None)
 
-    job = open_next()
-    gen = job.start(0) if job is not None else None
+    def finish(j):
+        with ws():
+            return j.finish()
+
+    with ws():
+        job = open_next()
+        gen = job.start(0) if job is not None else None
     pending = None                                 # the previous video: all rounds fed, result not yet collected
     while job is not None:
         nxt_job = None
         for q in range(job.rounds):
-            if q + 1 < job.rounds:
-                nxt_gen = job.start(q + 1)         # the next round's per-frame work goes to the frame stream first ...
-            else:
-                nxt_job = open_next()              # ... or the first round of the next video
-                nxt_gen = nxt_job.start(0) if nxt_job is not None else None
-            local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
-            merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank)
-            job.feed(merged)
+            with ws():
+                if q + 1 < job.rounds:
+                    nxt_gen = job.start(q + 1)     # the next round's per-frame work goes to the frame stream first ...
+                else:
+                    nxt_job = open_next()          # ... or the first round of the next video
+                    nxt_gen = nxt_job.start(0) if nxt_job is not None else None
+                local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
+                merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank)
+                job.feed(merged)
             if q == 0 and pending is not None:     # the previous video's tail has had this whole round to finish
-                yield pending.finish()
+                yield finish(pending)
                 pending = None
             gen = nxt_gen
         if pending is not None:                    # (a video without rounds cannot occur: a plan has at least one chunk)
-            yield pending.finish()
+            yield finish(pending)
         pending, job = job, nxt_job
     if pending is not None:
-        yield pending.finish()
+        yield finish(pending)
 
 
 def run_sharded(model, shard_frames, f0, L, rank, world, dist, out_size):
