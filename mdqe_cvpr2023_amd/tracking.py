@@ -170,7 +170,10 @@ class OverTracker:
             sh = np.nonzero(self.untracked[:ni] < self.n_short)[0]
             sm = np.zeros((ni, n_in), dtype=np.float32)
             sm[lo] = ctt_similarity(qm[lo], clip.query_embeds)
-            sm[sh] = 0.5 * (sm[sh] + ctt_similarity(qm[sh], clip.query_embeds))
+            if not (len(sh) == len(lo) and self.n_short <= self.n_long):
+                sm[sh] = 0.5 * (sm[sh] + ctt_similarity(qm[sh], clip.query_embeds))
+            # (else: sh is the same index set as lo -- the usual case, every track seen recently -- and
+            #  0.5 * (a + a) == a bit for bit, so the second similarity is skipped)
             ii, si_ = [], []
             for o, f in enumerate(clip.frame_idx):
                 if f in self.saved_idx and f >= self.start_frame:
