@@ -107,8 +107,8 @@ def check(code, what=""):
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (None -> NULL)."""
-    return None if t is None else c_void_p(t.data_ptr())
+    """Device pointer of a torch tensor as a plain int (None -> NULL); the argtypes convert it, no ctypes object per argument."""
+    return None if t is None else t.data_ptr()
 
 
 def raw_stream(device=None):
@@ -125,4 +125,4 @@ def raw_stream(device=None):
 
 
 def cur_stream(device=None):
-    return c_void_p(raw_stream(device))
+    return raw_stream(device)
