@@ -195,12 +195,58 @@ int mdqe_dwconv5x5_up2_c256_f32(const float* x, const float* wt, const float* bi
  * siou: out3[i,j,:] = (|A_i & B_j|, |A_i|, |B_j|) with A_i = saved[i*saved_stride + k] > 0, B_j = inp[j*inp_stride + k] > 0,
  * k < n (the overlapping frames of both are contiguous); feeds OverTracker._get_siou (:92-113).
  * accumulate: sum[r[k]*sum_stride + e] += src[c[k]*src_stride + e] (e < n), cnt[r[k]*cnt_stride + f] += 1 (f < nf);
- * r/c are HOST int arrays (count <= 128)  (OverTracker._update_memory :65-76). */
+ * r/c are HOST int arrays of any length  (OverTracker._update_memory :65-76). */
 int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
                       int n_in, long n, float* out3, void* stream);
 int mdqe_trk_accumulate_f32(float* sum, long sum_stride, float* cnt, long cnt_stride, const float* src,
                             long src_stride, long n, int nf, const int* r_host, const int* c_host, int count,
                             void* stream);
+
+/* window flush, device half (OverTracker.get_result :195-225): window_mean: out[i,f,:] = sum[i,f0+f,:] / max(cnt[i,f0+f],1)
+ * for i < n, f < nf (rows of `out` are nf frames apart).  carry: frames [src0, src0+k) of rows < n become frames [0,k) as
+ * their mean logits with count 1 where seen; the rest of those rows is zeroed (`carry`: device scratch, n*k*hw floats). */
+int mdqe_trk_window_mean_f32(const float* sum, const float* cnt, long hw, int mem_len, int n, int nf, long f0,
+                             float* out, void* stream);
+int mdqe_trk_carry_f32(float* sum, float* cnt, long hw, int mem_len, int n, int k, long src0, float* carry, void* stream);
+
+/* ---- tracker, host half + drivers (csrc/tracker_native.hip) -----------------------------------------
+ * The HOST state and decisions of OverTracker (mdqe/tracking/OverTracker.py:16-63 __init__/_init_memory, :65-90
+ * _update_memory, :115-193 update, :195-225 get_result, :228-242 get_ctt_similarity) as an opaque object.  These
+ * entry points are the exception to "never synchronise": mdqe_tracker_update* wait for one small device->host copy per
+ * clip (the assignment needs the intersection counts), as the reference's update() does (`.cpu()` at :159).
+ * All array arguments below are HOST pointers unless named bank_*, masks, counts_dev, out_masks, carry.
+ *
+ * mdqe_lsap_f64: scipy.optimize.linear_sum_assignment (the reference's call at OverTracker.py:159; scipy==1.8.1,
+ *   requirements.txt:3) restated: cost [nr,nc] row-major -> min(nr,nc) (row, col) pairs in ascending row order.
+ * create: thr = MODEL.MDQE.APPLY_CLS_THRES; E = embedding width; K = classes.
+ * overlap -> (ni saved instances, bank frame s0, clip frame a, nf frames) of the frames of clip [f0, f0+n_frames) that the
+ *   window already holds; decide: the update given counts3 [ni, n_in, 3] = (|A&B|, |A|, |B|) over those frames (NULL: no
+ *   overlap) -> pairs (bank row r_idx[k] <- clip instance c_idx[k]) and the frame range (s0, a, nf) of the memory write;
+ *   result: window class scores out_cls [n,K], n, ln (frames emitted) and, unless is_last, re-bases the host state
+ *   (carry_valid [n, mem_len-win] optional).  A stand-in bank (CPU tests) drives these three.
+ * update: overlap + siou kernel + D2H + sync + decide + accumulate kernel for one clip.  bank_sum [max_inst, win+T, hw],
+ *   bank_cnt [max_inst, win+T]; masks [n_in, frames, hw] rows inst_stride floats apart; counts_dev / counts_host (pinned):
+ *   scratch of max_inst*n_in*3 floats.  update_many: the same for a run of clips (clip i: host rows row0[i].. of
+ *   scores/cls_probs/embeds, masks[i] = HOST array of device pointers).
+ * get_result: result + window_mean into out_masks [n, ln, hw] + (unless is_last) carry. */
+int mdqe_lsap_f64(const double* cost, int nr, int nc, int maximize, int* rows_out, int* cols_out, int* n_out);
+int mdqe_tracker_create(int max_inst, int T, int win, int stride, int K, int E, float thr, void** handle);
+int mdqe_tracker_destroy(void* handle);
+int mdqe_tracker_state(void* handle, int* num_inst, int* num_clip, int* start_frame);
+int mdqe_tracker_overlap(void* handle, int f0, int n_frames, int* ni, int* s0, int* a, int* nf);
+int mdqe_tracker_decide(void* handle, int f0, int n_frames, int n_in, const float* scores, const float* cls_probs,
+                        const float* embeds, const float* counts3, int* r_idx, int* c_idx, int* n_pairs,
+                        int* s0, int* a, int* nf);
+int mdqe_tracker_result(void* handle, int is_last, float* out_cls, int* n, int* ln, unsigned char* carry_valid);
+int mdqe_tracker_update(void* handle, float* bank_sum, float* bank_cnt, long hw, int f0, int n_frames, int n_in,
+                        const float* scores, const float* cls_probs, const float* embeds, const float* masks,
+                        long inst_stride, float* counts_dev, float* counts_host, void* stream);
+int mdqe_tracker_update_many(void* handle, float* bank_sum, float* bank_cnt, long hw, int n_clips, const int* f0,
+                             const int* n_frames, const int* n_in, const int* row0, const float* scores,
+                             const float* cls_probs, const float* embeds, const float* const* masks,
+                             const long* inst_stride, float* counts_dev, float* counts_host, void* stream);
+int mdqe_tracker_get_result(void* handle, int is_last, float* bank_sum, float* bank_cnt, long hw, float* out_masks,
+                            float* carry, float* out_cls, int* n, int* ln, void* stream);
 
 /* ---- per-row statistics of dynamic mask logits (mdqe/mdqe.py:387-413) in one pass -------------------
  * logits [n, T, H, W].  stats[r] = (any(x>0), sum sigmoid(x)[x>0], count[x>0], sum_half sigmoid(x), count_half[x>0]);

@@ -17,6 +17,18 @@ SIGNATURES = {
     "mdqe_msda_fused_f32": [p, l, l, p, p, l, p, l, p, l, i, i, p, p, p, p, i, i, i, i, i, i, i, f, p, l, l, p],
     "mdqe_trk_siou_f32": [p, l, i, p, l, i, l, p, p],
     "mdqe_trk_accumulate_f32": [p, l, p, l, p, l, l, i, p, p, i, p],
+    "mdqe_trk_window_mean_f32": [p, p, l, i, i, i, l, p, p],
+    "mdqe_trk_carry_f32": [p, p, l, i, i, i, l, p, p],
+    "mdqe_lsap_f64": [p, i, i, i, p, p, p],
+    "mdqe_tracker_create": [i, i, i, i, i, i, f, p],
+    "mdqe_tracker_destroy": [p],
+    "mdqe_tracker_state": [p, p, p, p],
+    "mdqe_tracker_overlap": [p, i, i, p, p, p, p],
+    "mdqe_tracker_decide": [p, i, i, i, p, p, p, p, p, p, p, p, p, p],
+    "mdqe_tracker_result": [p, i, p, p, p, p],
+    "mdqe_tracker_update": [p, p, p, l, i, i, i, p, p, p, p, l, p, p, p],
+    "mdqe_tracker_update_many": [p, p, p, l, i, p, p, p, p, p, p, p, p, p, p, p, p],
+    "mdqe_tracker_get_result": [p, i, p, p, l, p, p, p, p, p, p],
     "mdqe_mha_small_f32": [p, l, p, l, p, l, i, i, i, i, p],
     "mdqe_query_select_f32": [p, i, i, i, i, i, p, p, p],
     "mdqe_sample_levels_mean_f32": [p, i, l, i, p, i, p, p, p, i, p, p],

@@ -67,9 +67,9 @@ extern "C" int mdqe_msda_backward_f32(const float* value, const int64_t* shapes,
                                       const float* attn, const float* grad_out, int B, int S, int M, int D, int L, int Q,
                                       int P, float* grad_value, float* grad_loc, float* grad_attn, void* stream) {
   MDQE_REQUIRE(B >= 0 && S >= 0 && M > 0 && D > 0 && L > 0 && Q >= 0 && P > 0);
-  MDQE_CHECK_PTR(grad_value);
   hipStream_t st = (hipStream_t)stream;
   mdqe_clear_error();
+  if ((long)B * S > 0) MDQE_CHECK_PTR(grad_value);      // empty tensors (B == 0) come with NULL pointers: accepted, as the reference does
   if ((long)B * S > 0 && hipMemsetAsync(grad_value, 0, (size_t)B * S * M * D * sizeof(float), st) != hipSuccess) return MDQE_ELAUNCH;
   const long total = (long)B * Q * M * L * P;
   if (total == 0) return MDQE_OK;

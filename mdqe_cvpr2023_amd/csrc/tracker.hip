@@ -82,17 +82,88 @@ trk_accumulate_kernel(float* __restrict__ sum, long sum_stride, float* __restric
 extern "C" int mdqe_trk_accumulate_f32(float* sum, long sum_stride, float* cnt, long cnt_stride, const float* src,
                                        long src_stride, long n, int nf, const int* r_host, const int* c_host, int count,
                                        void* stream) {
-  MDQE_REQUIRE(count >= 0 && count <= 128 && n >= 0 && n % 4 == 0 && nf >= 0 && nf <= 256);
+  MDQE_REQUIRE(count >= 0 && n >= 0 && n % 4 == 0 && nf >= 0 && nf <= 256);
   MDQE_REQUIRE(sum_stride % 4 == 0 && src_stride % 4 == 0);
   if (count == 0 || n == 0) return MDQE_OK;
   MDQE_CHECK_PTR(sum); MDQE_CHECK_PTR(cnt); MDQE_CHECK_PTR(src); MDQE_CHECK_PTR(r_host); MDQE_CHECK_PTR(c_host);
   MDQE_REQUIRE((((uintptr_t)sum | (uintptr_t)src) & 15) == 0);
-  TrkIdx idx;
-  for (int i = 0; i < 128; ++i) { idx.r[i] = 0; idx.c[i] = 0; }
-  for (int i = 0; i < count; ++i) { idx.r[i] = r_host[i]; idx.c[i] = c_host[i]; }
   mdqe_clear_error();
   long bx = (n / 4 + 255) / 256; if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(trk_accumulate_kernel, dim3((unsigned)bx, count), dim3(256), 0, (hipStream_t)stream, sum, sum_stride, cnt,
-                     cnt_stride, src, src_stride, n, nf, idx);
+  for (int o = 0; o < count; o += 128) {                // any number of (row, clip instance) pairs, 128 per launch
+    const int c = count - o < 128 ? count - o : 128;
+    TrkIdx idx;
+    for (int i = 0; i < 128; ++i) { idx.r[i] = 0; idx.c[i] = 0; }
+    for (int i = 0; i < c; ++i) { idx.r[i] = r_host[o + i]; idx.c[i] = c_host[o + i]; }
+    hipLaunchKernelGGL(trk_accumulate_kernel, dim3((unsigned)bx, c), dim3(256), 0, (hipStream_t)stream, sum, sum_stride, cnt,
+                       cnt_stride, src, src_stride, n, nf, idx);
+  }
+  return mdqe_launch_status();
+}
+
+// ---- window flush (OverTracker.get_result :195-225), device half -------------------------------------------------------
+// out[i, f, :] = sum[i, f0 + f, :] / max(cnt[i, f0 + f], 1)  for i < n, f < nf  (per-frame mean of the saved logits over clips)
+__global__ void __launch_bounds__(256)
+trk_window_mean_kernel(const float* __restrict__ sum, const float* __restrict__ cnt, long hw, int mem_len, int nf, int f0,
+                       float* __restrict__ out) {
+  const int i = blockIdx.z, f = blockIdx.y;
+  const float c = cnt[(long)i * mem_len + f0 + f];
+  const float* s = sum + ((long)i * mem_len + f0 + f) * hw;
+  float* o = out + ((long)i * nf + f) * hw;
+  for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < hw; e += (long)gridDim.x * blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(s + e);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = v[k] / (c > 1.f ? c : 1.f);      // true division, as torch: sum / cnt.clamp(min=1)
+    *reinterpret_cast<f32x4*>(o + e) = r;
+  }
+}
+
+extern "C" int mdqe_trk_window_mean_f32(const float* sum, const float* cnt, long hw, int mem_len, int n, int nf, long f0,
+                                        float* out, void* stream) {
+  MDQE_REQUIRE(hw > 0 && hw % 4 == 0 && mem_len > 0 && n >= 0 && nf >= 0 && f0 >= 0 && f0 + nf <= mem_len);
+  if (n == 0 || nf == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(sum); MDQE_CHECK_PTR(cnt); MDQE_CHECK_PTR(out);
+  mdqe_clear_error();
+  long bx = (hw / 4 + 255) / 256; if (bx > 16) bx = 16;
+  hipLaunchKernelGGL(trk_window_mean_kernel, dim3((unsigned)bx, nf, n), dim3(256), 0, (hipStream_t)stream, sum, cnt, hw, mem_len,
+                     nf, (int)f0, out);
+  return mdqe_launch_status();
+}
+
+// cnt row i <- [cnt[i, src0 + f] > 0 for f < k] followed by zeros (one block per instance: the row is read whole, then rewritten)
+__global__ void __launch_bounds__(256)
+trk_carry_cnt_kernel(float* __restrict__ cnt, int mem_len, int k, int src0) {
+  __shared__ float row[1024];
+  float* c = cnt + (long)blockIdx.x * mem_len;
+  for (int f = threadIdx.x; f < mem_len; f += blockDim.x) row[f] = c[f];
+  __syncthreads();
+  for (int f = threadIdx.x; f < mem_len; f += blockDim.x) c[f] = (f < k && row[src0 + f] > 0.f) ? 1.f : 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+trk_carry_copy_kernel(float* __restrict__ sum, const float* __restrict__ carry, long hw, int mem_len, int k) {
+  const int i = blockIdx.z, f = blockIdx.y;
+  const float* s = carry + ((long)i * k + f) * hw;
+  float* d = sum + ((long)i * mem_len + f) * hw;
+  for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < hw; e += (long)gridDim.x * blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(d + e) = *reinterpret_cast<const f32x4*>(s + e);
+}
+
+// Re-base the bank after a flush: frames [src0, src0 + k) of rows < n become frames [0, k) as their MEAN logits with
+// count 1 where they had been seen (count 0 and logits 0 elsewhere); everything else of those rows is zeroed.
+extern "C" int mdqe_trk_carry_f32(float* sum, float* cnt, long hw, int mem_len, int n, int k, long src0, float* carry, void* stream) {
+  MDQE_REQUIRE(hw > 0 && hw % 4 == 0 && mem_len > 0 && mem_len <= 1024 && n >= 0 && k >= 0 && src0 >= 0 && src0 + k <= mem_len);
+  if (n == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(sum); MDQE_CHECK_PTR(cnt); MDQE_CHECK_PTR(carry);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = mdqe_trk_window_mean_f32(sum, cnt, hw, mem_len, n, k, src0, carry, stream);
+  if (rc != MDQE_OK) return rc;
+  mdqe_clear_error();
+  if (hipMemsetAsync(sum, 0, (size_t)n * mem_len * hw * sizeof(float), st) != hipSuccess) return MDQE_ELAUNCH;
+  hipLaunchKernelGGL(trk_carry_cnt_kernel, dim3(n), dim3(256), 0, st, cnt, mem_len, k, (int)src0);
+  if (k > 0) {
+    long bx = (hw / 4 + 255) / 256; if (bx > 16) bx = 16;
+    hipLaunchKernelGGL(trk_carry_copy_kernel, dim3((unsigned)bx, k, n), dim3(256), 0, st, sum, carry, hw, mem_len, k);
+  }
   return mdqe_launch_status();
 }

@@ -46,8 +46,17 @@ class MDQE(nn.Module):
         self._engine = None
         sd = state_dict if state_dict is not None else random_state(self.cfg, seed)
         man = full_manifest(self.cfg)
+        if state_dict is not None:
+            sd = dict(sd)
+            for k in list(sd):                       # released checkpoints carry the decoder's shared modules under an alias too
+                for a, b in ALIASES.items():
+                    if k.startswith(a) and (b + k[len(a):]) not in sd:
+                        sd[b + k[len(a):]] = sd[k]
+            missing = [n for n in man if n not in sd]
+            if missing:                              # a partial / mis-prefixed checkpoint must not become silent all-zero layers
+                raise KeyError("MDQE(cfg, state_dict=...): %d parameters of the manifest are missing, e.g. %s" % (len(missing), missing[:5]))
         for name, shape in man.items():
-            t = sd[name] if name in sd else torch.zeros(shape)
+            t = sd[name]
             _register(self, name, t.detach().clone().float(), buffer=name.endswith(("running_mean", "running_var")))
         self._extra = {k: v for k, v in sd.items() if k not in man}      # e.g. custom-backbone weights
         # frames per pass of the per-frame stages: 0 = by resolution (~300k encoder tokens per pass: at most 40 frames: 40 at 360p, 20 at 640p)
@@ -57,6 +66,7 @@ class MDQE(nn.Module):
         self._copy_stream = None
         self.resize_on_device = False               # True: frames arrive at native size and get the mapper's ResizeShortestEdge here
         self.rle_output = False                     # True: forward() returns per-frame COCO RLEs ("pred_rles") instead of dense masks
+        self.merge_on_cpu = None                    # None: cfg.merge_on_cpu (MODEL.MDQE.MERGE_ON_CPU); True / False override it
         self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.clip_priority = os.environ.get("MDQE_CLIP_PRIORITY", "1") != "0"       # per-clip stages on a high-priority stream
         self._work_stream = None
@@ -85,7 +95,8 @@ class MDQE(nn.Module):
         if self._engine is None:
             sd = OrderedDict((k, v) for k, v in self.state_dict().items())
             sd.update(self._extra)
-            self._engine = Engine(self.cfg, sd, self.device, backbone_fn=self._backbone_fn)
+            with self._on_device():
+                self._engine = Engine(self.cfg, sd, self.device, backbone_fn=self._backbone_fn)
         return self._engine
 
     # ---- forward (mdqe/mdqe.py:194-242) ------------------------------------------------------------
@@ -113,11 +124,15 @@ class MDQE(nn.Module):
         finally:
             cur.wait_stream(ws)
 
+    def _on_device(self):
+        """Every ctypes launch goes to the CURRENT device's current stream: make the model's device current for the call."""
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
+
     @torch.no_grad()
     def forward(self, batched_inputs):
         if len(batched_inputs) != 1:
             raise RuntimeError("MDQE eval takes exactly one video per call (mdqe/mdqe.py:292)")
-        with torch.autocast(device_type="cuda", enabled=False), self.work_stream():   # neutralise ambient autocast
+        with self._on_device(), torch.autocast(device_type="cuda", enabled=False), self.work_stream():   # neutralise ambient autocast (SURVEY A.11)
             if self.cfg.is_coco:                                           # DATASETS.TEST[0] is a COCO set (mdqe/mdqe.py:213,233-236)
                 return self.inference_image(batched_inputs)
             return self.inference_vis(batched_inputs)
@@ -199,6 +214,8 @@ class MDQE(nn.Module):
                         for k, v in rings[slot].items():
                             v[:keep].copy_(rings[prev["slot"]][k][o:o + keep])
                         count = keep
+                if count == 0:
+                    nxt = max(nxt, ls)                             # CLIP_STRIDE > clip length: the frames between two clips are never read
                 while nxt < le:
                     c1 = min(n_local, nxt + fbatch)
                     n_new = c1 - nxt
@@ -253,19 +270,27 @@ class MDQE(nn.Module):
                 ready = torch.cuda.Event()
                 ready.record(clip_stream)         # the clip results are complete once this event fires
                 free_ev[cur["slot"]] = ready      # ... and ring `slot` may be overwritten
-            for (start, end, last), res in zip(group, ress):
+            for gi, ((start, end, last), res) in enumerate(zip(group, ress)):
                 if trace is not None:
                     trace.append({k_: v.clone() for k_, v in res.items() if torch.is_tensor(v)})
                 res["ready"] = ready
+                res["batch_end"] = gi == len(group) - 1
                 yield start, end, last, res
             i, k, cur = j, k + 1, nxt_state
 
     def merge_clips(self, results, frame_hw, out_size, mask_hw, n_frames=None):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""
         m = ClipMerger(self, frame_hw, out_size, mask_hw, n_frames)
-        for item in results:
-            if m.feed(*item):
-                break
+        buf = []
+        for item in results:                       # the clips of one decoder batch go to the tracker together
+            buf.append(item)
+            if item[3].get("batch_end", True):
+                done = m.feed_many(buf)
+                buf = []
+                if done:
+                    break
+        if buf:
+            m.feed_many(buf)
         return m.finish()
 
     def to_device_frames(self, imgs):
@@ -347,7 +372,7 @@ class MDQE(nn.Module):
             return
 
         def guarded(fn):                                   # no context manager is held across a yield
-            with torch.autocast(device_type="cuda", enabled=False), torch.no_grad(), self.work_stream():
+            with self._on_device(), torch.autocast(device_type="cuda", enabled=False), torch.no_grad(), self.work_stream():
                 return fn()
 
         def step():
@@ -469,7 +494,13 @@ class MDQE(nn.Module):
             cnt = sum(1 for i in sel if i < m.shape[0])       # sel is ascending: these are its first `cnt` entries
             if cnt:
                 ops.final_masks(m, sel_dev[:cnt], self.cfg.match_stride, frame_hw[0], frame_hw[1], Ho, Wo, out, f_off)
-        host = out.cpu().view(torch.bool)
+        if out.is_cuda:                                            # one D2H into pinned memory (pageable copies run at a fraction of PCIe)
+            hbuf = torch.empty(out.shape, dtype=torch.uint8, pin_memory=True)
+            hbuf.copy_(out, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            host = hbuf.view(torch.bool)
+        else:
+            host = out.view(torch.bool)
         pos = {i: p for p, i in enumerate(sel)}
         if self.rle_output:                                        # no early path (CPU device / unknown length): encode on the host
             from . import rle as R
@@ -484,13 +515,19 @@ class ClipMerger:
     final video merge.  The tracker runs on its own HIP stream so that its small kernels and per-clip host syncs overlap
     with per-frame work the producer has already queued on the main stream."""
 
+    tracker_cls = OverTracker               # (tests without a GPU substitute a stand-in bank, tests/_standins.py)
+
     def __init__(self, model, frame_hw, out_size, mask_hw, n_frames=None, emit_masks=True):
         self.model, self.frame_hw, self.out_size, self.mask_hw = model, frame_hw, out_size, mask_hw
         self.emit_masks = emit_masks                # False: scores / labels only (ranks > 0 of a sharded video)
         self.n_frames = n_frames                    # total frames of the video when known: enables the early mask path
         self.early = None
-        # MODEL.MDQE.MERGE_ON_CPU exists in the reference to fit 16-40 GB GPUs (mdqe/mdqe.py:185-186,354-355); with
-        # 288 GB of HBM the merge always stays on the device (results are identical either way).
+        # MODEL.MDQE.MERGE_ON_CPU (mdqe/mdqe.py:185-186,354-355; True in R50_ovis_720 / swinl_ovis): where the windows' masks
+        # wait for the end of the video.  True: each window's final masks leave the device as soon as the window is flushed
+        # (pinned host buffers, copied under the later windows' compute) and the video is merged on the host; False: the
+        # windows' stride-4 logits stay on the device, final masks are produced and copied in one pass at the end.  Same
+        # outputs either way (MDQE.merge_on_cpu overrides the config value).
+        self.merge_on_cpu = bool(model.cfg.merge_on_cpu if model.merge_on_cpu is None else model.merge_on_cpu)
         self.dev = model.device
         self.use_side = self.dev.type == "cuda"
         self.main = torch.cuda.current_stream(self.dev) if self.use_side else None
@@ -504,36 +541,62 @@ class ClipMerger:
 
     def feed(self, start, end, last, res):
         """Returns True once the last clip has been consumed."""
+        return self.feed_many([(start, end, last, res)])
+
+    def feed_many(self, items):
+        """Clip results in global order.  The clips between two window flushes go to the tracker as ONE native call
+        (`OverTracker.update_many`: no Python between clips -- what keeps rank 0's replay of a gathered round off the critical
+        path of a sharded video).  Returns True once the last clip has been consumed."""
+        cfg = self.model.cfg
+        stride, win = cfg.clip_stride, cfg.n_frames_window_test
+        run = []
+        for it in items:
+            run.append(it)
+            start, last = it[0], it[2]
+            if last or (start + stride >= win * (self.saved + 1)):
+                self._consume(run, True, last)
+                run = []
+                if last:
+                    break
+        if run:
+            self._consume(run, False, False)
+        return self.done
+
+    def _consume(self, run, flush, last):
         cfg = self.model.cfg
         T, stride, win = cfg.n_frames_test, cfg.clip_stride, cfg.n_frames_window_test
         # (a replay thread makes the tracker stream its current stream once instead of entering a stream context per clip)
         ctx = torch.cuda.stream(self.side) if self.use_side and not self.side_is_current else contextlib.nullcontext()
         with ctx:
-            if self.use_side:
-                if res.get("ready") is not None:
-                    self.side.wait_event(res["ready"])
-                else:
-                    self.side.wait_stream(self.main)
-                res["pred_masks"].record_stream(self.side)
+            clips, seen = [], set()
+            for start, end, _, res in run:
+                if self.use_side:
+                    ev = res.get("ready")
+                    if ev is None:
+                        self.side.wait_stream(self.main)
+                    elif id(ev) not in seen:            # the clips of one decoder batch share their event
+                        seen.add(id(ev))
+                        self.side.wait_event(ev)
+                    res["pred_masks"].record_stream(self.side)
+                clips.append(Clips(range(start, end), res))
             if self.tracker is None:
-                self.tracker = OverTracker(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
-                                           self.mask_hw, self.dev, cfg.apply_cls_thres)
-            self.tracker.update(Clips(range(start, end), res))
-            if last or (start + stride >= win * (self.saved + 1)):
+                self.tracker = self.tracker_cls(cfg.n_max_inst, T, win, stride, cfg.num_classes, cfg.mask_dim, cfg.hidden_dim,
+                                                self.mask_hw, self.dev, cfg.apply_cls_thres)
+            self.tracker.update_many(clips)
+            if flush:
                 c, m = self.tracker.get_result(is_last_clip=last)   # m: mean logits [n, F, Hm, Wm] of this window
                 self.cls_clips.append(c)
                 m = m.contiguous()
                 if not self.emit_masks:
                     self.windows.append((self.f_off, None))
-                elif self.use_side and self.n_frames is not None:
+                elif self.use_side and self.n_frames is not None and (self.merge_on_cpu or self.model.rle_output):
                     self._early_masks(m)
                     self.windows.append((self.f_off, None))
                 else:
                     self.windows.append((self.f_off, m))
                 self.f_off += m.shape[1]
                 self.saved += 1
-        self.done = bool(last)
-        return self.done
+        self.done = self.done or bool(last)
 
     def _early_masks(self, m):
         """Final masks of EVERY instance tracked so far for the window just flushed (m: [n, F, Hm, Wm] mean logits), copied to

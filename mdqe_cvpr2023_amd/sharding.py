@@ -146,12 +146,18 @@ class ReplayThread:
                     items = self.q.get()
                     if items is None:
                         return
-                    for it in items:
-                        self.merger.feed(*it)
+                    fm = getattr(self.merger, "feed_many", None)
+                    if fm is not None:
+                        fm(items)                  # runs of clips between window flushes: one native tracker call each
+                    else:
+                        for it in items:
+                            self.merger.feed(*it)
         except BaseException as e:                     # surfaced by finish()
             self.err = e
 
     def put(self, items):
+        if self.err is not None:                   # a worker-side failure surfaces at the next hand-over, not only at finish()
+            raise self.err
         self.q.put(items)
 
     def finish(self):
@@ -241,13 +247,24 @@ class _Job:
         if self.replay is not None:
             self.replay.put(merged)                # global clip order within the round: chunk q*world, q*world+1, ...
         elif self.merger is not None:
-            for item in merged:
-                self.merger.feed(*item)
+            fm = getattr(self.merger, "feed_many", None)
+            if fm is not None:
+                fm(merged)
+            else:
+                for item in merged:
+                    self.merger.feed(*item)
 
     def finish(self):
         if self.replay is not None:
             return self.replay.finish()
         return self.merger.finish() if self.merger is not None else None
+
+    def abort(self):
+        """The producer failed (or the caller dropped the generator): stop the worker so that it does not stay blocked in
+        q.get() holding the merger, the tracker bank and its pinned buffers."""
+        if self.replay is not None:
+            self.replay.abort()
+            self.replay = None
 
 
 def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False):
@@ -269,31 +286,38 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
         with ws():
             return j.finish()
 
-    with ws():
-        job = open_next()
-        gen = job.start(0) if job is not None else None
-    pending = None                                 # the previous video: all rounds fed, result not yet collected
-    while job is not None:
-        nxt_job = None
-        for q in range(job.rounds):
-            with ws():
-                if q + 1 < job.rounds:
-                    nxt_gen = job.start(q + 1)     # the next round's per-frame work goes to the frame stream first ...
-                else:
-                    nxt_job = open_next()          # ... or the first round of the next video
-                    nxt_gen = nxt_job.start(0) if nxt_job is not None else None
-                local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
-                merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank)
-                job.feed(merged)
-            if q == 0 and pending is not None:     # the previous video's tail has had this whole round to finish
-                yield finish(pending)
-                pending = None
-            gen = nxt_gen
-        if pending is not None:                    # (a video without rounds cannot occur: a plan has at least one chunk)
-            yield finish(pending)
-        pending, job = job, nxt_job
-    if pending is not None:
-        yield finish(pending)
+    job = pending = nxt_job = None                 # pending: the previous video, all rounds fed, result not yet collected
+    try:
+        with ws():
+            job = open_next()
+            gen = job.start(0) if job is not None else None
+        while job is not None:
+            nxt_job = None
+            for q in range(job.rounds):
+                with ws():
+                    if q + 1 < job.rounds:
+                        nxt_gen = job.start(q + 1)     # the next round's per-frame work goes to the frame stream first ...
+                    else:
+                        nxt_job = open_next()          # ... or the first round of the next video
+                        nxt_gen = nxt_job.start(0) if nxt_job is not None else None
+                    local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
+                    merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank)
+                    job.feed(merged)
+                if q == 0 and pending is not None:     # the previous video's tail has had this whole round to finish
+                    p, pending = pending, None
+                    yield finish(p)
+                gen = nxt_gen
+            if pending is not None:                    # (a video without rounds cannot occur: a plan has at least one chunk)
+                p, pending = pending, None
+                yield finish(p)
+            pending, job, nxt_job = job, nxt_job, None
+        if pending is not None:
+            p, pending = pending, None
+            yield finish(p)
+    finally:                                           # an exception above, or the caller dropped the generator (GeneratorExit)
+        for j in (job, pending, nxt_job):
+            if j is not None:
+                j.abort()
 
 
 def run_sharded(model, shard_frames, f0, L, rank, world, dist, out_size):

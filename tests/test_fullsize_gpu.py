@@ -1,0 +1,287 @@
+"""GPU parity AT FULL SIZE on BASELINE.json's configurations, product (HIP kernels behind the C ABI) against the CPU oracle:
+
+  * R50_ovis_360 (360x640 -> 384x640, N=5100, 196 queries, 96x160 mask maps): the whole path from uint8 frames to the
+    video output -- per-clip mask logits, scores, labels, tracker windows and final boolean masks (mdqe/mdqe.py:291-471);
+  * R50_ovis_720 geometry (640x1138 -> 640x1152, N=15300, levels 80x144 .. 10x18, 160x288 mask maps;
+    configs/R50_ovis_720.yaml): the same chain stage by stage + size-independent MSDA properties on the 640p level table;
+  * swinl_ovis at 480x853 (-> 480x864, C=192, D=24, N=8617): Swin-L backbone + encoder.
+
+Two kinds of comparison.  `direct`: product and oracle each run from the frames.  `chained`: every product stage is fed the
+ORACLE's output of the stage before it, so that a discrete decision that falls the other way on a near-tie (arg-max of a
+query cell, a score at a threshold) cannot hide or fake a numerical difference downstream.  Bar: 1e-3 (north star) on
+logits / masks, relative to the activation scale where the values are not O(1).
+
+The oracle passes are cached per process: both GEMM precision modes compare against the same CPU run."""
+import dataclasses
+import functools
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import mdqe_oracle as O
+from _golden import maxdiff
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(params=["f32", "f16x3"])
+def gemm_precision(request):
+    from mdqe_cvpr2023_amd import ops
+    ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision("f32")
+
+
+def _hyper(cfg):
+    return O.Hyper(hidden_dim=cfg.hidden_dim, n_frames=cfg.n_frames, n_frames_test=cfg.n_frames_test,
+                   n_frames_window_test=cfg.n_frames_window_test, apply_cls_thres=cfg.apply_cls_thres, n_max_inst=cfg.n_max_inst,
+                   clip_stride=cfg.clip_stride)
+
+
+@functools.lru_cache(maxsize=None)
+def _workload(name, fh, fw, n_frames, window, max_inst=120):
+    """Weights (random reference-style init, zero-init trap removed, class logits calibrated on the synthetic video so that
+    several instances per clip survive -- bench.py's workload), OVIS-like synthetic frames, and ONE oracle pass with every
+    intermediate kept."""
+    from bench import calibrate_synthetic_scores, synth_video
+    from mdqe_cvpr2023_amd import ops
+    from mdqe_cvpr2023_amd.config import PRESETS
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    from mdqe_cvpr2023_amd.params import random_state
+    base = PRESETS[name]
+    cfg = dataclasses.replace(base, n_frames_window_test=window, n_max_inst=max_inst)   # (the oracle's tracker bank is [clips, max_inst, frames, h, w] on the host)
+    sd = random_state(base, seed=0)
+    prec = ops.get_gemm_precision()
+    ops.set_gemm_precision("f32")
+    model = MDQE(base, state_dict=sd).eval()
+    calibrate_synthetic_scores(model, sd, base, fh, fw)              # shifts the class bias in sd (and in this throw-away model)
+    del model
+    torch.cuda.empty_cache()
+    ops.set_gemm_precision(prec)
+    frames = list(synth_video(0, n_frames, seed=0, h=fh, w=fw))
+    hp = _hyper(cfg)
+    bb = lambda im: O.resnet(sd, "detr.backbone.0.backbone", im, 50)
+    ref = {"frames": frames, "sd": sd, "cfg": cfg, "hp": hp}
+    with torch.no_grad():
+        x, sizes = O.pad_frames(O.preprocess(hp, frames), 32)
+        enc, mask, shapes, mf = O.frame_features(sd, hp, x, sizes, bb)
+        ref.update(enc=enc, mask=mask, shapes=shapes, mf=mf)
+        L, T = n_frames, cfg.n_frames_test
+        clips, saved, tracker = [], 0, None
+        cls_w, mask_w, win_logits = [], [], []
+        for start in range(0, L, cfg.clip_stride):
+            end, last = start + T, False
+            if end > L:
+                last, end = True, L
+            idx = list(range(start, end))
+            dbg = {}
+            out = O.transformer_dec(sd, hp, enc[idx], mask[idx], shapes, dbg=dbg)
+            clip = O.inference_clip(hp, out, mf[:, idx])
+            clip["frame_idx"] = idx
+            clips.append({"start": start, "end": end, "last": last, "out": out, "coords0": dbg["coords0"], "clip": clip})
+            if tracker is None:
+                tracker = O.Tracker(hp, mf.shape[-2:])
+            tracker.update(clip)
+            if last or (start + cfg.clip_stride >= window * (saved + 1)):
+                c, m = tracker.get_result(last)
+                win_logits.append(m.clone())
+                cls_w.append(c)
+                mask_w.append(O.aligned_bilinear(m, hp.match_stride).sigmoid()[..., :fh, :fw])
+                saved += 1
+            if last:
+                break
+        ref.update(clips=clips, cls_w=cls_w, win_logits=win_logits, video=O.inference_video(hp, (fh, fw), cls_w, mask_w))
+    return ref
+
+
+def _model(ref):
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    return MDQE(ref["cfg"], state_dict=ref["sd"]).eval()
+
+
+def _check_video(out, ref_video, tol=1e-3):
+    assert out["pred_labels"] == ref_video["pred_labels"]
+    assert np.allclose(out["pred_scores"], ref_video["pred_scores"], atol=1e-3)
+    got, want = torch.stack(out["pred_masks"]), torch.stack(ref_video["pred_masks"])
+    assert got.shape == want.shape and got.dtype == torch.bool
+    assert float((got != want).float().mean()) < tol
+
+
+def _check_clip(res, rc, scale=1.0):
+    assert res["pred_masks"].shape == rc["pred_masks"].shape, (res["pred_masks"].shape, rc["pred_masks"].shape)
+    assert res["pred_classes"].tolist() == rc["pred_classes"].tolist()
+    assert maxdiff(res["pred_masks"].cpu(), rc["pred_masks"]) < 1e-3 * scale
+    assert maxdiff(res["scores"].cpu(), rc["scores"]) < 1e-3
+    assert maxdiff(res["cls_probs"].cpu(), rc["cls_probs"]) < 1e-3
+    assert maxdiff(res["query_embeds"].cpu(), rc["query_embeds"]) < 1e-3 * max(1.0, float(rc["query_embeds"].abs().max()))
+
+
+def _chain(ref, model, fh, fw):
+    """Stage by stage, each product stage on the oracle's input: a1-a10 from the frames; a11-a14 on the oracle's encoder
+    output; a15 on the oracle's decoder heads + mask features; a16-a18 on the oracle's clip results."""
+    from mdqe_cvpr2023_amd.meta_arch import ClipMerger
+    eng, cfg = model.engine, ref["cfg"]
+    geo = eng.geometry(fh, fw)
+    enc_r, mf_r = ref["enc"], ref["mf"]
+    assert ref["shapes"] == geo.shapes
+    with torch.no_grad():
+        fd = torch.stack(ref["frames"]).cuda()
+        enc = eng.encode(eng.backbone(fd, geo), geo)
+        mf = eng.mask_features(enc, geo)
+        assert maxdiff(enc.cpu(), enc_r) < 1e-3 * float(enc_r.abs().max())
+        assert maxdiff(mf.cpu(), mf_r.permute(1, 2, 3, 0)) < 1e-3 * max(1.0, float(mf_r.abs().max()))
+        del enc, mf
+        enc_d = enc_r.cuda().contiguous()
+        mf_d = mf_r.permute(1, 2, 3, 0).contiguous().cuda()                  # [frames, Hm, Wm, M] channels-last, as the engine keeps it
+        coords, content, emb = eng.frame_queries(enc_d, geo)
+        vals = eng.dec_values(enc_d, geo)
+        cache = {"coords": coords, "content": content, "emb": emb, "vals": vals}
+        lscale = max(1.0, max(float(c["clip"]["pred_masks"].abs().max()) for c in ref["clips"] if c["clip"]["pred_masks"].numel()))
+        items = []
+        for c in ref["clips"]:
+            s, e = c["start"], c["end"]
+            # a11-a14: decoder of this clip on the oracle's encoder tokens
+            out = eng.decode_clips(cache, [s], e - s, geo)
+            for k in ("cls", "mask_coeff", "query_embed"):
+                d = maxdiff(out[k][0].cpu(), c["out"][k][0])
+                assert d < 1e-3 * max(1.0, float(c["out"][k].abs().max())), (s, k, d)
+            # a15: inference_clip on the ORACLE's decoder heads
+            outs_r = {k: c["out"][k].cuda().contiguous() for k in ("cls", "mask_coeff", "query_embed")}
+            res = eng.inference_clips(outs_r, [mf_d[s:e]])[0]
+            _check_clip(res, c["clip"], lscale)
+            # ... and end to end within the clip stage (decoder -> inference_clip on product values)
+            res2 = eng.inference_clips(out, [mf_d[s:e]])[0]
+            _check_clip(res2, c["clip"], lscale)
+            rc = c["clip"]
+            items.append((s, e, c["last"], {"scores": rc["scores"].cuda(), "pred_classes": rc["pred_classes"].cuda(),
+                                            "cls_probs": rc["cls_probs"].cuda(), "query_embeds": rc["query_embeds"].cuda(),
+                                            "pred_masks": rc["pred_masks"].cuda().contiguous()}))
+        torch.cuda.synchronize()
+        # a16-a18: tracker + window flushes + final masks on the ORACLE's clip results, both mask-merge modes
+        ms = cfg.match_stride
+        for merge_on_cpu in (True, False):
+            model.merge_on_cpu = merge_on_cpu
+            m = ClipMerger(model, (fh, fw), (fh, fw), (geo.Hp // ms, geo.Wp // ms), n_frames=len(ref["frames"]))
+            m.feed_many([(s, e, l, dict(r)) for s, e, l, r in items])
+            assert len(m.cls_clips) == len(ref["cls_w"])
+            for a, b in zip(m.cls_clips, ref["cls_w"]):
+                assert maxdiff(a, b) < 1e-5
+            _check_video(m.finish(), ref["video"])
+        model.merge_on_cpu = None
+
+
+def _direct(ref, model, fh, fw):
+    trace = []
+    with torch.no_grad():
+        out = model.inference_vis([{"image": ref["frames"], "height": fh, "width": fw}], trace=trace)
+    assert len(trace) == len(ref["clips"])
+    lscale = max(1.0, max(float(c["clip"]["pred_masks"].abs().max()) for c in ref["clips"] if c["clip"]["pred_masks"].numel()))
+    for res, c in zip(trace, ref["clips"]):
+        _check_clip(res, c["clip"], lscale)
+    _check_video(out, ref["video"])
+    assert out["pred_masks"][0].shape == (len(ref["frames"]), fh, fw)
+    return out
+
+
+def test_r50_ovis_360_full_size_end_to_end(gemm_precision):
+    """6 frames of 360x640, 4-frame clips, 4-frame tracker windows (two flushes, one carry): frames -> boolean masks."""
+    ref = _workload("R50_ovis_360", 360, 640, 6, 4)
+    assert sum(int(c["clip"]["scores"].numel()) for c in ref["clips"]) > len(ref["clips"])      # the workload keeps >1 instance per clip
+    model = _model(ref)
+    _chain(ref, model, 360, 640)
+    _direct(ref, model, 360, 640)
+
+
+def test_r50_ovis_720_geometry_full_size(gemm_precision):
+    """configs/R50_ovis_720.yaml geometry: 640x1138 -> 640x1152, N=15300; 3 frames (one short clip -> last-frame repeat in the
+    temporal attention, transformer_dec.py:382-386), APPLY_CLS_THRES 0.2, MERGE_ON_CPU both ways."""
+    ref = _workload("R50_ovis_720", 640, 1138, 3, 20, 40)
+    model = _model(ref)
+    geo = model.engine.geometry(640, 1138)
+    assert (geo.Hp, geo.Wp, geo.N) == (640, 1152, 15300) and geo.shapes == [(80, 144), (40, 72), (20, 36), (10, 18)]
+    _chain(ref, model, 640, 1138)
+    _direct(ref, model, 640, 1138)
+
+
+def test_msda_640p_level_table_properties():
+    """The native op on the 640p level table (S = Q = 15300, B = 2): linearity in value, partition of unity on a constant map,
+    agreement with the oracle on a slice of queries of every level."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    g = torch.Generator().manual_seed(1)
+    shapes = [(80, 144), (40, 72), (20, 36), (10, 18)]
+    starts = [0, 11520, 14400, 15120]
+    S = 15300
+    B, M, D, L, P = 2, 8, 32, 4, 4
+    sh, st = torch.tensor(shapes, dtype=torch.int64).cuda(), torch.tensor(starts, dtype=torch.int64).cuda()
+    v1, v2 = torch.randn(B, S, M, D, generator=g), torch.randn(B, S, M, D, generator=g)
+    loc = torch.rand(B, S, 1, 1, 1, 2, generator=g) + 0.05 * torch.randn(B, S, M, L, P, 2, generator=g)
+    at = torch.softmax(torch.randn(B, S, M, L * P, generator=g), -1).view(B, S, M, L, P)
+    f = lambda v: MSDA.ms_deform_attn_forward(v.cuda(), sh, st, loc.cuda(), at.cuda(), 64)
+    o1, o2, o12 = f(v1), f(v2), f(2 * v1 - 3 * v2)
+    assert maxdiff((2 * o1 - 3 * o2).cpu(), o12.cpu()) < 1e-4
+    loc_in = 0.25 + 0.5 * torch.rand(B, S, M, L, P, 2, generator=g)
+    oc = MSDA.ms_deform_attn_forward(torch.full((B, S, M, D), -0.75).cuda(), sh, st, loc_in.cuda(), at.cuda(), 64).cpu()
+    assert maxdiff(oc, torch.full_like(oc, -0.75)) < 1e-5
+    for q0 in (0, 11500, 14390, 15100):                                      # slices that straddle the level boundaries
+        ref = O.msda_forward(v1[1:2], shapes, starts, loc[1:2, q0:q0 + 200], at[1:2, q0:q0 + 200])
+        assert maxdiff(o1[1:2, q0:q0 + 200].cpu(), ref) < 2e-5
+
+
+def test_swinl_ovis_480p_backbone_and_encoder(gemm_precision):
+    """swinl_ovis.yaml at its own size: 2 frames of 480x853 -> 480x864, Swin-L (window 12/6, 195 M parameters) stage3/4/5 maps
+    and the 6-layer encoder (C=192, head dim 24, N=8617) against the oracle."""
+    from mdqe_cvpr2023_amd.config import SWINL_OVIS
+    ref = _swin_reference()
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    model = MDQE(SWINL_OVIS, state_dict=ref["sd"]).eval()
+    eng = model.engine
+    geo = eng.geometry(480, 853)
+    assert (geo.Hp, geo.Wp, geo.N) == (480, 864, 8617) and geo.shapes == [(60, 108), (30, 54), (15, 27), (8, 14)]
+    with torch.no_grad():
+        feats = eng.backbone(torch.stack(ref["frames"]).cuda(), geo)
+        enc = eng.encode(feats, geo)
+    for o, r in zip(feats, ref["feats"]):
+        assert maxdiff(o.permute(0, 3, 1, 2).cpu(), r) < 1e-3 * max(1.0, float(r.abs().max()))
+    assert maxdiff(enc.cpu(), ref["enc"]) < 1e-3 * max(1.0, float(ref["enc"].abs().max()))
+
+
+@functools.lru_cache(maxsize=None)
+def _swin_reference():
+    from bench import synth_video
+    from mdqe_cvpr2023_amd.config import SWINL_OVIS
+    from mdqe_cvpr2023_amd.params import random_state
+    sd = random_state(SWINL_OVIS, seed=1)
+    frames = list(synth_video(0, 2, seed=2, h=480, w=853))
+    hp = O.Hyper(hidden_dim=192, n_frames=2, n_frames_test=2, n_frames_window_test=20)
+    with torch.no_grad():
+        x, sizes = O.pad_frames(O.preprocess(hp, frames), 32)
+        feats = O.swinv2(sd, "detr.backbone.0.backbone", x, O.SwinHyper())
+        masks = O.padding_masks(2, [tuple(f.shape[-2:]) for f in feats], (8, 16, 32), sizes)
+        xr, mr, pr, shapes = O.input_proj_and_flatten(sd, hp, feats, masks)
+        enc = O.encoder(sd, hp, xr, mr, pr, shapes)
+    return {"sd": sd, "frames": frames, "feats": feats, "enc": enc}
+
+
+def test_checkpoint_load_path_equals_constructor_path():
+    """B-model: weights through `load_state_dict` of a released-checkpoint-shaped dict (aliases, buffers, criterion.*) give the
+    same engine outputs, bit for bit, as weights through the constructor."""
+    from bench import synth_video
+    from mdqe_cvpr2023_amd.config import MDQEConfig
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    from test_bmodel_contract_cpu import SMALL, _released_checkpoint
+    cfg = MDQEConfig(**SMALL, n_frames_test=3, n_frames_window_test=4, n_max_inst=40)
+    sd, ckpt = _released_checkpoint(cfg, seed=4)
+    a = MDQE(cfg, state_dict=sd).eval()
+    b = MDQE(cfg, seed=9).eval()
+    _ = b.engine                                                              # an engine built from the OLD weights must be dropped
+    b.load_state_dict(ckpt, strict=True)
+    frames = synth_video(0, 7, seed=3, h=64, w=96, n_obj=3).cuda()
+    inp = [{"image": frames, "height": 64, "width": 96}]
+    oa, ob = a(inp), b(inp)
+    assert oa["pred_labels"] == ob["pred_labels"] and oa["pred_scores"] == ob["pred_scores"]
+    assert all(bool((x == y).all()) for x, y in zip(oa["pred_masks"], ob["pred_masks"]))

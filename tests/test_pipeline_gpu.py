@@ -141,50 +141,7 @@ def test_resnet50_vs_oracle():
         assert float((o - r).abs().max() / r.abs().max()) < 1e-4
 
 
-def test_full_size_r50_360p_vs_oracle():
-    """R50_ovis_360 at the real size (360x640 -> 384x640, N=5100, 6+6 layers), 5 synthetic frames, random
-    reference-style weights with the zero-init trap removed: product vs CPU oracle, stage by stage."""
-    from mdqe_cvpr2023_amd.config import R50_OVIS_360
-    from mdqe_cvpr2023_amd.meta_arch import MDQE
-    from mdqe_cvpr2023_amd.params import random_state
-    cfg = R50_OVIS_360
-    sd = random_state(cfg, seed=0)
-    g = torch.Generator().manual_seed(0)
-    frames = [torch.randint(0, 256, (3, 360, 640), generator=g, dtype=torch.uint8) for _ in range(5)]
-    model = MDQE(cfg, state_dict=sd).eval()
-    eng = model.engine
-    geo = eng.geometry(360, 640)
-    with torch.no_grad():
-        fd = torch.stack(frames).cuda()
-        feats = eng.backbone(fd, geo)
-        enc = eng.encode(feats, geo)
-        mf = eng.mask_features(enc, geo)
-    hp = O.Hyper()
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    x, sizes = O.pad_frames(O.preprocess(hp, frames), 32)
-    bb = lambda im: O.resnet(sd, "detr.backbone.0.backbone", im, 50)
-    with torch.no_grad():
-        enc_r, mask_r, shapes, mf_r = O.frame_features(sd, hp, x, sizes, bb)
-    assert shapes == geo.shapes
-    scale = float(enc_r.abs().max())
-    assert maxdiff(enc.cpu(), enc_r) / scale < 1e-3
-    assert maxdiff(mf.cpu(), mf_r.permute(1, 2, 3, 0)) < 1e-3 * max(1.0, float(mf_r.abs().max()))
-    # decoder on the ORACLE's encoder output for the first clip (isolates discrete query selection)
-    with torch.no_grad():
-        e4 = enc_r[:4].cuda().contiguous()
-        coords, content, emb = eng.frame_queries(e4, geo)
-        out = eng.decode_clip(coords, content, emb, eng.dec_values(e4, geo), geo)
-        dbg = {}
-        out_r = O.transformer_dec(sd, hp, enc_r[:4], mask_r[:4], shapes, dbg=dbg)
-    assert maxdiff(coords.cpu(), dbg["coords0"]) < 1e-6 or (coords.cpu() != dbg["coords0"]).float().mean() < 0.02
-    for k in ("cls", "mask_coeff", "query_embed"):
-        d = maxdiff(out[k].cpu(), out_r[k][0])
-        assert d < 1e-3 * max(1.0, float(out_r[k].abs().max())), (k, d)
-    # whole video through the driver: well-formed output
-    with torch.no_grad():
-        res = model([{"image": frames, "height": 360, "width": 640}])
-    assert len(res["pred_masks"]) == len(res["pred_scores"]) == len(res["pred_labels"]) >= 10
-    assert res["pred_masks"][0].shape == (5, 360, 640) and res["pred_masks"][0].dtype == torch.bool
+# (full-size R50_ovis_360 / R50_ovis_720 / swinl_ovis parity: tests/test_fullsize_gpu.py)
 
 
 def test_swinv2_backbone_vs_reference():

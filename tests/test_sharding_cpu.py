@@ -8,7 +8,9 @@ import torch.multiprocessing as mp
 
 from mdqe_cvpr2023_amd import sharding
 from mdqe_cvpr2023_amd.config import MDQEConfig
-from mdqe_cvpr2023_amd.tracking import Clips, OverTracker
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _standins import Clips, TorchBankTracker as OverTracker   # the native host core + a torch stand-in for the HIP bank
 
 CFG = MDQEConfig(backbone="custom", n_frames_test=3, n_frames_window_test=4, num_classes=5, hidden_dim=32, n_max_inst=16,
                  apply_cls_thres=0.1)
@@ -243,3 +245,50 @@ def test_round_robin_stream_two_ranks_root_only(tmp_path):
         ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clip_schedule(Lv, CFG.n_frames_test, 1)])
         for (c, m), (cr, mr) in zip(tracks, ref):
             assert torch.allclose(c, cr) and torch.equal(m, mr)
+
+
+class _Dist1:
+    """world_size 1 stand-in for torch.distributed (the collectives copy)."""
+
+    @staticmethod
+    def all_gather(outs, t):
+        outs[0].copy_(t)
+
+    @staticmethod
+    def gather(t, outs, dst=0):
+        outs[0].copy_(t)
+
+
+def test_producer_failure_stops_the_replay_workers():
+    """A producer that raises mid-stream (or a caller that drops the generator) must not leave replay threads blocked in
+    q.get() holding their mergers."""
+    import threading
+    import pytest
+    import mdqe_cvpr2023_amd.meta_arch as MA
+
+    class Boom(_FakeModel):
+        def iter_clip_results(self, frames, clips, f0, trace=None, primed=False, on_frames_queued=None):
+            if frames.shape[0] == 7:
+                raise ValueError("bad video")
+            yield from super().iter_clip_results(frames, clips, f0, trace, primed, on_frames_queued)
+
+    old = MA.ClipMerger
+    MA.ClipMerger = _FakeMerger
+    try:
+        base = threading.active_count()
+
+        def jobs(second_len):
+            for Lv in (13, second_len):
+                plan = sharding.chunk_plan(Lv, CFG.n_frames_test, 1, 40)
+                yield ({0: torch.zeros(Lv, 3, HW[0] * 4, HW[1] * 4)}, plan)
+        it = sharding.run_round_robin_stream(Boom([]), jobs(7), 0, 1, _Dist1, (HW[0] * 4, HW[1] * 4), root_only=True)
+        with pytest.raises(ValueError, match="bad video"):
+            list(it)
+        assert threading.active_count() == base
+        it = sharding.run_round_robin_stream(Boom([]), jobs(9), 0, 1, _Dist1, (HW[0] * 4, HW[1] * 4), root_only=True)
+        first = next(it)
+        assert first[0] == clip_schedule(13, CFG.n_frames_test, 1)
+        it.close()                                       # the caller walks away after the first video
+        assert threading.active_count() == base
+    finally:
+        MA.ClipMerger = old

@@ -1,8 +1,10 @@
-"""CPU: the product tracker (running-sum state) against the reference OverTracker's recorded behaviour."""
+"""CPU: the product tracker's native host core (decisions, bookkeeping, rectangular assignment; csrc/tracker_native.hip) with
+a torch stand-in for the device bank, against the reference OverTracker's recorded behaviour.  The HIP bank faces the
+same sequence in tests/test_tracker_gpu.py."""
 import torch
 
 from _golden import Fixture, maxdiff
-from mdqe_cvpr2023_amd.tracking import Clips, OverTracker
+from _standins import Clips, TorchBankTracker as OverTracker
 
 
 def test_tracker_matches_reference_sequence():

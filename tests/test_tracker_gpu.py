@@ -1,0 +1,72 @@
+"""GPU: the product tracker (native host core + the HIP bank kernels trk_siou / trk_accumulate / trk_window_mean / trk_carry)
+against the reference OverTracker's recorded behaviour on the crafted sequence (late, vanishing and duplicate objects,
+3 windows; fixture tracker_seq made by running mdqe/tracking/OverTracker.py:115-225), clip by clip and as runs of clips
+through ONE native call (update_many)."""
+import pytest
+import torch
+
+from _golden import Fixture, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _clips(fx):
+    from mdqe_cvpr2023_amd.tracking import Clips
+    out = []
+    for i in range(fx.i("n_clips")):
+        clip = {k: fx.t(f"clip{i}::{k}") for k in ("scores", "pred_classes", "cls_probs", "pred_masks", "query_embeds")}
+        clip["pred_masks"] = clip["pred_masks"].cuda()
+        fi = fx.t(f"clip{i}::frame_idx").tolist()
+        out.append((fi, Clips(fi, clip)))
+    return out
+
+
+def _tracker(fx):
+    from mdqe_cvpr2023_amd.tracking import OverTracker
+    return OverTracker(fx.i("MAXI"), fx.i("T"), fx.i("WIN"), 1, fx.i("K"), 4, fx.i("E"), tuple(int(v) for v in fx.z["HW"]),
+                       torch.device("cuda"), fx.f("THR"))
+
+
+@pytest.mark.parametrize("mode", ["per_clip", "runs"])
+def test_hip_tracker_matches_reference_sequence(mode):
+    fx = Fixture("tracker_seq")
+    trk = _tracker(fx)
+    clips = _clips(fx)
+    saved, n = 0, len(clips)
+    run = []
+    for i, (fi, clip) in enumerate(clips):
+        last = i == n - 1
+        flush = last or (fi[0] + 1 >= fx.i("WIN") * (saved + 1))
+        if mode == "per_clip":
+            trk.update(clip)
+            assert trk.num_inst == fx.i(f"clip{i}::num_inst_after")
+        else:
+            run.append(clip)
+            if flush:
+                trk.update_many(run)                       # every clip since the previous flush in one native call
+                run = []
+                assert trk.num_inst == fx.i(f"clip{i}::num_inst_after")
+        if flush:
+            c, m = trk.get_result(last)
+            assert maxdiff(c, fx.t(f"win{saved}::cls")) < 1e-6
+            ref = fx.t(f"win{saved}::masks")
+            assert m.shape == ref.shape and maxdiff(m.cpu(), ref) < 1e-5
+            saved += 1
+    assert saved == fx.i("n_windows")
+
+
+def test_hip_tracker_more_than_128_new_tracks_in_one_clip():
+    """A clip may deliver up to min(n_query, 10*DETECTIONS_PER_IMAGE) = 150 instances and on the first clip each becomes a track
+    (the accumulate kernel takes 128 pairs per launch)."""
+    import numpy as np
+    from mdqe_cvpr2023_amd.tracking import Clips, OverTracker
+    n, hw = 150, (8, 12)
+    trk = OverTracker(160, 2, 4, 1, 3, 4, 16, hw, torch.device("cuda"), 0.1)
+    g = torch.Generator().manual_seed(0)
+    masks = torch.randn(n, 2, *hw, generator=g).cuda()
+    host = {"scores": np.full(n, 0.9, np.float32), "cls_probs": np.full((n, 3), 0.5, np.float32),
+            "query_embeds": torch.randn(n, 16, generator=g).numpy()}
+    trk.update(Clips([0, 1], {"pred_masks": masks, "host": host}))
+    assert trk.num_inst == n
+    c, m = trk.get_result(True)
+    assert m.shape == (n, 2) + hw and torch.equal(m, masks)
