@@ -1,0 +1,461 @@
+// Per-clip stages of the MDQE eval path as a handful of gfx950 kernels (SURVEY.md §8 a11, a12 glue, a15):
+// inter-frame query association, decoder initialisation gathers, iterative box refinement + clip boxes,
+// time-softmax fusion, and `inference_clip` (mdqe/mdqe.py:368-428) for a whole BATCH of clips: score sort /
+// threshold / near-duplicate removal, the fused dynamic-mask kernel (einsum 'qm,mthw->qthw' :384 with the blank test,
+// mask-quality sums and the half-resolution soft / hard maps of the NMS in its epilogue), the soft-IoU NMS matrix and
+// the final per-clip top-k.  Every reduction runs in a fixed order: results do not depend on the launch schedule.
+#include "common.h"
+
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------------
+// a11: inter-frame query association (transformer_dec.py:111-145).  For clip b, frame t, centre-frame query k:
+//   idx[b,t,k] = argmax_q  e[f(b,t), q] . e[f(b,ct), k]   over the q whose grid cell lies within +-w*|t-ct| cells of k's
+// (softmax is monotone: its arg-max is the arg-max of the masked similarity; first maximum wins).
+// One block per (b, t, 64 centre queries); the frame's embeddings [Q, E] go through LDS, the block's centre rows are
+// register-resident; every lane reads the same LDS row -> broadcast reads.
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ void __launch_bounds__(64)
+clip_assoc_kernel(const float* __restrict__ emb, const int* __restrict__ fidx, int T, int Q, int ct, float wdw, int nb,
+                  int* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float sE[];          // [Q][E]
+  const int bt = blockIdx.y, b = bt / T, t = bt % T;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const float* et = emb + (long)fidx[b * T + t] * Q * E;
+  const float* ec = emb + (long)fidx[b * T + ct] * Q * E;
+  for (int i = threadIdx.x; i < Q * (E / 4); i += 64)
+    *reinterpret_cast<f32x4*>(sE + i * 4) = *reinterpret_cast<const f32x4*>(et + i * 4);
+  __syncthreads();
+  if (k >= Q) return;
+  float c[E];
+#pragma unroll
+  for (int e = 0; e < E; e += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ec + (long)k * E + e);
+    c[e] = v[0]; c[e + 1] = v[1]; c[e + 2] = v[2]; c[e + 3] = v[3];
+  }
+  const float w = wdw * (float)abs(t - ct);
+  const int ki = k / nb, kj = k % nb;
+  float best = -INFINITY;
+  int bi = 0;
+  bool have = false;
+  for (int q = 0; q < Q; ++q) {
+    const int qi = q / nb, qj = q % nb;
+    if ((float)abs(qi - ki) > w || (float)abs(qj - kj) > w) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sE + q * E + e);
+      s += v[0] * c[e]; s += v[1] * c[e + 1]; s += v[2] * c[e + 2]; s += v[3] * c[e + 3];
+    }
+    if (!have || s > best) { best = s; bi = q; have = true; }
+  }
+  idx[((long)b * T + t) * Q + k] = bi;
+}
+
+extern "C" int mdqe_clip_assoc_f32(const float* emb, int Q, int E, const int* fidx, int Bc, int T, int ct, float wdw, int nb,
+                                   int* idx_out, void* stream) {
+  MDQE_REQUIRE(Q > 0 && Bc >= 0 && T > 0 && ct >= 0 && ct < T && nb > 0 && nb * nb == Q);
+  MDQE_REQUIRE(E == 16 || E == 32 || E == 64);
+  if (Bc == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(emb); MDQE_CHECK_PTR(fidx); MDQE_CHECK_PTR(idx_out);
+  MDQE_REQUIRE((size_t)Q * E * 4 <= 150 * 1024);
+  mdqe_clear_error();
+  const dim3 grid((Q + 63) / 64, Bc * T);
+  const size_t sm = (size_t)Q * E * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 64) hipLaunchKernelGGL(clip_assoc_kernel<64>, grid, dim3(64), sm, st, emb, fidx, T, Q, ct, wdw, nb, idx_out);
+  else if (E == 32) hipLaunchKernelGGL(clip_assoc_kernel<32>, grid, dim3(64), sm, st, emb, fidx, T, Q, ct, wdw, nb, idx_out);
+  else hipLaunchKernelGGL(clip_assoc_kernel<16>, grid, dim3(64), sm, st, emb, fidx, T, Q, ct, wdw, nb, idx_out);
+  return mdqe_launch_status();
+}
+
+// Decoder inputs of a batch of clips from the per-frame cache (transformer_dec.py:142-143,462,470-471):
+//   x[b,t,k,:] = content[f(b,t), idx[b,t,k], :]; ref[b,t,k] = (coords[f(b,t), idx[b,t,k]], 0.1, 0.1); x_inst[b,k] = x[b,ct,k]
+// idx == NULL: identity (single-frame clips).  One wave per row of C floats.
+__global__ void __launch_bounds__(256)
+clip_gather_init_kernel(const float* __restrict__ content, const float* __restrict__ coords, const int* __restrict__ fidx,
+                        const int* __restrict__ idx, int T, int Q, int C, int ct, long rows, float* __restrict__ x,
+                        float* __restrict__ ref, float* __restrict__ xinst) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int k = (int)(r % Q);
+  const long bt = r / Q;
+  const int t = (int)(bt % T);
+  const long b = bt / T;
+  const int q = idx ? idx[r] : k;
+  const long src = (long)fidx[bt] * Q + q;
+  const float* s = content + src * C;
+  float* d = x + r * C;
+  float* di = (t == ct) ? xinst + (b * Q + k) * C : nullptr;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(s + c);
+    *reinterpret_cast<f32x4*>(d + c) = v;
+    if (di) *reinterpret_cast<f32x4*>(di + c) = v;
+  }
+  if (lane == 0) *reinterpret_cast<f32x4*>(ref + r * 4) = f32x4{coords[src * 2], coords[src * 2 + 1], 0.1f, 0.1f};
+}
+
+extern "C" int mdqe_clip_gather_init_f32(const float* content, const float* coords, const int* fidx, const int* idx, int Bc, int T,
+                                         int Q, int C, int ct, float* x, float* ref, float* xinst, void* stream) {
+  MDQE_REQUIRE(Bc >= 0 && T > 0 && Q > 0 && C > 0 && C % 4 == 0 && ct >= 0 && ct < T);
+  if (Bc == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(content); MDQE_CHECK_PTR(coords); MDQE_CHECK_PTR(fidx); MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(ref); MDQE_CHECK_PTR(xinst);
+  mdqe_clear_error();
+  const long rows = (long)Bc * T * Q;
+  hipLaunchKernelGGL(clip_gather_init_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, content, coords, fidx,
+                     idx, T, Q, C, ct, rows, x, ref, xinst);
+  return mdqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12: iterative box refinement + clip-circumscribed box (transformer_dec.py:473-480,492-503; util/misc.py:478-482;
+// util/box_ops.py:8-19).  One thread per (clip, query): for every frame t
+//   box[b,t,q] = sigmoid(delta[b,t,q] + inverse_sigmoid(prev[b,t,q]))
+// and over the frames [t0, t1): the box spanned by the min of the clamped top-left and the max of the clamped bottom-right corners.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float inv_sigmoid(float x) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float a = fmaxf(x, 1e-5f), b = fmaxf(1.f - x, 1e-5f);
+  return logf(a / b);
+}
+
+__global__ void __launch_bounds__(256)
+box_refine_kernel(const float* __restrict__ delta, const float* __restrict__ prev, int T, int Q, int t0, int t1, long n,
+                  float* __restrict__ boxes, float* __restrict__ ibox) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // (b, q)
+  if (i >= n) return;
+  const long b = i / Q;
+  const int q = (int)(i % Q);
+  float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+  for (int t = 0; t < T; ++t) {
+    const long r = (b * T + t) * Q + q;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(delta + r * 4);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(prev + r * 4);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = 1.0f / (1.0f + expf(-(d[c] + inv_sigmoid(p[c]))));
+    *reinterpret_cast<f32x4*>(boxes + r * 4) = o;
+    if (t >= t0 && t < t1) {
+      const float ax = fminf(fmaxf(o[0] - 0.5f * o[2], 0.f), 1.f), ay = fminf(fmaxf(o[1] - 0.5f * o[3], 0.f), 1.f);
+      const float bx = fminf(fmaxf(o[0] + 0.5f * o[2], 0.f), 1.f), by = fminf(fmaxf(o[1] + 0.5f * o[3], 0.f), 1.f);
+      x0 = fminf(x0, ax); y0 = fminf(y0, ay); x1 = fmaxf(x1, bx); y1 = fmaxf(y1, by);
+    }
+  }
+  *reinterpret_cast<f32x4*>(ibox + i * 4) = f32x4{(x0 + x1) / 2.f, (y0 + y1) / 2.f, x1 - x0, y1 - y0};
+}
+
+extern "C" int mdqe_box_refine_f32(const float* delta, const float* prev, int Bc, int T, int Q, int t0, int t1, float* boxes,
+                                   float* ibox, void* stream) {
+  MDQE_REQUIRE(Bc >= 0 && T > 0 && Q > 0 && t0 >= 0 && t0 < t1);
+  if (Bc == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(delta); MDQE_CHECK_PTR(prev); MDQE_CHECK_PTR(boxes); MDQE_CHECK_PTR(ibox);
+  mdqe_clear_error();
+  const long n = (long)Bc * Q;
+  hipLaunchKernelGGL(box_refine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, delta, prev, T, Q, t0,
+                     t1 < T ? t1 : T, n, boxes, ibox);
+  return mdqe_launch_status();
+}
+
+// out = a + b (row-strided a, b, out; C % 4 == 0)
+__global__ void __launch_bounds__(256)
+add_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb, float* __restrict__ o, long ldo,
+                long rows, int C4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C4) return;
+  const long r = i / C4;
+  const int c = (int)(i % C4) * 4;
+  const f32x4 x = *reinterpret_cast<const f32x4*>(a + r * lda + c);
+  const f32x4 y = *reinterpret_cast<const f32x4*>(b + r * ldb + c);
+  *reinterpret_cast<f32x4*>(o + r * ldo + c) = x + y;
+}
+
+extern "C" int mdqe_add_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long rows, int C,
+                                 void* stream) {
+  MDQE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0);
+  if (rows == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(a); MDQE_CHECK_PTR(b); MDQE_CHECK_PTR(out);
+  mdqe_clear_error();
+  const long n = rows * (C / 4);
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo,
+                     rows, C / 4);
+  return mdqe_launch_status();
+}
+
+// Instance query from the frame-level queries (transformer_dec.py:374-376):
+//   out[b,q,:] = sum_t softmax_t(w[b,t,q]) * x[b,t,q,:]      (+ pos[b,q,:] into out2 when given)
+__global__ void __launch_bounds__(256)
+time_fuse_kernel(const float* __restrict__ w, const float* __restrict__ x, int T, int Q, int C4, long n, float* __restrict__ out,
+                 const float* __restrict__ pos, float* __restrict__ out2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C4) * 4;
+  const long bq = i / C4;
+  const int q = (int)(bq % Q);
+  const long b = bq / Q;
+  float m = -INFINITY;
+  for (int t = 0; t < T; ++t) m = fmaxf(m, w[(b * T + t) * Q + q]);
+  float den = 0.f;
+  for (int t = 0; t < T; ++t) den += expf(w[(b * T + t) * Q + q] - m);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t) {
+    const float p = expf(w[(b * T + t) * Q + q] - m) / den;
+    acc += p * *reinterpret_cast<const f32x4*>(x + ((b * T + t) * Q + q) * (long)(C4 * 4) + c);
+  }
+  *reinterpret_cast<f32x4*>(out + bq * (long)(C4 * 4) + c) = acc;
+  if (out2) *reinterpret_cast<f32x4*>(out2 + bq * (long)(C4 * 4) + c) = acc + *reinterpret_cast<const f32x4*>(pos + bq * (long)(C4 * 4) + c);
+}
+
+extern "C" int mdqe_time_fuse_f32(const float* w, const float* x, int Bc, int T, int Q, int C, float* out, const float* pos,
+                                  float* out_plus_pos, void* stream) {
+  MDQE_REQUIRE(Bc >= 0 && T > 0 && Q > 0 && C > 0 && C % 4 == 0);
+  if (Bc == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(w); MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(out);
+  if (out_plus_pos) MDQE_CHECK_PTR(pos);
+  mdqe_clear_error();
+  const long n = (long)Bc * Q * (C / 4);
+  hipLaunchKernelGGL(time_fuse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, x, T, Q, C / 4, n, out,
+                     pos, out_plus_pos);
+  return mdqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a15, step 1 (mdqe/mdqe.py:373-374): per clip, sort the queries by their best class score (descending; equal scores by
+// query index) and keep those >= min(thr, best).  One block of 256 threads per clip (Q <= 256): bitonic sort in LDS.
+// Outputs: order[b, r] = query at rank r, n_thr[b] = how many pass, inv_norm[b, r] = 1 / max(|embed|, 1e-12) of that query
+// (F.normalize, :376) for the near-duplicate test.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool before(float ka, int ia, float kb, int ib) { return ka > kb || (ka == kb && ia < ib); }
+
+__device__ __forceinline__ void bitonic256(float* key, int* val, int tid) {
+  for (int k = 2; k <= 256; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int p = tid ^ j;
+      if (p > tid) {
+        const bool up = (tid & k) == 0;
+        const float ka = key[tid], kb = key[p];
+        const int ia = val[tid], ib = val[p];
+        const bool a_first = before(ka, ia, kb, ib);
+        if (up != a_first) { key[tid] = kb; key[p] = ka; val[tid] = ib; val[p] = ia; }
+      }
+      __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+clip_rank_kernel(const float* __restrict__ cls, const float* __restrict__ emb, int Q, int K, int C, float thr, int* __restrict__ order,
+                 int* __restrict__ n_thr, float* __restrict__ inv_norm) {
+  __shared__ float key[256];
+  __shared__ int val[256];
+  __shared__ int cnt;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s = -INFINITY;
+  if (tid < Q) {
+    const float* c = cls + ((long)b * Q + tid) * K;
+    s = c[0];
+    for (int k = 1; k < K; ++k) s = fmaxf(s, c[k]);
+  }
+  key[tid] = s; val[tid] = tid;
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  bitonic256(key, val, tid);
+  const float top = key[0];
+  const float lim = fminf(top, thr);
+  if (tid < Q) {
+    order[(long)b * Q + tid] = val[tid];
+    if (key[tid] >= lim) atomicAdd(&cnt, 1);
+  }
+  __syncthreads();
+  if (tid == 0) n_thr[b] = cnt;
+  // norms of the ranked rows: one wave per row
+  const int lane = tid & 63;
+  for (int r = tid >> 6; r < Q; r += 4) {
+    const float* e = emb + ((long)b * Q + val[r]) * C;
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += e[c] * e[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) inv_norm[(long)b * Q + r] = 1.0f / fmaxf(sqrtf(a), 1e-12f);
+  }
+}
+
+// Gram matrix of the ranked embeddings of every clip: sim[b, p, q] = e[b, order[b,p]] . e[b, order[b,q]] for p, q < n_thr[b]
+// (only the tiles that hold a pair p < q are computed).  64x64 tile per block, 4x4 outputs per thread, K through LDS.
+__global__ void __launch_bounds__(256)
+clip_gram_kernel(const float* __restrict__ emb, const int* __restrict__ order, const int* __restrict__ n_thr, int Q, int C,
+                 float* __restrict__ sim) {
+  __shared__ float sA[16][65], sB[16][65];
+  const int b = blockIdx.z, tp = blockIdx.y, tq = blockIdx.x;
+  const int n = n_thr[b];
+  if (tp * 64 >= n || tq * 64 >= n || tq < tp) return;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  float acc[4][4] = {};
+  const int lr = tid >> 2, lc = (tid & 3) * 4;                // load: row lr (0..63), 4 columns at lc
+  const int pa = tp * 64 + lr, pb = tq * 64 + lr;
+  const float* ra = pa < n ? emb + ((long)b * Q + order[(long)b * Q + pa]) * C : nullptr;
+  const float* rb = pb < n ? emb + ((long)b * Q + order[(long)b * Q + pb]) * C : nullptr;
+  for (int k0 = 0; k0 < C; k0 += 16) {
+    f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = va;
+    if (ra && k0 + lc < C) va = *reinterpret_cast<const f32x4*>(ra + k0 + lc);
+    if (rb && k0 + lc < C) vb = *reinterpret_cast<const f32x4*>(rb + k0 + lc);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sA[lc + e][lr] = va[e]; sB[lc + e][lr] = vb[e]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = sA[k][ty * 4 + i]; bb[i] = sB[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = tp * 64 + ty * 4 + i, q = tq * 64 + tx * 4 + j;
+      if (p < n && q < n) sim[((long)b * Q + p) * Q + q] = acc[i][j];
+    }
+}
+
+// a15, step 2 (:375-379): drop rank q if max_{p<q, p passed the threshold} cos(e_p, e_q) >= 0.99 (skipped for a single
+// query), cap at max_keep.  Output: kept[b, j] = query index of the j-th kept rank (score order), n_keep[b].
+__global__ void __launch_bounds__(256)
+clip_dedup_kernel(const float* __restrict__ sim, const int* __restrict__ order, const int* __restrict__ n_thr,
+                  const float* __restrict__ inv_norm, int Q, int max_keep, int* __restrict__ kept, int* __restrict__ n_keep) {
+  __shared__ int flag[256];
+  const int b = blockIdx.x, q = threadIdx.x;
+  const int n = n_thr[b];
+  int keep = 0;
+  if (q < n) {
+    keep = 1;
+    if (n > 1) {
+      float ms = 0.f;                                         // triu(...).max(0): the zeros below the diagonal take part
+      const float nq = inv_norm[(long)b * Q + q];
+      for (int p = 0; p < q; ++p) ms = fmaxf(ms, sim[((long)b * Q + p) * Q + q] * inv_norm[(long)b * Q + p] * nq);
+      keep = ms < 0.99f;
+    }
+  }
+  flag[q] = keep;
+  __syncthreads();
+  if (q == 0) {
+    int c = 0;
+    for (int r = 0; r < n; ++r)
+      if (flag[r] && c < max_keep) kept[(long)b * Q + c++] = order[(long)b * Q + r];
+    n_keep[b] = c;
+  }
+}
+
+extern "C" int mdqe_clip_select_f32(const float* cls, const float* emb, int B, int Q, int K, int C, float thr, int max_keep,
+                                    int* order_ws, int* n_thr_ws, float* inv_norm_ws, float* sim_ws, int* kept, int* n_keep,
+                                    void* stream) {
+  MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && K > 0 && C > 0 && C % 4 == 0 && max_keep > 0);
+  if (B == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(cls); MDQE_CHECK_PTR(emb); MDQE_CHECK_PTR(order_ws); MDQE_CHECK_PTR(n_thr_ws); MDQE_CHECK_PTR(inv_norm_ws);
+  MDQE_CHECK_PTR(sim_ws); MDQE_CHECK_PTR(kept); MDQE_CHECK_PTR(n_keep);
+  mdqe_clear_error();
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(clip_rank_kernel, dim3(B), dim3(256), 0, st, cls, emb, Q, K, C, thr, order_ws, n_thr_ws, inv_norm_ws);
+  const int nt = (Q + 63) / 64;
+  hipLaunchKernelGGL(clip_gram_kernel, dim3(nt, nt, B), dim3(256), 0, st, emb, order_ws, n_thr_ws, Q, C, sim_ws);
+  hipLaunchKernelGGL(clip_dedup_kernel, dim3(B), dim3(256), 0, st, sim_ws, order_ws, n_thr_ws, inv_norm_ws, Q, max_keep, kept, n_keep);
+  return mdqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a15, step 3: the fused dynamic-mask kernel.  For every kept instance r of clip b (rows row0[b] .. row0[b]+n[b]):
+//   logits[r, t, y, x] = sum_m coef[b, kept[b, r-row0], m] * feats[f0[b]+t, y, x, m]          (einsum 'qm,mthw->qthw', :384)
+// feats are the channels-last mask features of the frame cache, so a thread owns ONE pixel: its M channels are loaded once
+// (M*4 contiguous bytes) and every instance of the clip is a dot product against coefficients broadcast from LDS; stores are
+// coalesced along the pixels.  Epilogue, per instance (mdqe/mdqe.py:387-413): blank test any(x > 0); mask quality
+// sum(sigmoid(x)[hard]) and count(hard), hard = sigmoid(x) > 0.5; on the half-resolution grid of the NMS (every 2nd pixel in
+// y and x, every t_step-th frame: F.interpolate(scale_factor=0.5) of :394-396) sigmoid(x) -> soft_h[r, .] and the hard bits
+// of ALL instances of the clip at that pixel -> hard_t[b, pixel, word] (bit r-row0), plus their sums.  Counts come from
+// wave ballots, float sums from a fixed-order butterfly; per-(instance, block) partials go to part[r, tile, 5] and are added
+// in tile order by mask_stats_reduce_kernel.
+// ------------------------------------------------------------------------------------------------
+struct ClipMeta { int row0[64]; int n[64]; int f0[64]; };
+
+template <int M>
+__global__ void __launch_bounds__(256)
+dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, const float* __restrict__ feats, int Q, int T, int H,
+                int W, int t_step, int c0, ClipMeta meta, float* __restrict__ logits, float* __restrict__ soft_h,
+                unsigned* __restrict__ hard_t, float* __restrict__ part, int n_tiles, int Mreal) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int bl = blockIdx.y;                       // clip within this launch
+  const int b = c0 + bl;
+  const int n = meta.n[bl], row0 = meta.row0[bl];
+  if (n == 0) return;
+  float* sC = sm;                                  // [n][M]
+  float* sP = sm + n * M;                          // [n][4 waves][5]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n * M; i += 256) {
+    const int r = i / M, m = i % M;
+    sC[i] = m < Mreal ? coef[((long)b * Q + kept[(long)b * Q + r]) * Mreal + m] : 0.f;
+  }
+  __syncthreads();
+  const long P = (long)T * H * W;
+  const int Hh = H / 2, Wh = W / 2;
+  const long Ph = (long)((T + t_step - 1) / t_step) * Hh * Wh;
+  const long pix = (long)blockIdx.x * 256 + tid;
+  const bool in = pix < P;
+  float f[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) f[m] = 0.f;
+  if (in) {
+    const float* fp = feats + ((long)meta.f0[bl] * H * W + pix) * Mreal;      // the clip's T frames are consecutive in the cache
+#pragma unroll
+    for (int m = 0; m < M; m += 4)
+      if (m < Mreal) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(fp + m);
+        f[m] = v[0]; f[m + 1] = v[1]; f[m + 2] = v[2]; f[m + 3] = v[3];
+      }
+  }
+  const int xx = (int)(pix % W);
+  const long t2 = pix / W;
+  const int yy = (int)(t2 % H), tt = (int)(t2 / H);
+  const bool grid_px = in && ((xx | yy) & 1) == 0 && (xx >> 1) < Wh && (yy >> 1) < Hh && (tt % t_step) == 0;
+  const long ho = ((long)(tt / t_step) * Hh + (yy >> 1)) * Wh + (xx >> 1);
+  unsigned bits = 0;
+  const int n_words = (n + 31) >> 5;
+  for (int r = 0; r < n; ++r) {
+    const float* c = sC + r * M;
+    float v = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; m += 4) {
+      const f32x4 cc = *reinterpret_cast<const f32x4*>(c + m);
+      v += cc[0] * f[m]; v += cc[1] * f[m + 1]; v += cc[2] * f[m + 2]; v += cc[3] * f[m + 3];
+    }
+    if (in) logits[(long)(row0 + r) * P + pix] = v;
+    const float s = 1.0f / (1.0f + expf(-v));
+    const bool hard = in && s > 0.5f;              // the reference thresholds the sigmoid (:412)
+    const bool hg = hard && grid_px;
+    const unsigned long long any_m = __ballot(in && v > 0.f), hard_m = __ballot(hard), hg_m = __ballot(hg);
+    float qn = hard ? s : 0.f, ss = grid_px ? s : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { qn += __shfl_xor(qn, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (lane == 0) {
+      float* p = sP + (r * 4 + wave) * 5;
+      p[0] = any_m ? 1.f : 0.f; p[1] = qn; p[2] = (float)__popcll(hard_m); p[3] = ss; p[4] = (float)__popcll(hg_m);
+    }
+    if (grid_px) soft_h[(long)(row0 + r) * Ph + ho] = s;
+    if (hg) bits |= 1u << (r & 31);
+    if ((r & 31) == 31 || r == n - 1) {
+      if (grid_px) hard_t[((long)b * Ph + ho) * n_words_cap(Q) + (r >> 5)] = bits;
+      bits = 0;
+    }
+  }
+  (void)n_words;
+  __syncthreads();
+  for (int i = tid; i < n * 5; i += 256) {
+    const int r = i / 5, k = i % 5;
+    const float* p = sP + r * 20 + k;
+    const float a = (k == 0) ? fmaxf(fmaxf(p[0], p[5]), fmaxf(p[10], p[15])) : ((p[0] + p[5]) + p[10]) + p[15];
+    part[((long)(row0 + r) * n_tiles + blockIdx.x) * 5 + k] = a;
+  }
+}

@@ -168,7 +168,7 @@ class MDQE(nn.Module):
                 break
         return clips
 
-    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None):
+    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None, h2d=None):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
@@ -219,6 +219,12 @@ class MDQE(nn.Module):
                 while nxt < le:
                     c1 = min(n_local, nxt + fbatch)
                     n_new = c1 - nxt
+                    if h2d:                                        # the upload chunks this pass reads (upload_frames)
+                        for end, ev in h2d:
+                            if end > nxt:
+                                fstream.wait_event(ev)
+                            if end >= c1:
+                                break
                     if rings[slot] is None:
                         first = self._frame_cache(frames_dev[nxt:c1], geo)
                         rings[slot] = {k: torch.empty((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for k, v in first.items()}
@@ -293,27 +299,94 @@ class MDQE(nn.Module):
             m.feed_many(buf)
         return m.finish()
 
+    H2D_CHUNK = 10                                  # frames per host->device copy (one event each)
+
+    def upload_frames(self, imgs):
+        """a1's host->device step (mdqe/mdqe.py:473-484 copies every frame inside the call): frames that arrive in host
+        memory go to ONE device buffer in chunks of a few frames on the model's copy stream, an event per chunk; the
+        per-frame stages wait only for the chunks they read, so the upload of the rest of the video runs under the first
+        pass (asynchronous when the frames are pinned; pageable frames are staged by the runtime).  A list whose tensors are
+        consecutive views of one buffer (a loader that decoded into one block) is copied chunk-wise too.
+        Returns (frames [L,3,h,w] on the device, [(end_frame, event), ...] or None when nothing is in flight)."""
+        if torch.is_tensor(imgs):
+            stack = imgs
+        else:
+            imgs = list(imgs)
+            if len(imgs) == 0:
+                raise RuntimeError("MDQE: a video needs at least one frame")
+            stack = None
+            f0 = imgs[0]
+            if not f0.is_cuda and f0.is_contiguous() and len(imgs) > 1:
+                nb = f0.numel() * f0.element_size()
+                if all(f.dtype == f0.dtype and f.shape == f0.shape and f.is_contiguous() and f.data_ptr() == f0.data_ptr() + i * nb
+                       for i, f in enumerate(imgs)):
+                    try:                                           # (as_strided checks the storage bounds)
+                        stack = f0.as_strided((len(imgs),) + tuple(f0.shape), (f0.numel(),) + tuple(f0.stride()))
+                    except RuntimeError:
+                        stack = None
+            if stack is None and f0.is_cuda:
+                stack = torch.stack(imgs)
+        if self.device.type != "cuda" and stack is None:
+            stack = torch.stack(imgs)
+        if stack is not None and (stack.is_cuda or self.device.type != "cuda"):
+            if stack.dtype not in (torch.uint8, torch.float32):
+                stack = stack.float()
+            return stack.to(self.device).contiguous(), None
+        # host frames -> device, chunked on the copy stream
+        first = stack[0] if stack is not None else imgs[0]
+        L = stack.shape[0] if stack is not None else len(imgs)
+        dt = first.dtype if first.dtype in (torch.uint8, torch.float32) else torch.float32
+        dev = torch.empty((L,) + tuple(first.shape), dtype=dt, device=self.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(self.device)
+        cs = self._copy_stream
+        cs.wait_stream(torch.cuda.current_stream(self.device))     # (the buffer may be a recycled block still read upstream)
+        dev.record_stream(cs)
+        events = []
+        with torch.cuda.stream(cs):
+            for a in range(0, L, self.H2D_CHUNK):
+                b = min(L, a + self.H2D_CHUNK)
+                if stack is not None:
+                    dev[a:b].copy_(stack[a:b], non_blocking=True)
+                else:
+                    for i in range(a, b):
+                        dev[i].copy_(imgs[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+                events.append((b, ev))
+        return dev, events
+
     def to_device_frames(self, imgs):
-        stack = imgs if torch.is_tensor(imgs) else torch.stack(list(imgs))
-        if stack.dtype not in (torch.uint8, torch.float32):
-            stack = stack.float()
-        return stack.to(self.device, non_blocking=True).contiguous()
+        """All frames on the device, visible to the current stream."""
+        dev, events = self.upload_frames(imgs)
+        if events:
+            torch.cuda.current_stream(self.device).wait_event(events[-1][1])
+        return dev
+
+    def _frames_for(self, video):
+        """(frames on the device, upload events, original (h0, w0)) of one input dict; the optional device-side resize
+        (the mapper's eval augmentation) needs the whole upload."""
+        frames_dev, h2d = self.upload_frames(video["image"])
+        h0, w0 = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
+        if self.resize_on_device and frames_dev.dtype == torch.uint8:
+            from .preprocess import resize_shortest_edge
+            if h2d:
+                torch.cuda.current_stream(self.device).wait_event(h2d[-1][1])
+                h2d = None
+            frames_dev = resize_shortest_edge(frames_dev, self.cfg.min_size_test, self.cfg.max_size_test)
+        return frames_dev, h2d, h0, w0
 
     def inference_vis(self, batched_inputs, trace=None):
         """mdqe/mdqe.py:291-366 with the compute-once schedule (same clips, same flush points)."""
         cfg = self.cfg
         video = batched_inputs[0]
-        frames_dev = self.to_device_frames(video["image"])
-        h0, w0 = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
-        if self.resize_on_device and frames_dev.dtype == torch.uint8:       # the mapper's eval augmentation, on the device
-            from .preprocess import resize_shortest_edge
-            frames_dev = resize_shortest_edge(frames_dev, cfg.min_size_test, cfg.max_size_test)
+        frames_dev, h2d, h0, w0 = self._frames_for(video)
         L, h, w = frames_dev.shape[0], int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
         out_size = (video.get("height", h0), video.get("width", w0))       # the mapper reports the ORIGINAL size as height/width
         geo = self.engine.geometry(h, w)
         ms = cfg.match_stride
         clips = self.clip_schedule(L, cfg.n_frames_test, cfg.clip_stride)
-        return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace), (h, w), out_size,
+        return self.merge_clips(self.iter_clip_results(frames_dev, clips, 0, trace, h2d=h2d), (h, w), out_size,
                                 (geo.Hp // ms, geo.Wp // ms), n_frames=L)
 
     def forward_stream(self, batches):
@@ -331,11 +404,7 @@ class MDQE(nn.Module):
                 raise RuntimeError("MDQE eval takes exactly one video per call (mdqe/mdqe.py:292)")
             cfg = self.cfg
             video = b[0]
-            frames_dev = self.to_device_frames(video["image"])
-            h0, w0 = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
-            if self.resize_on_device and frames_dev.dtype == torch.uint8:
-                from .preprocess import resize_shortest_edge
-                frames_dev = resize_shortest_edge(frames_dev, cfg.min_size_test, cfg.max_size_test)
+            frames_dev, h2d, h0, w0 = self._frames_for(video)
             L, h, w = frames_dev.shape[0], int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
             st = {"done_frames": False, "out_size": (video.get("height", h0), video.get("width", w0)), "hw": (h, w), "L": L}
             geo = self.engine.geometry(h, w)
@@ -345,7 +414,7 @@ class MDQE(nn.Module):
             def cb():
                 st["done_frames"] = True
                 look_ahead(st)
-            st["gen"] = self.iter_clip_results(frames_dev, clips, 0, None, primed=True, on_frames_queued=cb)
+            st["gen"] = self.iter_clip_results(frames_dev, clips, 0, None, primed=True, on_frames_queued=cb, h2d=h2d)
             next(st["gen"])
             return st
 

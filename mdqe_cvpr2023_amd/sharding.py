@@ -220,7 +220,7 @@ class _Job:
         any_fr = next(iter(chunk_frames.values()), like)
         if any_fr is None:
             raise ValueError("a rank that owns no chunk of a video must pass `like` (any [.., h, w] tensor on the frames' device)")
-        self.device = any_fr.device
+        self.device = any_fr.device if any_fr.is_cuda else torch.device(getattr(model, "device", any_fr.device))   # host frames: uploaded per chunk
         h, w = int(any_fr.shape[-2]), int(any_fr.shape[-1])
         geo = model.engine.geometry(h, w)
         ms = cfg.match_stride
@@ -239,7 +239,11 @@ class _Job:
         g = q * self.world + self.rank
         if q >= self.rounds or g >= len(self.plan):
             return None
-        gen = self.model.iter_clip_results(self.chunk_frames[g], self.plan[g][0], self.plan[g][1], primed=True)
+        fr, h2d = self.chunk_frames[g], None
+        if not fr.is_cuda and self.device.type == "cuda":          # a1's host->device copy of this chunk, chunked on the copy stream
+            fr, h2d = self.model.upload_frames(fr)
+        kw = {"h2d": h2d} if h2d else {}
+        gen = self.model.iter_clip_results(fr, self.plan[g][0], self.plan[g][1], primed=True, **kw)
         next(gen)
         return gen
 
