@@ -248,6 +248,50 @@ int mdqe_tracker_update_many(void* handle, float* bank_sum, float* bank_cnt, lon
 int mdqe_tracker_get_result(void* handle, int is_last, float* bank_sum, float* bank_cnt, long hw, float* out_masks,
                             float* carry, float* out_cls, int* n, int* ln, void* stream);
 
+/* ---- per-clip stages as batch kernels (csrc/clip_ops.hip) --------------------------------------------
+ * clip_assoc: inter-frame query association (transformer_dec.py:111-145): emb [frames, Q, E] (E in {16,32,64}), fidx [Bc, T]
+ *   (device int32: cache frame of (clip, t)) -> idx [Bc, T, Q] = arg-max_q of e[f(b,t),q].e[f(b,ct),k] over the cells within
+ *   +-wdw*|t-ct| of k's (Q = nb*nb grid cells).
+ * clip_gather_init (:142-143,462,470-471): x [Bc*T*Q, C] = content[f(b,t), idx], ref [Bc*T*Q, 4] = (coords[..], 0.1, 0.1),
+ *   xinst [Bc*Q, C] = x[b, ct]; idx NULL = identity.
+ * box_refine (:473-480,492-503; util/misc.py:478-482; util/box_ops.py:8-19): boxes = sigmoid(delta + inverse_sigmoid(prev))
+ *   [Bc*T*Q, 4]; ibox [Bc*Q, 4] = cxcywh of (min clamped top-left, max clamped bottom-right) over frames [t0, t1).
+ * add_rows: out = a + b on row-strided operands.  time_fuse (:374-376): out[b,q,:] = sum_t softmax_t(w[b,t,q]) x[b,t,q,:]
+ *   (+ pos into out_plus_pos when given). */
+int mdqe_clip_assoc_f32(const float* emb, int Q, int E, const int* fidx, int Bc, int T, int ct, float wdw, int nb,
+                        int* idx_out, void* stream);
+int mdqe_clip_gather_init_f32(const float* content, const float* coords, const int* fidx, const int* idx, int Bc, int T,
+                              int Q, int C, int ct, float* x, float* ref, float* xinst, void* stream);
+int mdqe_box_refine_f32(const float* delta, const float* prev, int Bc, int T, int Q, int t0, int t1, float* boxes,
+                        float* ibox, void* stream);
+int mdqe_add_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long rows, int C, void* stream);
+int mdqe_time_fuse_f32(const float* w, const float* x, int Bc, int T, int Q, int C, float* out, const float* pos,
+                       float* out_plus_pos, void* stream);
+
+/* inference_clip (mdqe/mdqe.py:368-428) for a batch of B clips.
+ * clip_select (:373-379): cls [B,Q,K], emb [B,Q,C] -> kept [B,Q] (query indices of the kept ranks, score order), n_keep [B]:
+ *   sort by best class score, keep >= min(thr, best), drop rank q if max_{p<q} cos(e_p, e_q) >= 0.99, cap at max_keep.
+ *   Workspaces: order [B,Q] int, n_thr [B] int, inv_norm [B,Q], sim [B,Q,Q].
+ * dyn_mask_nms: the fused dynamic-mask kernel + NMS.  HOST int arrays row0 / n / f0 [B] (first instance row, kept count,
+ *   first cache frame of the clip).  coef [B,Q,M], feats [frames,H,W,M] channels-last ->
+ *   logits [n_rows,T,H,W] = einsum 'qm,mthw->qthw' (:384); stats [n_rows,5] = (any(x>0), sum sigmoid(x)[hard], count(hard),
+ *   sum_half sigmoid(x), count_half(hard)), hard = sigmoid(x) > 0.5, half = F.interpolate(scale_factor=0.5) grid of :394-396
+ *   (every 2nd frame when T >= 5); mi [n_rows] = max_{p<q} soft-IoU (:398-405).  Scratch: soft_h [n_rows, Ph],
+ *   hard_t [B*Ph*ceil(Q/32)] words, part [mdqe_dyn_mask_workspace_floats()].
+ * clip_finalize (:408-419): out [n_rows, 2+K+C] = (score, label, class scores, embedding) of the j-th selected row of clip b at
+ *   row row0[b]+j, sel [n_rows] its instance row, n_sel [B].
+ * rows_gather: out[i,:] = src[idx[i],:]. */
+int mdqe_clip_select_f32(const float* cls, const float* emb, int B, int Q, int K, int C, float thr, int max_keep,
+                         int* order_ws, int* n_thr_ws, float* inv_norm_ws, float* sim_ws, int* kept, int* n_keep, void* stream);
+long mdqe_dyn_mask_workspace_floats(int n_rows, int T, int H, int W);
+int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const float* feats, int B, int Q, int M, int T, int H, int W,
+                          const int* row0_host, const int* n_host, const int* f0_host, float* logits, float* soft_h,
+                          unsigned* hard_t, float* part, float* stats, float* mi, void* stream);
+int mdqe_clip_finalize_f32(const float* cls, const float* emb, const int* kept, const float* stats, const float* mi, int B,
+                           int Q, int K, int C, float thr, const int* row0_host, const int* n_host, int* sel, int* n_sel,
+                           float* out, void* stream);
+int mdqe_rows_gather_f32(const float* src, const int* idx_dev, int n, long len, float* out, void* stream);
+
 /* ---- per-row statistics of dynamic mask logits (mdqe/mdqe.py:387-413) in one pass -------------------
  * logits [n, T, H, W].  stats[r] = (any(x>0), sum sigmoid(x)[x>0], count[x>0], sum_half sigmoid(x), count_half[x>0]);
  * half = every 2nd pixel in y and x (and every 2nd frame when t_step == 2), i.e. F.interpolate(scale_factor=0.5,

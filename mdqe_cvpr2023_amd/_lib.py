@@ -29,6 +29,15 @@ SIGNATURES = {
     "mdqe_tracker_update": [p, p, p, l, i, i, i, p, p, p, p, l, p, p, p],
     "mdqe_tracker_update_many": [p, p, p, l, i, p, p, p, p, p, p, p, p, p, p, p, p],
     "mdqe_tracker_get_result": [p, i, p, p, l, p, p, p, p, p, p],
+    "mdqe_clip_assoc_f32": [p, i, i, p, i, i, i, f, i, p, p],
+    "mdqe_clip_gather_init_f32": [p, p, p, p, i, i, i, i, i, p, p, p, p],
+    "mdqe_box_refine_f32": [p, p, i, i, i, i, i, p, p, p],
+    "mdqe_add_rows_f32": [p, l, p, l, p, l, l, i, p],
+    "mdqe_time_fuse_f32": [p, p, i, i, i, i, p, p, p, p],
+    "mdqe_clip_select_f32": [p, p, i, i, i, i, f, i, p, p, p, p, p, p, p],
+    "mdqe_dyn_mask_nms_f32": [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p],
+    "mdqe_clip_finalize_f32": [p, p, p, p, p, i, i, i, i, f, p, p, p, p, p, p],
+    "mdqe_rows_gather_f32": [p, p, i, l, p, p],
     "mdqe_mha_small_f32": [p, l, p, l, p, l, i, i, i, i, p],
     "mdqe_query_select_f32": [p, i, i, i, i, i, p, p, p],
     "mdqe_sample_levels_mean_f32": [p, i, l, i, p, i, p, p, p, i, p, p],
@@ -94,6 +103,8 @@ def load_library(path=None):
     h.mdqe_strerror.argtypes = [c_int]
     h.mdqe_get_gemm_precision.restype = c_int
     h.mdqe_get_gemm_precision.argtypes = []
+    h.mdqe_dyn_mask_workspace_floats.restype = c_long
+    h.mdqe_dyn_mask_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     h.mdqe_groupnorm_workspace_bytes.restype = c_long
     h.mdqe_groupnorm_workspace_bytes.argtypes = [c_int, c_int]
     for name, args in SIGNATURES.items():

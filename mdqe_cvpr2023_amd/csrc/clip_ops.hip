@@ -385,7 +385,7 @@ template <int M>
 __global__ void __launch_bounds__(256)
 dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, const float* __restrict__ feats, int Q, int T, int H,
                 int W, int t_step, int c0, ClipMeta meta, float* __restrict__ logits, float* __restrict__ soft_h,
-                unsigned* __restrict__ hard_t, float* __restrict__ part, int n_tiles, int Mreal) {
+                unsigned* __restrict__ hard_t, int nw, float* __restrict__ part, int n_tiles, int Mreal) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int bl = blockIdx.y;                       // clip within this launch
   const int b = c0 + bl;
@@ -422,7 +422,6 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
   const bool grid_px = in && ((xx | yy) & 1) == 0 && (xx >> 1) < Wh && (yy >> 1) < Hh && (tt % t_step) == 0;
   const long ho = ((long)(tt / t_step) * Hh + (yy >> 1)) * Wh + (xx >> 1);
   unsigned bits = 0;
-  const int n_words = (n + 31) >> 5;
   for (int r = 0; r < n; ++r) {
     const float* c = sC + r * M;
     float v = 0.f;
@@ -446,11 +445,10 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
     if (grid_px) soft_h[(long)(row0 + r) * Ph + ho] = s;
     if (hg) bits |= 1u << (r & 31);
     if ((r & 31) == 31 || r == n - 1) {
-      if (grid_px) hard_t[((long)b * Ph + ho) * n_words_cap(Q) + (r >> 5)] = bits;
+      if (grid_px) hard_t[((long)bl * Ph + ho) * nw + (r >> 5)] = bits;
       bits = 0;
     }
   }
-  (void)n_words;
   __syncthreads();
   for (int i = tid; i < n * 5; i += 256) {
     const int r = i / 5, k = i % 5;
@@ -458,4 +456,208 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
     const float a = (k == 0) ? fmaxf(fmaxf(p[0], p[5]), fmaxf(p[10], p[15])) : ((p[0] + p[5]) + p[10]) + p[15];
     part[((long)(row0 + r) * n_tiles + blockIdx.x) * 5 + k] = a;
   }
+}
+
+// stats[r, k] = partials of instance r added in tile order (k = 0: any -> max)
+__global__ void __launch_bounds__(256)
+mask_stats_reduce_kernel(const float* __restrict__ part, int n_tiles, long n_rows, float* __restrict__ stats) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * 5) return;
+  const long r = i / 5;
+  const int k = (int)(i % 5);
+  const float* p = part + r * n_tiles * 5 + k;
+  float a = p[0];
+  for (int t = 1; t < n_tiles; ++t) a = (k == 0) ? fmaxf(a, p[(long)t * 5]) : a + p[(long)t * 5];
+  stats[i] = a;
+}
+
+// Soft-IoU NMS inside each clip (mdqe/mdqe.py:398-408), rows in score order.  Block = (instance p of a clip); thread q > p:
+//   num = sum over the half-resolution pixels of soft_h[p, pix] * hard[q, pix]     (fixed pixel order)
+//   iou = num / (sum soft_h[p] + sum hard[q] - num + 1);  mi[q] = max_p iou        (non-negative floats: integer atomicMax)
+// soft_h[p, pix] is uniform over the block (scalar loads); the hard bits of all instances of the clip at a pixel sit in nw
+// consecutive words, so a wave reads one or two words per pixel.  Blank rows p (no positive logit) take no part (:387-390).
+__global__ void __launch_bounds__(256)
+mask_nms_kernel(const float* __restrict__ soft_h, const unsigned* __restrict__ hard_t, int nw, long Ph, const float* __restrict__ stats,
+                ClipMeta meta, int n_clips, float* __restrict__ mi) {
+  // blockIdx.x = instance row (global within this launch's clips); find its clip
+  int bl = 0;
+  const int row = blockIdx.x + meta.row0[0];
+  while (bl + 1 < n_clips && row >= meta.row0[bl + 1]) ++bl;
+  const int n = meta.n[bl], row0 = meta.row0[bl];
+  const int p = row - row0;
+  if (p >= n - 1) return;                                   // nothing ranks below the last row
+  if (!(stats[(long)row * 5] > 0.f)) return;                // blank p
+  const float* sp = soft_h + (long)row * Ph;
+  const unsigned* hb = hard_t + (long)bl * Ph * nw;
+  const float shp = stats[(long)row * 5 + 3];
+  for (int q = p + 1 + threadIdx.x; q < n; q += blockDim.x) {
+    const int w = q >> 5;
+    const unsigned bit = 1u << (q & 31);
+    float num = 0.f;
+    for (long x = 0; x < Ph; ++x)
+      if (hb[x * nw + w] & bit) num += sp[x];
+    const float den = shp + stats[(long)(row0 + q) * 5 + 4] - num;
+    const float iou = num / (den + 1.f);
+    atomicMax(reinterpret_cast<unsigned*>(mi + row0 + q), __float_as_uint(iou));
+  }
+}
+
+// a15, last step (:408-419) per clip: class scores x (1 - max IoU) x mask quality, best class, drop blank / suppressed rows,
+// keep the max(#(score > thr), 1) best of the rest (score order, equal scores by rank).  Writes, for the j-th selected row of
+// clip b, its instance row into sel[row0 + j] and (score, label, class scores [K], embedding [C]) into out[row0 + j]; n_sel[b].
+__global__ void __launch_bounds__(256)
+clip_finalize_kernel(const float* __restrict__ cls, const float* __restrict__ emb, const int* __restrict__ kept,
+                     const float* __restrict__ stats, const float* __restrict__ mi, int Q, int K, int C, float thr, int c0,
+                     ClipMeta meta, int* __restrict__ sel, int* __restrict__ n_sel, float* __restrict__ out) {
+  __shared__ float key[256];
+  __shared__ int val[256];
+  __shared__ int n_alive, n_above;
+  const int bl = blockIdx.x, b = c0 + bl, tid = threadIdx.x;
+  const int n = meta.n[bl], row0 = meta.row0[bl];
+  if (tid == 0) { n_alive = 0; n_above = 0; }
+  __syncthreads();
+  float sc = -1.f, f1 = 0.f, f2 = 0.f;
+  int lab = 0;
+  bool alive = false;
+  if (tid < n) {
+    const long row = row0 + tid;
+    const float m = mi[row];
+    const float quality = stats[row * 5 + 1] / (stats[row * 5 + 2] + 1e-6f);
+    f1 = 1.f - m; f2 = quality;
+    const float* c = cls + ((long)b * Q + kept[(long)b * Q + tid]) * K;
+    float best = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      const float v = (c[k] * f1) * f2;
+      if (v > best) { best = v; lab = k; }
+    }
+    alive = stats[row * 5] > 0.f && m < 0.5f;
+    if (alive) { atomicAdd(&n_alive, 1); if (best > thr) atomicAdd(&n_above, 1); }
+    sc = alive ? best : -1.f;
+  }
+  key[tid] = tid < n ? sc : -INFINITY;
+  val[tid] = tid;
+  __syncthreads();
+  bitonic256(key, val, tid);
+  int k_sel = n_above > 1 ? n_above : 1;
+  if (k_sel > n_alive) k_sel = n_alive;
+  if (tid == 0) n_sel[b] = k_sel;
+  // row `tid` learns its output position
+  __shared__ int posn[256];
+  posn[val[tid]] = tid;
+  __syncthreads();
+  if (tid < n) {
+    const int j = posn[tid];
+    if (j < k_sel) {
+      sel[row0 + j] = row0 + tid;
+      float* o = out + (long)(row0 + j) * (2 + K + C);
+      o[0] = sc; o[1] = (float)lab;
+      const long src = (long)b * Q + kept[(long)b * Q + tid];
+      for (int k = 0; k < K; ++k) o[2 + k] = (cls[src * K + k] * f1) * f2;
+      for (int c = 0; c < C; ++c) o[2 + K + c] = emb[src * C + c];
+    }
+  }
+}
+
+extern "C" long mdqe_dyn_mask_workspace_floats(int n_rows, int T, int H, int W) {
+  const long P = (long)T * H * W;
+  return (long)n_rows * ((P + 255) / 256) * 5;
+}
+
+// The batch form of inference_clip's mask part.  Host arrays (B entries): row0 (first instance row of the clip), n_keep,
+// f0 (first frame of the clip in `feats`).  coef [B, Q, M]; kept [B, Q] (device, from mdqe_clip_select_f32); feats
+// [frames, H, W, M]; logits [n_rows, T, H, W]; soft_h [n_rows, Ph]; hard_t: B * Ph * ceil(Q/32) words; part: workspace of
+// mdqe_dyn_mask_workspace_floats(n_rows, ..) floats; stats [n_rows, 5]; mi [n_rows].  Ph = ceil(T/t_step)*(H/2)*(W/2),
+// t_step = 2 when T >= 5.
+extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const float* feats, int B, int Q, int M, int T, int H,
+                                     int W, const int* row0_host, const int* n_host, const int* f0_host, float* logits,
+                                     float* soft_h, unsigned* hard_t, float* part, float* stats, float* mi, void* stream) {
+  MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && M > 0 && M <= 32 && M % 4 == 0 && T > 0 && H > 1 && W > 1);
+  if (B == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(row0_host); MDQE_CHECK_PTR(n_host); MDQE_CHECK_PTR(f0_host);
+  long n_rows = 0;
+  for (int b = 0; b < B; ++b) { MDQE_REQUIRE(n_host[b] >= 0 && n_host[b] <= Q && row0_host[b] == n_rows); n_rows += n_host[b]; }
+  if (n_rows == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(coef); MDQE_CHECK_PTR(kept); MDQE_CHECK_PTR(feats); MDQE_CHECK_PTR(logits); MDQE_CHECK_PTR(soft_h); MDQE_CHECK_PTR(hard_t);
+  MDQE_CHECK_PTR(part); MDQE_CHECK_PTR(stats); MDQE_CHECK_PTR(mi);
+  hipStream_t st = (hipStream_t)stream;
+  mdqe_clear_error();
+  const int t_step = T >= 5 ? 2 : 1;
+  const long P = (long)T * H * W;
+  const long Ph = (long)((T + t_step - 1) / t_step) * (H / 2) * (W / 2);
+  const int n_tiles = (int)((P + 255) / 256);
+  const int nw = (Q + 31) / 32;
+  if (hipMemsetAsync(mi, 0, (size_t)n_rows * sizeof(float), st) != hipSuccess) return MDQE_ELAUNCH;
+  for (int c0 = 0; c0 < B; c0 += 64) {
+    const int nc = B - c0 < 64 ? B - c0 : 64;
+    ClipMeta meta;
+    int nmax = 0;
+    for (int i = 0; i < 64; ++i) {
+      meta.row0[i] = i < nc ? row0_host[c0 + i] : 0; meta.n[i] = i < nc ? n_host[c0 + i] : 0; meta.f0[i] = i < nc ? f0_host[c0 + i] : 0;
+      if (meta.n[i] > nmax) nmax = meta.n[i];
+    }
+    if (nmax == 0) continue;
+    const int Mp = M == 24 ? 24 : 32;
+    const size_t sm = ((size_t)nmax * Mp + (size_t)nmax * 20) * sizeof(float);
+    unsigned* ht = hard_t + (long)c0 * Ph * nw;
+    if (M == 32)
+      hipLaunchKernelGGL(dyn_mask_kernel<32>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
+                         logits, soft_h, ht, nw, part, n_tiles, M);
+    else if (M == 24)
+      hipLaunchKernelGGL(dyn_mask_kernel<24>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
+                         logits, soft_h, ht, nw, part, n_tiles, M);
+    else
+      hipLaunchKernelGGL(dyn_mask_kernel<32>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
+                         logits, soft_h, ht, nw, part, n_tiles, M);
+  }
+  hipLaunchKernelGGL(mask_stats_reduce_kernel, dim3((unsigned)((n_rows * 5 + 255) / 256)), dim3(256), 0, st, part, n_tiles, n_rows, stats);
+  for (int c0 = 0; c0 < B; c0 += 64) {
+    const int nc = B - c0 < 64 ? B - c0 : 64;
+    ClipMeta meta;
+    int rows = 0;
+    for (int i = 0; i < 64; ++i) {
+      meta.row0[i] = i < nc ? row0_host[c0 + i] : 0; meta.n[i] = i < nc ? n_host[c0 + i] : 0; meta.f0[i] = 0;
+      rows += meta.n[i];
+    }
+    if (rows == 0) continue;
+    hipLaunchKernelGGL(mask_nms_kernel, dim3(rows), dim3(128), 0, st, soft_h, hard_t + (long)c0 * Ph * nw, nw, Ph, stats, meta, nc, mi);
+  }
+  return mdqe_launch_status();
+}
+
+// out [n_rows, 2+K+C] (only the first n_sel[b] rows of each clip are written), sel [n_rows], n_sel [B]
+extern "C" int mdqe_clip_finalize_f32(const float* cls, const float* emb, const int* kept, const float* stats, const float* mi, int B,
+                                      int Q, int K, int C, float thr, const int* row0_host, const int* n_host, int* sel, int* n_sel,
+                                      float* out, void* stream) {
+  MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && K > 0 && C > 0);
+  if (B == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(cls); MDQE_CHECK_PTR(emb); MDQE_CHECK_PTR(kept); MDQE_CHECK_PTR(row0_host); MDQE_CHECK_PTR(n_host); MDQE_CHECK_PTR(sel);
+  MDQE_CHECK_PTR(n_sel); MDQE_CHECK_PTR(out);
+  mdqe_clear_error();
+  for (int c0 = 0; c0 < B; c0 += 64) {
+    const int nc = B - c0 < 64 ? B - c0 : 64;
+    ClipMeta meta;
+    for (int i = 0; i < 64; ++i) { meta.row0[i] = i < nc ? row0_host[c0 + i] : 0; meta.n[i] = i < nc ? n_host[c0 + i] : 0; meta.f0[i] = 0; }
+    hipLaunchKernelGGL(clip_finalize_kernel, dim3(nc), dim3(256), 0, (hipStream_t)stream, cls, emb, kept, stats, mi, Q, K, C, thr, c0, meta,
+                       sel, n_sel, out);
+  }
+  return mdqe_launch_status();
+}
+
+// out[i, :] = src[idx[i], :]  (rows of `len` floats, len % 4 == 0)
+__global__ void __launch_bounds__(256)
+rows_gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, long len, float* __restrict__ out) {
+  const float* s = src + (long)idx[blockIdx.y] * len;
+  float* d = out + (long)blockIdx.y * len;
+  for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < len; e += (long)gridDim.x * blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(d + e) = *reinterpret_cast<const f32x4*>(s + e);
+}
+
+extern "C" int mdqe_rows_gather_f32(const float* src, const int* idx_dev, int n, long len, float* out, void* stream) {
+  MDQE_REQUIRE(n >= 0 && len >= 0 && len % 4 == 0);
+  if (n == 0 || len == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(src); MDQE_CHECK_PTR(idx_dev); MDQE_CHECK_PTR(out);
+  mdqe_clear_error();
+  long bx = (len / 4 + 255) / 256; if (bx > 32) bx = 32;
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream, src, idx_dev, len, out);
+  return mdqe_launch_status();
 }

@@ -524,12 +524,12 @@ class Engine:
         v = ops.linear(v_in.reshape(-1, C), sa.wv, sa.bv)
         return ops.mha_small(qk, v, B, Q, C, nh), sa
 
-    @staticmethod
-    def _clip_box(boxes, t0, t1):
-        """Circumscribed clip box, transformer_dec.py:473-480.  boxes [B,T,Q,4] -> [B*Q,4]."""
-        b = box_cxcywh_to_xyxy(boxes.transpose(1, 2)[:, :, t0:t1]).clamp(0, 1)
-        b = torch.cat([b[..., :2].min(-2)[0], b[..., 2:].max(-2)[0]], -1)
-        return box_xyxy_to_cxcywh(b).reshape(-1, 4).contiguous()
+    def _to_dev_i32(self, arr):
+        """Small host int array -> device int32 through pinned memory (asynchronous, no host sync)."""
+        h = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32))
+        if self.dev.type != "cuda":
+            return h.to(self.dev)
+        return h.pin_memory().to(self.dev, non_blocking=True)
 
     def decode_clip(self, coords, content, emb, values, geo):
         """One clip: coords [T,Q,2], content [T,Q,C], emb [T,Q,E], values [T,N,n_val*C] (contiguous frames)."""
@@ -540,34 +540,25 @@ class Engine:
     def decode_clips(self, cache, starts, T, geo):
         """Decoder for a BATCH of clips that all have T frames (clips are independent through a11-a14).
         cache: per-frame tensors of one chunk (coords/content/emb/vals, leading dim = frames); starts: first frame
-        (index into the cache) of each clip.  Returns cls [B,Q,K], mask_coeff [B,Q,M], query_embed [B,Q,C]."""
+        (index into the cache) of each clip.  Returns cls [B,Q,K], mask_coeff [B,Q,M], query_embed [B,Q,C].
+        Everything between the GEMMs is a clip_ops.hip kernel over the whole batch."""
         P, cfg = self.P, self.cfg
         Bc = len(starts)
-        fidx = torch.tensor([[a + t for t in range(T)] for a in starts], device=self.dev)      # [Bc,T]
-        coords, content, emb = cache["coords"][fidx], cache["content"][fidx], cache["emb"][fidx]
-        vals = cache["vals"]
-        Q, C = content.shape[2], content.shape[3]
+        fidx_h = np.asarray([[a + t for t in range(T)] for a in starts], dtype=np.int32).reshape(Bc, T)
+        fidx = self._to_dev_i32(fidx_h)                                                        # [Bc,T] cache frame of (clip, t)
+        content, vals = cache["content"], cache["vals"]
+        Q, C = content.shape[1], content.shape[2]
         nh, N = cfg.nheads, geo.N
         D, Tc = C // nh, cfg.n_frames
         ct = int((T - 1) / 2)
-        # inter-frame query association (transformer_dec.py:111-145), eval window = w/2
-        if T > 1:
-            sim = torch.einsum("btqc,bkc->btqk", emb, emb[:, ct])
-            wdw = cfg.window_inter_frame_asso / 2
-            itv = (torch.arange(T, device=self.dev) - ct).abs().view(T, 1, 1)
-            m = (P.relpos[None].float() > (wdw * itv)[..., None]).any(-1)                       # [T,Q,K]
-            idx = sim.masked_fill(m[None], float("-inf")).softmax(-2).argmax(-2)                # [Bc,T,K]
-            content = torch.gather(content, 2, idx[..., None].expand(-1, -1, -1, C))
-            coords = torch.gather(coords, 2, idx[..., None].expand(-1, -1, -1, 2))
+        # inter-frame query association (transformer_dec.py:111-145), eval window = w/2; T == 1: identity
+        idx = ops.clip_assoc(cache["emb"], fidx, ct, cfg.window_inter_frame_asso / 2, cfg.n_bins) if T > 1 else None
+        x, ref, x_inst = ops.clip_gather_init(content, cache["coords"], fidx, idx, ct)
         BT = Bc * T
-        x = content.reshape(BT * Q, C).contiguous()
-        ref = torch.cat([coords, torch.full_like(coords, 0.1)], -1).reshape(BT * Q, 4)
-        x_inst = content[:, ct].reshape(Bc * Q, C).contiguous()
         bbox = lambda z: self._mlp(ops.layernorm(z, *P.dec_norm), P.bbox_embed)
-        boxes = (bbox(x) + inverse_sigmoid(ref)).sigmoid().contiguous()
-        x_pos = ops.linear(boxes, *P.p2p)
         t0, t1 = max(ct - int((Tc - 1) / 2), 0), ct + Tc
-        ibox = self._clip_box(boxes.view(Bc, T, Q, 4), t0, t1)
+        boxes, ibox = ops.box_refine(bbox(x), ref, Bc, T, Q, t0, t1)                            # warm-up boxes + clip boxes (:473-480)
+        x_pos = ops.linear(boxes, *P.p2p)
         ipos = ops.linear(ibox, *P.p2p)
         itv = max(int(T / Tc), 1)
         ts = max(ct - int((Tc - 1) / 2) * itv, 0)
@@ -579,41 +570,43 @@ class Engine:
         LP = cfg.n_levels * cfg.dec_points
         TP = Tc * cfg.dec_points
         vals2 = vals.view(-1, vals.shape[-1])
-        vidx_sp = fidx.reshape(-1).to(torch.int32).contiguous()                             # value block of (clip, frame)
-        vidx_tp = fidx[:, 0].to(torch.int32).contiguous()                                   # first frame of each clip
+        vidx_sp = fidx.view(-1)                                                             # value block of (clip, frame)
+        vidx_tp = self._to_dev_i32(fidx_h[:, 0])                                            # first frame of each clip
+        xq = torch.empty_like(x)
+        xiq = torch.empty_like(x_inst)
         vi = 0
         for L in P.dec:
             # ---- box level: CA -> SA -> FFN (transformer_dec.py:415-422)
-            pr = ops.linear(x + x_pos, L.ca.wq, L.ca.bq)
+            pr = ops.linear(ops.add_rows(x, x_pos, out=xq), L.ca.wq, L.ca.bq)
             a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * LP], pr[:, 2 * nh * LP:], boxes.view(BT, Q, 4), lv_sp,
                                BT, Q, nh, D, cfg.n_levels, cfg.dec_points, mode=1, grid=P.grid_sp, v_brows=N, vidx=vidx_sp)
             vi += 1
             x = ops.linear_ln(a, L.ca.wo, L.ca.bo, x, *L.norm2)
             sx = x
-            o, sa = self._mha(L.sa, (x + x_pos).view(BT, Q, C), x.view(BT, Q, C), nh)
+            o, sa = self._mha(L.sa, ops.add_rows(x, x_pos, out=xq).view(BT, Q, C), x.view(BT, Q, C), nh)
             x = ops.linear_ln(o, sa.wo, sa.bo, x, *L.norm1)
             hdn = ops.linear(x, *L.linear1, act="gelu")
             x = ops.linear_ln(hdn, *L.linear2, x, *L.norm3)
             # ---- instance level (transformer_dec.py:361-409)
-            tw = ops.linear(x, *L.time_weights).view(Bc, T, Q, 1)
-            fused = (torch.softmax(tw, 1) * sx.view(Bc, T, Q, C)).sum(1).reshape(Bc * Q, C)
-            xi2 = fused
+            tw = ops.linear(x, *L.time_weights)                                             # [BT*Q, 1]
             if L.ta is not None:
-                pr = ops.linear(fused + ipos, L.ta.wq, L.ta.bq)
+                fused, fpos = ops.time_fuse(tw, sx, Bc, T, Q, pos=ipos)
+                pr = ops.linear(fpos, L.ta.wq, L.ta.bq)
                 a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * TP], pr[:, 2 * nh * TP:], ibox.view(Bc, Q, 4), lv_tp,
                                    Bc, Q, nh, D, Tc, cfg.dec_points, mode=1, grid=P.grid_tp, groups=len(geo.shapes),
                                    scale=1.0 / len(geo.shapes), v_brows=N, vidx=vidx_tp)
                 vi += 1
                 xi2 = ops.linear(a, L.ta.wo, L.ta.bo)
-            x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=xi2.contiguous())
-            o, sa = self._mha(L.sai, (x_inst + ipos).view(Bc, Q, C), x_inst.view(Bc, Q, C), nh)
+            else:
+                xi2 = ops.time_fuse(tw, sx, Bc, T, Q)
+            x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=xi2)
+            o, sa = self._mha(L.sai, ops.add_rows(x_inst, ipos, out=xiq).view(Bc, Q, C), x_inst.view(Bc, Q, C), nh)
             x_inst = ops.layernorm(ops.linear(o, sa.wo, sa.bo, residual=x_inst), *L.norm1_inst)
             hdn = ops.linear(x_inst, *L.linear1_inst, act="gelu")
             x_inst = ops.layernorm(ops.linear(hdn, *L.linear2_inst, residual=x_inst), *L.norm3_inst)
             # ---- iterative box refinement (transformer_dec.py:492-503)
-            boxes = (bbox(x) + inverse_sigmoid(boxes)).sigmoid().contiguous()
+            boxes, ibox = ops.box_refine(bbox(x), boxes, Bc, T, Q, t0, t1)
             x_pos = ops.linear(boxes, *P.p2p)
-            ibox = self._clip_box(boxes.view(Bc, T, Q, 4), t0, t1)
             ipos = ops.linear(ibox, *P.p2p)
         n = ops.layernorm(x_inst, *P.dec_norm)
         return {"cls": self._mlp(n, P.cls_embed, "sigmoid").view(Bc, Q, -1),
@@ -625,80 +618,62 @@ class Engine:
         """Single clip: out tensors [Q,*]; mask_feats [T,Hm,Wm,M]."""
         return self.inference_clips({k: v[None] for k, v in out.items()}, [mask_feats])[0]
 
-    def inference_clips(self, outs, mask_feats):
-        """outs: cls [B,Q,K], mask_coeff [B,Q,M], query_embed [B,Q,C]; mask_feats: list of B tensors [T,Hm,Wm,M]
-        (channels-last views of the frame cache).  Same decisions as the reference, computed for the whole batch
-        with masks instead of data-dependent shapes; 2 host syncs per batch."""
+    def inference_clips(self, outs, mask_feats, f0=None, T=None):
+        """outs: cls [B,Q,K], mask_coeff [B,Q,M], query_embed [B,Q,C]; mask_feats: the channels-last mask features of the
+        frame cache [frames,Hm,Wm,M] with f0 = first cache frame of every clip and T = frames per clip, or a
+        list of B views [T,Hm,Wm,M] of one such buffer.  Same decisions as the reference, computed for the whole batch by
+        six kernels (clip_ops.hip); 2 host syncs per batch: the kept counts, then the selected instances' vectors."""
         cfg = self.cfg
-        cls, coef, emb = outs["cls"], outs["mask_coeff"], outs["query_embed"]
+        cls, coef, emb = outs["cls"].contiguous(), outs["mask_coeff"].contiguous(), outs["query_embed"].contiguous()
         B, Q, K = cls.shape
+        C = emb.shape[-1]
         thr = cfg.apply_cls_thres
+        if isinstance(mask_feats, (list, tuple)):              # views of one cache buffer -> (base, first frame of each clip)
+            T = int(mask_feats[0].shape[0])
+            Hm, Wm, Md = (int(v) for v in mask_feats[0].shape[1:])
+            fbytes = Hm * Wm * Md * 4
+            p0 = min(m.data_ptr() for m in mask_feats)
+            if any((not m.is_contiguous()) or tuple(m.shape) != (T, Hm, Wm, Md) or (m.data_ptr() - p0) % fbytes for m in mask_feats):
+                raise RuntimeError("inference_clips: mask_feats must be contiguous [T,Hm,Wm,M] views of one channels-last buffer")
+            f0 = np.asarray([(m.data_ptr() - p0) // fbytes for m in mask_feats], dtype=np.int32)
+            nfr = int(f0.max()) + T
+            lo = min(mask_feats, key=lambda m: m.data_ptr())
+            feats = torch.as_strided(lo, (nfr, Hm, Wm, Md), (Hm * Wm * Md, Wm * Md, Md, 1))
+        else:
+            feats = mask_feats
+            f0 = np.asarray(f0, dtype=np.int32)
+            Hm, Wm, Md = (int(v) for v in feats.shape[1:])
         # -- score sort + threshold + near-duplicate embedding removal (:373-379)
-        ss, si = cls.max(-1)[0].sort(descending=True, dim=1)
-        keep = ss >= torch.clamp(ss[:, :1], max=thr)
-        e = F.normalize(torch.gather(emb, 1, si[..., None].expand(-1, -1, emb.shape[-1])), dim=-1)
-        sim = torch.bmm(e, e.transpose(1, 2)) * keep[:, :, None]           # rows of dropped queries do not count
-        ms = torch.triu(sim, diagonal=1).max(1)[0]
-        multi = keep.sum(1, keepdim=True) > 1                              # the reference skips this step for <=1 query
-        keep = keep & ((ms < 0.99) | ~multi)
-        keep = keep & (keep.cumsum(1) <= 10 * cfg.detections_per_image)
-        nz = keep.nonzero()                                                # host sync 1: [n_total, 2] (clip, sorted rank)
-        bi, ri = nz[:, 0], nz[:, 1]
-        qi = si[bi, ri]
-        n_tot = int(nz.shape[0])
-        counts = torch.bincount(bi, minlength=B).tolist()
-        cls_k, emb_k = cls[bi, qi], emb[bi, qi]
-        coef_k = coef[bi, qi].contiguous()
-        T, Hm, Wm, Md = mask_feats[0].shape
-        # -- dynamic mask product einsum('qm,mthw->qthw') (:384): NT GEMM per clip, rows = instances, "weights" = pixels
-        mp = torch.empty(n_tot, T, Hm, Wm, device=self.dev)
-        o = 0
-        for b in range(B):
-            if counts[b]:
-                ops.linear(coef_k[o:o + counts[b]], mask_feats[b].reshape(-1, Md), out=mp[o:o + counts[b]].view(counts[b], -1))
-            o += counts[b]
-        # one pass over the logits: blank test, mask-quality sums, half-resolution soft/hard maps + sums (:387-413)
-        stats, soft_h, hard_h = ops.mask_row_stats(mp)
-        nonblank = stats[:, 0] > 0
-        quality = stats[:, 1] / (stats[:, 2] + 1e-6)
-        sh, hh = stats[:, 3], stats[:, 4]
-        # -- soft-IoU NMS inside each clip (:398-408), rows in score order, blank rows excluded
-        mi = torch.zeros(n_tot, device=self.dev)
-        o = 0
-        for b in range(B):
-            n = counts[b]
-            if n > 1:
-                nbk = nonblank[o:o + n].float()
-                num = ops.linear(soft_h[o:o + n], hard_h[o:o + n]) * nbk[:, None]      # split-K NT GEMM over the pixels
-                den = sh[o:o + n, None] + hh[None, o:o + n] - num
-                iou = torch.triu(num / (den + 1), diagonal=1) * nbk[:, None]
-                mi[o:o + n] = iou.max(0)[0]
-            o += n
-        cls_k = cls_k * (1 - mi[:, None])
-        alive = nonblank & (mi < 0.5)
-        cls_k = cls_k * quality[:, None]
-        sc, lab = cls_k.max(-1)
-        # -- final per-clip top-k: max(#(score>thr),1) best alive rows (:416-419)
-        neg = torch.where(alive, sc, torch.full_like(sc, -1.0))
-        host = torch.stack([neg, (alive & (sc > thr)).float()], 1).cpu()   # host sync 2
-        sels, o = [], 0
-        for b in range(B):
-            n = counts[b]
-            sneg, above = host[o:o + n, 0], host[o:o + n, 1]
-            n_alive = int((sneg >= 0).sum())
-            order = torch.argsort(sneg, descending=True, stable=True)
-            k = min(max(int(above.sum()), 1), n_alive)
-            sels.append(order[:k] + o)
-            o += n
-        sel_all = torch.cat(sels).to(self.dev)
-        small = torch.cat([sc[:, None], cls_k, emb_k], 1)[sel_all].cpu().numpy()   # host sync 3: per-instance vectors for the tracker
+        kept, n_keep = ops.clip_select(cls, emb, thr, 10 * cfg.detections_per_image)
+        n = n_keep.cpu().numpy().astype(np.int32)                         # host sync 1: kept queries per clip
+        row0 = np.zeros(B, dtype=np.int32)
+        row0[1:] = np.cumsum(n)[:-1]
+        n_tot = int(n.sum())
+        # -- dynamic masks + blank test + quality + soft-IoU NMS (:384-408), then rescoring and the per-clip top-k (:408-419)
+        mp, stats, mi = ops.dyn_mask_nms(coef, kept, feats, row0, n, f0, T)
+        sel, n_sel, small = ops.clip_finalize(cls, emb, kept, stats, mi, thr, row0, n)
+        if self.dev.type == "cuda":
+            hs = torch.empty(small.shape, pin_memory=True)
+            hk = torch.empty(B, dtype=torch.int32, pin_memory=True)
+            hsel = torch.empty(sel.shape, dtype=torch.int32, pin_memory=True)
+            hs.copy_(small, non_blocking=True); hk.copy_(n_sel, non_blocking=True); hsel.copy_(sel, non_blocking=True)
+            torch.cuda.current_stream(self.dev).synchronize()          # host sync 2: the selected instances
+        else:
+            hs, hk, hsel = small, n_sel, sel
+        hs, hk, hsel = hs.numpy(), hk.numpy(), hsel.numpy()
+        rows = [hsel[row0[b]:row0[b] + hk[b]] for b in range(B)]
+        n_out = int(hk.sum())
+        pm = torch.empty(n_out, T, Hm, Wm, device=self.dev)
+        if n_out:
+            ops.rows_gather(mp, self._to_dev_i32(np.concatenate(rows)), out=pm)     # the selected instances' logits, clip by clip
+        labels = small[:, 1].long()
         results, o = [], 0
         for b in range(B):
-            k = len(sels[b])
-            t = sel_all[o:o + k]
-            hs = small[o:o + k]
-            results.append({"scores": sc[t], "pred_classes": lab[t], "cls_probs": cls_k[t], "pred_masks": mp[t],
-                            "query_embeds": emb_k[t],
-                            "host": {"scores": hs[:, 0], "cls_probs": hs[:, 1:1 + K], "query_embeds": hs[:, 1 + K:]}})
+            k, r0 = int(hk[b]), int(row0[b])
+            h = hs[r0:r0 + k]
+            d = small[r0:r0 + k]
+            results.append({"scores": d[:, 0], "pred_classes": labels[r0:r0 + k], "cls_probs": d[:, 2:2 + K], "pred_masks": pm[o:o + k],
+                            "query_embeds": d[:, 2 + K:],
+                            "host": {"scores": h[:, 0], "cls_probs": h[:, 2:2 + K], "query_embeds": h[:, 2 + K:]}})
             o += k
         return results

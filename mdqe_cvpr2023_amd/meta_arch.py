@@ -269,8 +269,9 @@ class MDQE(nn.Module):
             frames_queued()
             if cuda:
                 clip_stream.wait_event(cur["ready"])
-            outs = eng.decode_clips(cache, [c[0] - frame_offset - base for c in group], T, geo)
-            ress = eng.inference_clips(outs, [cache["mf"][c[0] - frame_offset - base:c[1] - frame_offset - base] for c in group])
+            starts = [c[0] - frame_offset - base for c in group]
+            outs = eng.decode_clips(cache, starts, T, geo)
+            ress = eng.inference_clips(outs, cache["mf"], starts, T)
             ready = None
             if cuda:
                 ready = torch.cuda.Event()

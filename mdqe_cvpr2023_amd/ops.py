@@ -460,3 +460,124 @@ def final_masks_rle(logits, inst_idx, factor, h, w, Ho, Wo, cap):
     check(lib.mdqe_final_masks_rle(ptr(logits), k, ptr(inst_idx), Fw, Hm, Wm, factor, h, w, Ho, Wo, cap, ptr(pos), ptr(n_pos),
                                    cur_stream()), "final_masks_rle")
     return pos, n_pos
+
+
+# ---- per-clip stages (csrc/clip_ops.hip) -----------------------------------------------------------------------------
+def clip_assoc(emb, fidx, ct, wdw, nb):
+    """emb [frames, Q, E]; fidx [Bc, T] int32 CUDA -> idx [Bc, T, Q] int32 (inter-frame query association)."""
+    _chk(emb, "emb"); _chk(fidx, "fidx", torch.int32)
+    Bc, T = fidx.shape
+    Q, E = emb.shape[1], emb.shape[2]
+    idx = torch.empty(Bc, T, Q, dtype=torch.int32, device=emb.device)
+    check(lib.mdqe_clip_assoc_f32(ptr(emb), Q, E, ptr(fidx), Bc, T, ct, float(wdw), nb, ptr(idx), cur_stream()), "clip_assoc")
+    return idx
+
+
+def clip_gather_init(content, coords, fidx, idx, ct):
+    """-> x [Bc*T*Q, C], ref [Bc*T*Q, 4], x_inst [Bc*Q, C]."""
+    _chk(content, "content"); _chk(coords, "coords"); _chk(fidx, "fidx", torch.int32); _chk(idx, "idx", torch.int32)
+    Bc, T = fidx.shape
+    Q, C = content.shape[1], content.shape[2]
+    x = torch.empty(Bc * T * Q, C, device=content.device)
+    ref = torch.empty(Bc * T * Q, 4, device=content.device)
+    xi = torch.empty(Bc * Q, C, device=content.device)
+    check(lib.mdqe_clip_gather_init_f32(ptr(content), ptr(coords), ptr(fidx), ptr(idx), Bc, T, Q, C, ct, ptr(x), ptr(ref), ptr(xi),
+                                        cur_stream()), "clip_gather_init")
+    return x, ref, xi
+
+
+def box_refine(delta, prev, Bc, T, Q, t0, t1):
+    """boxes = sigmoid(delta + inverse_sigmoid(prev)) [Bc*T*Q, 4]; clip boxes [Bc*Q, 4] over frames [t0, t1)."""
+    _chk(delta, "delta"); _chk(prev, "prev")
+    boxes = torch.empty(Bc * T * Q, 4, device=delta.device)
+    ibox = torch.empty(Bc * Q, 4, device=delta.device)
+    check(lib.mdqe_box_refine_f32(ptr(delta), ptr(prev), Bc, T, Q, t0, t1, ptr(boxes), ptr(ibox), cur_stream()), "box_refine")
+    return boxes, ibox
+
+
+def add_rows(a, b, out=None):
+    """out = a + b for 2-D row-strided fp32 operands of the same shape."""
+    rows, C = a.shape
+    if out is None:
+        out = torch.empty(rows, C, device=a.device)
+    check(lib.mdqe_add_rows_f32(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), rows, C, cur_stream()), "add_rows")
+    return out
+
+
+def time_fuse(w, x, Bc, T, Q, pos=None):
+    """out[b,q,:] = sum_t softmax_t(w[b,t,q]) x[b,t,q,:]  (-> (out, out + pos) when pos is given)."""
+    _chk(w, "w"); _chk(x, "x"); _chk(pos, "pos")
+    C = x.shape[-1]
+    out = torch.empty(Bc * Q, C, device=x.device)
+    out2 = torch.empty(Bc * Q, C, device=x.device) if pos is not None else None
+    check(lib.mdqe_time_fuse_f32(ptr(w), ptr(x), Bc, T, Q, C, ptr(out), ptr(pos), ptr(out2), cur_stream()), "time_fuse")
+    return (out, out2) if pos is not None else out
+
+
+def clip_select(cls, emb, thr, max_keep):
+    """cls [B,Q,K], emb [B,Q,C] -> kept [B,Q] int32 (query indices of the kept ranks, score order), n_keep [B] int32."""
+    _chk(cls, "cls"); _chk(emb, "emb")
+    B, Q, K = cls.shape
+    C = emb.shape[-1]
+    dev = cls.device
+    order = torch.empty(B, Q, dtype=torch.int32, device=dev)
+    n_thr = torch.empty(B, dtype=torch.int32, device=dev)
+    inv = torch.empty(B, Q, device=dev)
+    sim = torch.empty(B, Q, Q, device=dev)
+    kept = torch.empty(B, Q, dtype=torch.int32, device=dev)
+    n_keep = torch.empty(B, dtype=torch.int32, device=dev)
+    check(lib.mdqe_clip_select_f32(ptr(cls), ptr(emb), B, Q, K, C, float(thr), int(max_keep), ptr(order), ptr(n_thr), ptr(inv), ptr(sim),
+                                   ptr(kept), ptr(n_keep), cur_stream()), "clip_select")
+    return kept, n_keep
+
+
+def dyn_mask_nms(coef, kept, feats, row0, n, f0, T):
+    """The fused dynamic-mask kernel + NMS for a batch of clips.  coef [B,Q,M]; kept [B,Q] int32; feats [frames,H,W,M];
+    row0 / n / f0: host int32 numpy arrays [B].  -> logits [n_rows,T,H,W], stats [n_rows,5], mi [n_rows]."""
+    import numpy as np
+    _chk(coef, "coef"); _chk(kept, "kept", torch.int32); _chk(feats, "feats")
+    B, Q, M = coef.shape
+    H, W = feats.shape[1], feats.shape[2]
+    n_rows = int(n.sum())
+    dev = coef.device
+    t_step = 2 if T >= 5 else 1
+    Ph = ((T + t_step - 1) // t_step) * (H // 2) * (W // 2)
+    logits = torch.empty(n_rows, T, H, W, device=dev)
+    stats = torch.empty(n_rows, 5, device=dev)
+    mi = torch.empty(n_rows, device=dev)
+    if n_rows == 0:
+        return logits, stats, mi
+    soft_h = torch.empty(n_rows, Ph, device=dev)
+    hard_t = torch.empty(B * Ph * ((Q + 31) // 32), dtype=torch.int32, device=dev)
+    part = torch.empty(lib.mdqe_dyn_mask_workspace_floats(n_rows, T, H, W), device=dev)
+    row0 = np.ascontiguousarray(row0, dtype=np.int32); n = np.ascontiguousarray(n, dtype=np.int32); f0 = np.ascontiguousarray(f0, dtype=np.int32)
+    check(lib.mdqe_dyn_mask_nms_f32(ptr(coef), ptr(kept), ptr(feats), B, Q, M, T, H, W, row0.ctypes.data, n.ctypes.data, f0.ctypes.data,
+                                    ptr(logits), ptr(soft_h), ptr(hard_t), ptr(part), ptr(stats), ptr(mi), cur_stream()), "dyn_mask_nms")
+    return logits, stats, mi
+
+
+def clip_finalize(cls, emb, kept, stats, mi, thr, row0, n):
+    """-> sel [n_rows] int32, n_sel [B] int32, out [n_rows, 2+K+C] (rows row0[b] .. row0[b]+n_sel[b] of clip b are valid)."""
+    import numpy as np
+    B, Q, K = cls.shape
+    C = emb.shape[-1]
+    n_rows = int(n.sum())
+    dev = cls.device
+    sel = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+    n_sel = torch.empty(B, dtype=torch.int32, device=dev)
+    out = torch.empty(max(n_rows, 1), 2 + K + C, device=dev)
+    row0 = np.ascontiguousarray(row0, dtype=np.int32); n = np.ascontiguousarray(n, dtype=np.int32)
+    check(lib.mdqe_clip_finalize_f32(ptr(cls), ptr(emb), ptr(kept), ptr(stats), ptr(mi), B, Q, K, C, float(thr), row0.ctypes.data,
+                                     n.ctypes.data, ptr(sel), ptr(n_sel), ptr(out), cur_stream()), "clip_finalize")
+    return sel, n_sel, out
+
+
+def rows_gather(src, idx, out=None):
+    """out[i] = src[idx[i]] over the leading dim (idx int32 CUDA)."""
+    _chk(src, "src"); _chk(idx, "idx", torch.int32)
+    n = int(idx.numel())
+    row_len = src.numel() // max(src.shape[0], 1)
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), device=src.device)
+    check(lib.mdqe_rows_gather_f32(ptr(src), ptr(idx), n, row_len, ptr(out), cur_stream()), "rows_gather")
+    return out

@@ -1,0 +1,138 @@
+"""GPU: the per-clip batch kernels (csrc/clip_ops.hip) one by one against plain torch restatements of the reference lines
+they replace (transformer_dec.py:111-145,374-376,473-503; mdqe/mdqe.py:368-428), and the batched inference_clip against
+the oracle's per-clip `inference_clip` on crafted batches: ties at the thresholds, blank masks, near-duplicate embeddings,
+clips that keep one / all / more than max_keep queries."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mdqe_oracle as O
+from _golden import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def test_assoc_and_gather_init_vs_torch():
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for (nb, E, C, T, NF, starts) in ((14, 64, 256, 4, 9, [0, 3, 5]), (4, 16, 32, 3, 5, [2, 0]), (14, 64, 192, 2, 3, [1])):
+        Q = nb * nb
+        emb = torch.randn(NF, Q, E, generator=g)
+        content = torch.randn(NF, Q, C, generator=g)
+        coords = torch.rand(NF, Q, 2, generator=g)
+        fidx = torch.tensor([[a + t for t in range(T)] for a in starts], dtype=torch.int32)
+        ct = int((T - 1) / 2)
+        idx = ops.clip_assoc(emb.cuda(), fidx.cuda(), ct, 2.5, nb)
+        x, ref, xi = ops.clip_gather_init(content.cuda(), coords.cuda(), fidx.cuda(), idx, ct)
+        relpos = O.query_relpos_grid(nb)
+        for b, a in enumerate(starts):
+            fr = list(range(a, a + T))
+            q_r, c_r = O.inter_frame_query_association(content[fr], coords[fr], emb[fr], relpos, 2.5)
+            got = x.view(len(starts), T, Q, C)[b].cpu()
+            assert torch.equal(got, q_r)
+            assert torch.equal(ref.view(len(starts), T, Q, 4)[b, ..., :2].cpu(), c_r)
+            assert bool((ref.view(len(starts), T, Q, 4)[b, ..., 2:].cpu() == 0.1).all())
+            assert torch.equal(xi.view(len(starts), Q, C)[b].cpu(), q_r[ct])
+    # T == 1: identity
+    fidx = torch.tensor([[1], [0]], dtype=torch.int32).cuda()
+    x, ref, xi = ops.clip_gather_init(content.cuda(), coords.cuda(), fidx, None, 0)
+    assert torch.equal(x.view(2, Q, C)[0].cpu(), content[1]) and torch.equal(xi.view(2, Q, C)[1].cpu(), content[0])
+
+
+def test_box_refine_time_fuse_add_vs_torch():
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(1)
+    Bc, T, Q, C = 3, 4, 50, 64
+    delta = torch.randn(Bc * T * Q, 4, generator=g)
+    prev = torch.rand(Bc * T * Q, 4, generator=g)
+    prev[0] = torch.tensor([0.0, 1.0, 1e-7, 0.5])                       # the clamps of inverse_sigmoid
+    for (t0, t1) in ((0, 4), (1, 5), (0, 2)):
+        boxes, ibox = ops.box_refine(delta.cuda(), prev.cuda(), Bc, T, Q, t0, t1)
+        ref = (delta + O.inverse_sigmoid(prev)).sigmoid()
+        assert maxdiff(boxes.cpu(), ref) < 2e-6
+        want = O._clip_box(ref.view(Bc, T, Q, 4), T, t0, min(t1, T)) if False else None
+        b = O.box_cxcywh_to_xyxy(ref.view(Bc, T, Q, 4).transpose(1, 2)[:, :, t0:t1]).clamp(0, 1)
+        b = torch.cat([b[..., :2].min(-2)[0], b[..., 2:].max(-2)[0]], -1)
+        assert maxdiff(ibox.cpu(), O.box_xyxy_to_cxcywh(b).reshape(-1, 4)) < 2e-6
+    w = torch.randn(Bc * T * Q, 1, generator=g) * 3
+    x = torch.randn(Bc * T * Q, C, generator=g)
+    pos = torch.randn(Bc * Q, C, generator=g)
+    out, out2 = ops.time_fuse(w.cuda(), x.cuda(), Bc, T, Q, pos=pos.cuda())
+    ref = (torch.softmax(w.view(Bc, T, Q, 1), 1) * x.view(Bc, T, Q, C)).sum(1).reshape(Bc * Q, C)
+    assert maxdiff(out.cpu(), ref) < 2e-6 and maxdiff(out2.cpu(), ref + pos) < 2e-6
+    assert maxdiff(ops.time_fuse(w.cuda(), x.cuda(), Bc, T, Q).cpu(), ref) < 2e-6
+    a, b2 = torch.randn(77, 96, generator=g), torch.randn(77, 200, generator=g)
+    assert torch.equal(ops.add_rows(a.cuda(), b2.cuda()[:, 8:104]).cpu(), a + b2[:, 8:104])
+
+
+def _crafted_batch(g, B, Q, K, C, M, T, Hm, Wm):
+    cls = torch.rand(B, Q, K, generator=g) * 0.3
+    emb = torch.randn(B, Q, C, generator=g)
+    coef = torch.tanh(torch.randn(B, Q, M, generator=g))
+    mf = torch.relu(torch.randn(B + T - 1, Hm, Wm, M, generator=g))
+    return cls, emb, coef, mf
+
+
+@pytest.mark.parametrize("shape", [(5, 16, 5, 32, 32, 3, 16, 24), (3, 196, 25, 256, 32, 4, 24, 40), (2, 196, 25, 192, 24, 2, 16, 28),
+                                   (2, 36, 7, 64, 8, 5, 12, 20)])
+def test_batched_inference_clip_vs_oracle(shape):
+    """The whole of inference_clip for a batch of clips against the oracle clip by clip."""
+    from mdqe_cvpr2023_amd.config import MDQEConfig
+    from mdqe_cvpr2023_amd.engine import Engine
+    B, Q, K, C, M, T, Hm, Wm = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    cls, emb, coef, mf = _crafted_batch(g, B, Q, K, C, M, T, Hm, Wm)
+    thr = 0.25
+    # clip 0: several queries well above the threshold, two of them near-duplicates, one with a blank mask
+    cls[0, 3, 1] = 0.9; cls[0, 5, 2] = 0.8; cls[0, 7, 0] = 0.7; cls[0, 9, 1] = 0.6; cls[0, 11, 2] = 0.5
+    emb[0, 5] = emb[0, 3] * 1.5 + 1e-3 * torch.randn(C, generator=g)        # cosine > 0.99 with query 3 -> dropped
+    coef[0, 7] = -coef[0, 7].abs()                                           # features >= 0 -> all logits <= 0: blank
+    # clip 1: nothing reaches the threshold -> the best one alone (min(thr, top))
+    cls[1] *= 0.5
+    # clip 2: two identical masks (NMS suppresses the lower-scored one)
+    if B > 2:
+        cls[2, 1, 0] = 0.95; cls[2, 2, 1] = 0.85
+        coef[2, 2] = coef[2, 1]
+    cfg = MDQEConfig(backbone="custom", hidden_dim=C, num_classes=K, num_queries=Q, n_frames=T, n_frames_test=T, apply_cls_thres=thr,
+                     detections_per_image=2 if Q == 36 else 15)
+    eng = Engine.__new__(Engine)
+    eng.cfg, eng.dev = cfg, torch.device("cuda")
+    outs = {"cls": cls.cuda(), "mask_coeff": coef.cuda(), "query_embed": emb.cuda()}
+    mfd = mf.cuda()
+    res = eng.inference_clips(outs, mfd, list(range(B)), T)
+    res_v = eng.inference_clips(outs, [mfd[b:b + T] for b in range(B)])                       # the list-of-views form
+    hp = O.Hyper(hidden_dim=C, num_classes=K, n_frames=T, n_frames_test=T, apply_cls_thres=thr, detections_per_image=cfg.detections_per_image)
+    for b in range(B):
+        ref = O.inference_clip(hp, {"cls": cls[b:b + 1], "mask_coeff": coef[b:b + 1], "query_embed": emb[b:b + 1]},
+                               mf[b:b + T].permute(3, 0, 1, 2))
+        for r in (res[b], res_v[b]):
+            assert r["pred_masks"].shape == ref["pred_masks"].shape, (b, r["pred_masks"].shape, ref["pred_masks"].shape)
+            assert r["pred_classes"].tolist() == ref["pred_classes"].tolist()
+            assert maxdiff(r["pred_masks"].cpu(), ref["pred_masks"]) < 1e-4
+            assert maxdiff(r["scores"].cpu(), ref["scores"]) < 1e-5 and maxdiff(r["cls_probs"].cpu(), ref["cls_probs"]) < 1e-5
+            assert torch.equal(r["query_embeds"].cpu(), ref["query_embeds"])
+            assert np.array_equal(r["host"]["scores"], r["scores"].cpu().numpy())
+            assert np.array_equal(r["host"]["query_embeds"], r["query_embeds"].cpu().numpy())
+    assert res[1]["scores"].numel() == 1
+    assert 5 not in [int(q) for q in (emb[0] == res[0]["query_embeds"].cpu()[:, None]).all(-1).nonzero()[:, 1]]   # the duplicate is gone
+
+
+def test_batched_inference_clip_is_deterministic_and_handles_empty_batches():
+    from mdqe_cvpr2023_amd.config import MDQEConfig
+    from mdqe_cvpr2023_amd.engine import Engine
+    g = torch.Generator().manual_seed(5)
+    B, Q, K, C, M, T, Hm, Wm = 70, 16, 5, 32, 32, 2, 8, 12                  # more than 64 clips: two launches of the batch kernels
+    cls, emb, coef, mf = _crafted_batch(g, B, Q, K, C, M, T, Hm, Wm)
+    cls[:, 0, 0] = 0.9; cls[:, 1, 1] = 0.8
+    cfg = MDQEConfig(backbone="custom", hidden_dim=C, num_classes=K, num_queries=Q, n_frames=T, n_frames_test=T, apply_cls_thres=0.25)
+    eng = Engine.__new__(Engine)
+    eng.cfg, eng.dev = cfg, torch.device("cuda")
+    outs = {"cls": cls.cuda(), "mask_coeff": coef.cuda(), "query_embed": emb.cuda()}
+    a = eng.inference_clips(outs, mf.cuda(), list(range(B)), T)
+    b = eng.inference_clips(outs, mf.cuda(), list(range(B)), T)
+    hp = O.Hyper(hidden_dim=C, num_classes=K, n_frames=T, n_frames_test=T, apply_cls_thres=0.25)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert all(torch.equal(x[k], y[k]) for k in ("scores", "pred_classes", "cls_probs", "pred_masks", "query_embeds"))
+        ref = O.inference_clip(hp, {"cls": cls[i:i + 1], "mask_coeff": coef[i:i + 1], "query_embed": emb[i:i + 1]}, mf[i:i + T].permute(3, 0, 1, 2))
+        assert x["pred_classes"].tolist() == ref["pred_classes"].tolist() and maxdiff(x["pred_masks"].cpu(), ref["pred_masks"]) < 1e-4
