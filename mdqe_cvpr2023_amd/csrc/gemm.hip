@@ -344,7 +344,7 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   switch (tile) {
     case 1: return launch_gemm<128, 128, 2, 2>(p, st);
     case 2: return launch_gemm<128, 64, 2, 2>(p, st);
-    case 3: return launch_gemm<64, 64, 2, 2>(p, st);
+    case 3: case 7: case 8: case 9: return launch_gemm<64, 64, 2, 2>(p, st);
     default: return MDQE_EINVAL;
   }
 }

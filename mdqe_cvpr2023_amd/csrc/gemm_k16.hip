@@ -317,7 +317,7 @@ static int launch_k16_(const GemmParams& p, hipStream_t st) {
   return mdqe_launch_status();
 }
 
-// tile: 1 128x128, 2 128x64, 3 64x64 (as gemm.hip); the split-K reduce pass is launched by the caller
+// tile: 1 128x128, 2 128x64, 3 64x64 (as gemm.hip), 7 32x64, 8 32x128, 9 64x128; the split-K reduce pass is launched by the caller
 int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
   switch (tile) {
     case 1: return p.conv ? launch_k16_<128, 128, 2, 2, true>(p, st) : launch_k16_<128, 128, 2, 2, false>(p, st);
@@ -325,6 +325,9 @@ int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
     case 3: return p.conv ? launch_k16_<64, 64, 2, 2, true>(p, st) : launch_k16_<64, 64, 2, 2, false>(p, st);
     case 4: return p.conv ? MDQE_EINVAL : launch_k16_<64, 256, 1, 4, false>(p, st);      // full 256-wide rows per block
     case 5: return p.conv ? MDQE_EINVAL : launch_k16_<128, 256, 2, 4, false>(p, st);
+    case 7: return p.conv ? launch_k16_<32, 64, 1, 2, true>(p, st) : launch_k16_<32, 64, 1, 2, false>(p, st);   // small problems:
+    case 8: return p.conv ? launch_k16_<32, 128, 1, 2, true>(p, st) : launch_k16_<32, 128, 1, 2, false>(p, st); // more, shorter blocks
+    case 9: return p.conv ? launch_k16_<64, 128, 2, 2, true>(p, st) : launch_k16_<64, 128, 2, 2, false>(p, st);
     case 6:                                             // 64x256 with the LayerNorm epilogue (mdqe_gemm_ln_f32)
       if (p.conv || p.N != 256 || p.ksplit > 1 || !p.vec_ok || p.ln_g == nullptr || p.ln_b == nullptr) return MDQE_EINVAL;
       return launch_k16_<64, 256, 1, 4, false, true>(p, st);

@@ -122,8 +122,11 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
   constexpr int LP = L * P;                    // 16
   constexpr int D = 32, DV = 8;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) unsigned soff[32][LP][4];     // [group in block][sample][corner byte offset]
-  __shared__ __attribute__((aligned(16))) float swgt[32][LP][4];        // [group in block][sample][corner weight]
+  // [group in block][sample (+1 pad)][corner]: the pad makes the group stride 272 B, so the two groups served by one 16-lane
+  // pass of a ds_read/write_b128 fall on disjoint banks (a 256-B stride put every group on the same 4 banks: r01 PMC showed
+  // ~20 % of the kernel's cycles in LDS bank conflicts)
+  __shared__ __attribute__((aligned(16))) unsigned soff[32][LP + 1][4];  // corner byte offsets
+  __shared__ __attribute__((aligned(16))) float swgt[32][LP + 1][4];     // corner weights (bilinear x attention)
   __shared__ int sH[16], sW[16], sS[16];                                 // level table (indexed with a runtime level)
   if (threadIdx.x < 16) { sH[threadIdx.x] = lv.H[threadIdx.x]; sW[threadIdx.x] = lv.W[threadIdx.x]; sS[threadIdx.x] = lv.start[threadIdx.x]; }
   __syncthreads();
@@ -152,8 +155,9 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
     const int m = (within / DV) % M;
     const long t = (long)b * Q + q;
     // ---- this lane's two samples: i0 = 2j, i1 = 2j+1
-    const f32x4 o4 = *reinterpret_cast<const f32x4*>(offs + t * ldo + m * (2 * LP) + 4 * j);
-    const f32x2 l2 = *reinterpret_cast<const f32x2*>(logits + t * ldl + m * LP + 2 * j);
+    // offsets / logits / output are touched once: streamed past the caches so that they do not evict the value map's lines
+    const f32x4 o4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(offs + t * ldo + m * (2 * LP) + 4 * j));
+    const f32x2 l2 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(logits + t * ldl + m * LP + 2 * j));
     float mx = fmaxf(l2[0], l2[1]);
     mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
     const float e0 = expf(l2[0] - mx), e1 = expf(l2[1] - mx);
@@ -217,7 +221,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
       }
       __builtin_amdgcn_wave_barrier();
     }
-    *reinterpret_cast<f32x4*>(out + t * ldout + m * D + j * 4) = acc * scale;
+    __builtin_nontemporal_store(acc * scale, reinterpret_cast<f32x4*>(out + t * ldout + m * D + j * 4));
   }
 }
 

@@ -1,5 +1,6 @@
-"""GPU: the sharded path end to end with 2 ranks (gloo rendezvous, both ranks on cuda:0 -- RCCL needs one GPU
-per rank, which the 1-GPU test box cannot offer) must reproduce the single-process result."""
+"""GPU: the sharded path end to end with 2 ranks must reproduce the single-process result.  With two or more GPUs visible
+the ranks take one GPU each and talk over RCCL (backend "nccl": the production path of bench.py --gpus N); on a 1-GPU box
+both ranks share cuda:0 and rendezvous over gloo (RCCL needs one GPU per rank).  MDQE_TEST_BACKEND=gloo|nccl overrides."""
 import os
 import socket
 
@@ -32,9 +33,15 @@ def worker(rank, world, port, outdir):
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    cfg = _cfg()
+    backend = os.environ.get("MDQE_TEST_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dataclasses
+    cfg = dataclasses.replace(_cfg(), device="cuda:%d" % dev)
     model = MDQE(cfg, seed=5).eval()
     video = _video()
     L = video.shape[0]

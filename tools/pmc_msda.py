@@ -1,0 +1,36 @@
+"""Workload for the rocprofv3 --pmc passes over the fused encoder MSDA (msda_fused_v2_kernel<4,4>): the 40-frame encoder
+launch of R50_ovis_360 (5100 queries per frame, 8 heads x 32 channels, 4 levels x 4 points), offsets ~ N(0, 1) image-eighths
+like the model's (ms_deform_attn.py:155: one unit = W/8 pixels).  5 launches.  `python tools/pmc_msda.py time` prints timings."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mdqe_cvpr2023_amd import ops
+g = torch.Generator().manual_seed(0)
+Bf, Mh, D, L, P = 40, 8, 32, 4, 4
+shapes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+Nq = sum(a * c for a, c in shapes)
+starts = [0]
+for a, c in shapes[:-1]:
+    starts.append(starts[-1] + a * c)
+levels = ([s[0] for s in shapes], [s[1] for s in shapes], starts)
+proj = torch.randn(Bf * Nq, 256 + 3 * Mh * L * P, generator=g).cuda()
+ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(a) + 0.5) / a, (torch.arange(c) + 0.5) / c, indexing="ij"), -1).reshape(-1, 2).flip(-1)
+                 for a, c in shapes]).float().cuda().contiguous()
+out = torch.empty(Bf * Nq, 256, device="cuda")
+nq = 2 * Mh * L * P
+run = lambda: ops.msda_fused(proj[:, :256], proj[:, 256:256 + nq], proj[:, 256 + nq:], ref, levels, Bf, Nq, Mh, D, L, P, mode=0, v_brows=Nq, out=out)
+if len(sys.argv) > 1 and sys.argv[1] == "time":
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    comp = 18.3e6 * Bf
+    print("msda_fused enc 40 frames: %.1f us per launch = %.2f TB/s of the %.0f MB compulsory bytes" % (us, comp / us / 1e6, comp / 1e6))
+else:
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    print("done")
