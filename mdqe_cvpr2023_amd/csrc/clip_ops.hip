@@ -384,8 +384,8 @@ struct ClipMeta { int row0[64]; int n[64]; int f0[64]; };
 template <int M>
 __global__ void __launch_bounds__(256)
 dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, const float* __restrict__ feats, int Q, int T, int H,
-                int W, int t_step, int c0, ClipMeta meta, float* __restrict__ logits, float* __restrict__ soft_h,
-                unsigned* __restrict__ hard_t, int nw, float* __restrict__ part, int n_tiles, int Mreal) {
+                int W, int t_step, int c0, ClipMeta meta, float* __restrict__ logits, unsigned* __restrict__ hard_t, int nw,
+                float* __restrict__ part, int n_tiles, int Mreal) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int bl = blockIdx.y;                       // clip within this launch
   const int b = c0 + bl;
@@ -401,7 +401,6 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
   __syncthreads();
   const long P = (long)T * H * W;
   const int Hh = H / 2, Wh = W / 2;
-  const long Ph = (long)((T + t_step - 1) / t_step) * Hh * Wh;
   const long pix = (long)blockIdx.x * 256 + tid;
   const bool in = pix < P;
   float f[M];
@@ -420,7 +419,8 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
   const long t2 = pix / W;
   const int yy = (int)(t2 % H), tt = (int)(t2 / H);
   const bool grid_px = in && ((xx | yy) & 1) == 0 && (xx >> 1) < Wh && (yy >> 1) < Hh && (tt % t_step) == 0;
-  const long ho = ((long)(tt / t_step) * Hh + (yy >> 1)) * Wh + (xx >> 1);
+  const long Ph = (long)((T + t_step - 1) / t_step) * Hh * Wh;
+  const long ho = ((long)(tt / t_step) * Hh + (yy >> 1)) * Wh + (xx >> 1);      // index on the half-resolution grid
   unsigned bits = 0;
   for (int r = 0; r < n; ++r) {
     const float* c = sC + r * M;
@@ -442,9 +442,8 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
       float* p = sP + (r * 4 + wave) * 5;
       p[0] = any_m ? 1.f : 0.f; p[1] = qn; p[2] = (float)__popcll(hard_m); p[3] = ss; p[4] = (float)__popcll(hg_m);
     }
-    if (grid_px) soft_h[(long)(row0 + r) * Ph + ho] = s;
     if (hg) bits |= 1u << (r & 31);
-    if ((r & 31) == 31 || r == n - 1) {
+    if ((r & 31) == 31 || r == n - 1) {            // the hard bits of 32 instances of the clip at this half-resolution pixel
       if (grid_px) hard_t[((long)bl * Ph + ho) * nw + (r >> 5)] = bits;
       bits = 0;
     }
@@ -471,15 +470,19 @@ mask_stats_reduce_kernel(const float* __restrict__ part, int n_tiles, long n_row
   stats[i] = a;
 }
 
-// Soft-IoU NMS inside each clip (mdqe/mdqe.py:398-408), rows in score order.  Block = (instance p of a clip); thread q > p:
-//   num = sum over the half-resolution pixels of soft_h[p, pix] * hard[q, pix]     (fixed pixel order)
-//   iou = num / (sum soft_h[p] + sum hard[q] - num + 1);  mi[q] = max_p iou        (non-negative floats: integer atomicMax)
-// soft_h[p, pix] is uniform over the block (scalar loads); the hard bits of all instances of the clip at a pixel sit in nw
-// consecutive words, so a wave reads one or two words per pixel.  Blank rows p (no positive logit) take no part (:387-390).
+// Soft-IoU NMS inside each clip (mdqe/mdqe.py:398-408), rows in score order.  Block = instance p of a clip; thread = a
+// lower-ranked instance q > p of the same clip:
+//   num = sum over the half-resolution pixels of sigmoid(logits[p, pix]) where hard[q, pix]     (ascending pixel order)
+//   iou = num / (sum soft_h[p] + sum hard[q] - num + 1);  mi[q] = max_p iou          (non-negative floats: integer atomicMax)
+// The block walks the half-resolution grid in chunks of 1024 pixels: all threads stage row p's sigmoids and the clip's hard
+// words (dyn_mask_kernel: one word per 32 instances per pixel) in LDS with coalesced loads, then every thread runs over the
+// chunk reading both from LDS (the lanes of a wave read the same sigmoid and at most two distinct words: broadcasts).
+// Blank rows p (no positive logit) take no part (:387-390).
 __global__ void __launch_bounds__(256)
-mask_nms_kernel(const float* __restrict__ soft_h, const unsigned* __restrict__ hard_t, int nw, long Ph, const float* __restrict__ stats,
-                ClipMeta meta, int n_clips, float* __restrict__ mi) {
-  // blockIdx.x = instance row (global within this launch's clips); find its clip
+mask_nms_kernel(const float* __restrict__ logits, const unsigned* __restrict__ hard_t, int nw, int T, int H, int W, int t_step,
+                const float* __restrict__ stats, ClipMeta meta, int n_clips, float* __restrict__ mi) {
+  __shared__ float sS[1024];
+  __shared__ unsigned sH[1024 * 8];
   int bl = 0;
   const int row = blockIdx.x + meta.row0[0];
   while (bl + 1 < n_clips && row >= meta.row0[bl + 1]) ++bl;
@@ -487,16 +490,36 @@ mask_nms_kernel(const float* __restrict__ soft_h, const unsigned* __restrict__ h
   const int p = row - row0;
   if (p >= n - 1) return;                                   // nothing ranks below the last row
   if (!(stats[(long)row * 5] > 0.f)) return;                // blank p
-  const float* sp = soft_h + (long)row * Ph;
+  const int Hh = H / 2, Wh = W / 2;
+  const long Ph = (long)((T + t_step - 1) / t_step) * Hh * Wh;
+  const float* lp = logits + (long)row * T * H * W;
   const unsigned* hb = hard_t + (long)bl * Ph * nw;
-  const float shp = stats[(long)row * 5 + 3];
-  for (int q = p + 1 + threadIdx.x; q < n; q += blockDim.x) {
-    const int w = q >> 5;
-    const unsigned bit = 1u << (q & 31);
-    float num = 0.f;
-    for (long x = 0; x < Ph; ++x)
-      if (hb[x * nw + w] & bit) num += sp[x];
-    const float den = shp + stats[(long)(row0 + q) * 5 + 4] - num;
+  const int nwu = (n + 31) >> 5;                            // words in use (<= 8: n <= 256)
+  const int q = p + 1 + (int)threadIdx.x;
+  const bool act = q < n;
+  const int wq = act ? (q >> 5) : 0;
+  const unsigned bit = act ? (1u << (q & 31)) : 0u;
+  float num = 0.f;
+  for (long c0 = 0; c0 < Ph; c0 += 1024) {
+    const int cn = (int)((Ph - c0) < 1024 ? (Ph - c0) : 1024);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cn; i += blockDim.x) {
+      const long h = c0 + i;
+      const int x2 = (int)(h % Wh);
+      const long r2 = h / Wh;
+      const int y2 = (int)(r2 % Hh), t2 = (int)(r2 / Hh);
+      sS[i] = 1.0f / (1.0f + expf(-lp[((long)t2 * t_step * H + 2 * y2) * W + 2 * x2]));
+    }
+    for (int i = threadIdx.x; i < cn * nwu; i += blockDim.x) sH[i] = hb[(c0 + i / nwu) * nw + i % nwu];
+    __syncthreads();
+    if (act) {
+      const unsigned* hq = sH + wq;
+#pragma unroll 8
+      for (int i = 0; i < cn; ++i) num += (hq[i * nwu] & bit) ? sS[i] : 0.f;
+    }
+  }
+  if (act) {
+    const float den = stats[(long)row * 5 + 3] + stats[(long)(row0 + q) * 5 + 4] - num;
     const float iou = num / (den + 1.f);
     atomicMax(reinterpret_cast<unsigned*>(mi + row0 + q), __float_as_uint(iou));
   }
@@ -570,14 +593,14 @@ extern "C" long mdqe_dyn_mask_workspace_floats(int n_rows, int T, int H, int W) 
 // t_step = 2 when T >= 5.
 extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const float* feats, int B, int Q, int M, int T, int H,
                                      int W, const int* row0_host, const int* n_host, const int* f0_host, float* logits,
-                                     float* soft_h, unsigned* hard_t, float* part, float* stats, float* mi, void* stream) {
+                                     unsigned* hard_t, float* part, float* stats, float* mi, void* stream) {
   MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && M > 0 && M <= 32 && M % 4 == 0 && T > 0 && H > 1 && W > 1);
   if (B == 0) return MDQE_OK;
   MDQE_CHECK_PTR(row0_host); MDQE_CHECK_PTR(n_host); MDQE_CHECK_PTR(f0_host);
   long n_rows = 0;
   for (int b = 0; b < B; ++b) { MDQE_REQUIRE(n_host[b] >= 0 && n_host[b] <= Q && row0_host[b] == n_rows); n_rows += n_host[b]; }
   if (n_rows == 0) return MDQE_OK;
-  MDQE_CHECK_PTR(coef); MDQE_CHECK_PTR(kept); MDQE_CHECK_PTR(feats); MDQE_CHECK_PTR(logits); MDQE_CHECK_PTR(soft_h); MDQE_CHECK_PTR(hard_t);
+  MDQE_CHECK_PTR(coef); MDQE_CHECK_PTR(kept); MDQE_CHECK_PTR(feats); MDQE_CHECK_PTR(logits); MDQE_CHECK_PTR(hard_t);
   MDQE_CHECK_PTR(part); MDQE_CHECK_PTR(stats); MDQE_CHECK_PTR(mi);
   hipStream_t st = (hipStream_t)stream;
   mdqe_clear_error();
@@ -598,16 +621,15 @@ extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const f
     if (nmax == 0) continue;
     const int Mp = M == 24 ? 24 : 32;
     const size_t sm = ((size_t)nmax * Mp + (size_t)nmax * 20) * sizeof(float);
-    unsigned* ht = hard_t + (long)c0 * Ph * nw;
     if (M == 32)
       hipLaunchKernelGGL(dyn_mask_kernel<32>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
-                         logits, soft_h, ht, nw, part, n_tiles, M);
+                         logits, hard_t + (long)c0 * Ph * nw, nw, part, n_tiles, M);
     else if (M == 24)
       hipLaunchKernelGGL(dyn_mask_kernel<24>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
-                         logits, soft_h, ht, nw, part, n_tiles, M);
+                         logits, hard_t + (long)c0 * Ph * nw, nw, part, n_tiles, M);
     else
       hipLaunchKernelGGL(dyn_mask_kernel<32>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
-                         logits, soft_h, ht, nw, part, n_tiles, M);
+                         logits, hard_t + (long)c0 * Ph * nw, nw, part, n_tiles, M);
   }
   hipLaunchKernelGGL(mask_stats_reduce_kernel, dim3((unsigned)((n_rows * 5 + 255) / 256)), dim3(256), 0, st, part, n_tiles, n_rows, stats);
   for (int c0 = 0; c0 < B; c0 += 64) {
@@ -619,7 +641,11 @@ extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const f
       rows += meta.n[i];
     }
     if (rows == 0) continue;
-    hipLaunchKernelGGL(mask_nms_kernel, dim3(rows), dim3(128), 0, st, soft_h, hard_t + (long)c0 * Ph * nw, nw, Ph, stats, meta, nc, mi);
+    int nmax = 0;
+    for (int i = 0; i < nc; ++i) if (meta.n[i] > nmax) nmax = meta.n[i];
+    const int threads = nmax <= 65 ? 64 : nmax <= 129 ? 128 : 256;       // one thread per lower-ranked instance of the clip
+    hipLaunchKernelGGL(mask_nms_kernel, dim3(rows), dim3(threads), 0, st, logits, hard_t + (long)c0 * Ph * nw, nw, T, H, W, t_step, stats,
+                       meta, nc, mi);
   }
   return mdqe_launch_status();
 }

@@ -71,6 +71,7 @@ class MDQE(nn.Module):
         self.clip_priority = os.environ.get("MDQE_CLIP_PRIORITY", "1") != "0"       # per-clip stages on a high-priority stream
         self._work_stream = None
         self.stage_times = None
+        self.taper_passes = os.environ.get("MDQE_TAPER_PASSES", "0") != "0"   # half-size first / last frame pass (pipeline fill / drain)
 
     # ---- checkpoint contract ---------------------------------------------------------------------
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -183,6 +184,15 @@ class MDQE(nn.Module):
         Tmax = max((c[1] - c[0] for c in clips), default=1)
         fbatch = self.frame_batch if self.frame_batch > 0 else max(8, min(40, 306000 // max(geo.N, 1)))
         cap = Tmax - 1 + fbatch
+        # pass boundaries: uniform passes of `fbatch` frames, or (taper) a half-size first pass -- the clip stream starts after
+        # half a pass instead of a whole one -- and a last pass of at most half size -- the tail that runs with an idle frame
+        # stream (last decoder batch, tracker, mask read-back) is shorter
+        bounds = list(range(fbatch, n_local, fbatch)) + [n_local]
+        if self.taper_passes and n_local > fbatch:
+            h = max(fbatch // 2, 1)
+            bounds = [h] + list(range(h + fbatch, n_local, fbatch)) + [n_local]
+            if len(bounds) >= 2 and bounds[-1] - bounds[-2] > h and n_local - h - bounds[-2] >= 4:
+                bounds.insert(-1, n_local - h)
         cuda = frames_dev.is_cuda
         clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
         if cuda and self._frame_stream is None:
@@ -217,7 +227,7 @@ class MDQE(nn.Module):
                 if count == 0:
                     nxt = max(nxt, ls)                             # CLIP_STRIDE > clip length: the frames between two clips are never read
                 while nxt < le:
-                    c1 = min(n_local, nxt + fbatch)
+                    c1 = next(b for b in bounds if b > nxt)
                     n_new = c1 - nxt
                     if h2d:                                        # the upload chunks this pass reads (upload_frames)
                         for end, ev in h2d:

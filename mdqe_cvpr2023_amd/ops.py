@@ -540,19 +540,18 @@ def dyn_mask_nms(coef, kept, feats, row0, n, f0, T):
     H, W = feats.shape[1], feats.shape[2]
     n_rows = int(n.sum())
     dev = coef.device
-    t_step = 2 if T >= 5 else 1
-    Ph = ((T + t_step - 1) // t_step) * (H // 2) * (W // 2)
     logits = torch.empty(n_rows, T, H, W, device=dev)
     stats = torch.empty(n_rows, 5, device=dev)
     mi = torch.empty(n_rows, device=dev)
     if n_rows == 0:
         return logits, stats, mi
-    soft_h = torch.empty(n_rows, Ph, device=dev)
+    t_step = 2 if T >= 5 else 1
+    Ph = ((T + t_step - 1) // t_step) * (H // 2) * (W // 2)
     hard_t = torch.empty(B * Ph * ((Q + 31) // 32), dtype=torch.int32, device=dev)
     part = torch.empty(lib.mdqe_dyn_mask_workspace_floats(n_rows, T, H, W), device=dev)
     row0 = np.ascontiguousarray(row0, dtype=np.int32); n = np.ascontiguousarray(n, dtype=np.int32); f0 = np.ascontiguousarray(f0, dtype=np.int32)
     check(lib.mdqe_dyn_mask_nms_f32(ptr(coef), ptr(kept), ptr(feats), B, Q, M, T, H, W, row0.ctypes.data, n.ctypes.data, f0.ctypes.data,
-                                    ptr(logits), ptr(soft_h), ptr(hard_t), ptr(part), ptr(stats), ptr(mi), cur_stream()), "dyn_mask_nms")
+                                    ptr(logits), ptr(hard_t), ptr(part), ptr(stats), ptr(mi), cur_stream()), "dyn_mask_nms")
     return logits, stats, mi
 
 
