@@ -112,8 +112,13 @@ msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows, const
 // publishes 8 floats per sample in LDS; then every lane walks the 16 samples with two broadcast ds_read_b128 and four
 // bounds-checked buffer loads each (a corner outside the map carries an out-of-range offset and reads as 0: no branches).
 #define MSDA_OOB 0xF0000000u
-template <int L, int P>
-__global__ void __launch_bounds__(256)
+#define MSDA_DEFAULT_VARIANT 0
+// MAP: how a block's 32 (query, head) groups are chosen inside a batch element.  0: 4 consecutive queries x 8 heads.
+// 1: 32 consecutive queries of ONE head -- a head samples along its own direction (ms_deform_attn.py:81-87), so neighbouring
+// queries of the same head read neighbouring pixels of the same 128-B head slice: the block's lines overlap in L1.
+// 2: as 1 with the 32 queries an 8 x 4 patch of their level (overlap in y as well).
+template <int L, int P, int MAP, int WPE>
+__global__ void __launch_bounds__(256, WPE)
 msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode,
@@ -136,7 +141,10 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
   // dealt one per XCD (element b entirely on XCD b mod 8: its value map, 5.2 MB at 360p, is fetched into ONE 4-MB L2 instead
   // of all eight); the remainder -- and everything when B < 16 -- keeps the plain order so that no XCD idles.
   const int per_b = Q * M * DV;                // lanes per batch element
-  const int nbq = (per_b + 255) / 256;         // blocks per batch element
+  int nbq;                                     // blocks per batch element
+  if (MAP == 0) nbq = (per_b + 255) / 256;
+  else if (MAP == 1) nbq = ((Q + 31) / 32) * M;
+  else { nbq = 0; for (int l = 0; l < L; ++l) nbq += ((sW[l] + 7) / 8) * ((sH[l] + 3) / 4); nbq *= M; }
   const int Bn = B;
   const int full = (xcd_order && Bn >= 16) ? (Bn / 8) * 8 : 0;
   int b, blk;
@@ -149,10 +157,24 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
     b = full + r / nbq; blk = r - (r / nbq) * nbq;
   }
   {
-    const int within = blk * 256 + (int)threadIdx.x;
-    if (b >= B || within >= per_b) return;
-    const int q = within / (M * DV);
-    const int m = (within / DV) % M;
+    int q, m;
+    if (MAP == 0) {
+      const int within = blk * 256 + (int)threadIdx.x;
+      if (b >= B || within >= per_b) return;
+      q = within / (M * DV);
+      m = (within / DV) % M;
+    } else if (MAP == 1) {
+      m = blk % M;
+      q = (blk / M) * 32 + grp;
+      if (b >= B || q >= Q) return;
+    } else {
+      m = blk % M;
+      int tile = blk / M, l = 0, tw = (sW[0] + 7) / 8, nt = tw * ((sH[0] + 3) / 4);
+      while (l + 1 < L && tile >= nt) { tile -= nt; ++l; tw = (sW[l] + 7) / 8; nt = tw * ((sH[l] + 3) / 4); }
+      const int y = (tile / tw) * 4 + (grp >> 3), x = (tile % tw) * 8 + (grp & 7);
+      if (b >= B || y >= sH[l] || x >= sW[l]) return;
+      q = sS[l] + y * sW[l] + x;               // encoder: the queries ARE the tokens of the levels (one group, G == 1)
+    }
     const long t = (long)b * Q + q;
     // ---- this lane's two samples: i0 = 2j, i1 = 2j+1
     // offsets / logits / output are touched once: streamed past the caches so that they do not evict the value map's lines
@@ -227,6 +249,8 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
 
 static int g_msda_xcd_order = 1;   // tools/ A/B: 0 = plain block order in the fused kernel
 extern "C" int mdqe_debug_msda_xcd_order(int v) { g_msda_xcd_order = v; return MDQE_OK; }
+static int g_msda_variant = -1;    // tools/ A/B: block-to-query map (0, 1, 2) + 4 * (waves-per-SIMD hint 8 instead of none); -1 = by shape
+extern "C" int mdqe_debug_msda_variant(int v) { g_msda_variant = v; return MDQE_OK; }
 
 extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* vidx, const float* offs, long ldo,
                                    const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
@@ -252,11 +276,27 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
   // v2 (cooperative sample set-up, buffer loads): D == 32, 16 samples, value buffer addressable with 32-bit offsets
   const long vbytes = value_rows > 0 ? ((value_rows - 1) * ldv + (long)M * D) * 4 : 0;
   if (D == 32 && L * P == 16 && vbytes > 0 && vbytes < 0xF0000000L) {
-    const long nb2 = (long)B * (((long)Q * M * 8 + 255) / 256);                // exact grid: blocks per batch element x B
-#define LAUNCH2(LL, PP) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP>), dim3((unsigned)nb2), dim3(256), 0, st, value, (unsigned)vbytes, \
+    // block-to-query map: the patch / row forms need the queries to be the level tokens in raster order (encoder: mode 0, G == 1,
+    // Q == sum H*W); everything else keeps the plain order
+    long ntok = 0;
+    for (int l = 0; l < L; ++l) ntok += (long)lv.H[l] * lv.W[l];
+    int var = g_msda_variant >= 0 ? g_msda_variant : MSDA_DEFAULT_VARIANT;
+    int map = var & 3;
+    if (map == 2 && !(mode == 0 && G == 1 && ntok == Q)) map = (mode == 0) ? 1 : 0;
+    long nbq;
+    if (map == 0) nbq = ((long)Q * M * 8 + 255) / 256;
+    else if (map == 1) nbq = (long)((Q + 31) / 32) * M;
+    else { nbq = 0; for (int l = 0; l < L; ++l) nbq += (long)((lv.W[l] + 7) / 8) * ((lv.H[l] + 3) / 4); nbq *= M; }
+    const long nb2 = (long)B * nbq;                                            // exact grid: blocks per batch element x B
+#define LAUNCH2(LL, PP, MP, WP) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP, MP, WP>), dim3((unsigned)nb2), dim3(256), 0, st, value, (unsigned)vbytes, \
       ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total, g_msda_xcd_order)
-    if (L == 4 && P == 4) { LAUNCH2(4, 4); return mdqe_launch_status(); }
-    if (L == 2 && P == 8) { LAUNCH2(2, 8); return mdqe_launch_status(); }
+#define LAUNCH2M(LL, PP) do { const bool w8 = (var & 4) != 0; \
+      if (map == 0) { if (w8) LAUNCH2(LL, PP, 0, 8); else LAUNCH2(LL, PP, 0, 1); } \
+      else if (map == 1) { if (w8) LAUNCH2(LL, PP, 1, 8); else LAUNCH2(LL, PP, 1, 1); } \
+      else { if (w8) LAUNCH2(LL, PP, 2, 8); else LAUNCH2(LL, PP, 2, 1); } } while (0)
+    if (L == 4 && P == 4) { LAUNCH2M(4, 4); return mdqe_launch_status(); }
+    if (L == 2 && P == 8) { LAUNCH2M(2, 8); return mdqe_launch_status(); }
+#undef LAUNCH2M
 #undef LAUNCH2
   }
 #define LAUNCH(LL, PP) hipLaunchKernelGGL((msda_fused_kernel<LL, PP>), dim3((unsigned)nb), dim3(256), 0, st, value, ldv, v_brows, vidx, \

@@ -18,7 +18,26 @@ ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(a) + 0.5) / a, (torch.
 out = torch.empty(Bf * Nq, 256, device="cuda")
 nq = 2 * Mh * L * P
 run = lambda: ops.msda_fused(proj[:, :256], proj[:, 256:256 + nq], proj[:, 256 + nq:], ref, levels, Bf, Nq, Mh, D, L, P, mode=0, v_brows=Nq, out=out)
-if len(sys.argv) > 1 and sys.argv[1] == "time":
+if len(sys.argv) > 1 and sys.argv[1] == "variants":        # block-to-query maps x waves-per-SIMD hint, same box, output checked against variant 0
+    from mdqe_cvpr2023_amd._lib import lib
+    ref_out = None
+    for v in (0, 1, 2, 4, 5, 6):
+        lib.mdqe_debug_msda_variant(v)
+        run(); torch.cuda.synchronize()
+        if ref_out is None:
+            ref_out = out.clone()
+        same = bool(torch.equal(out, ref_out))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        print("variant %d (map %d, waves hint %s): %.1f us = %.2f TB/s compulsory, identical to variant 0: %s" % (v, v & 3, "8" if v & 4 else "-", us, 18.3e6 * Bf / us / 1e6, same), flush=True)
+    lib.mdqe_debug_msda_variant(-1)
+elif len(sys.argv) > 1 and sys.argv[1] == "time":
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
