@@ -11,7 +11,13 @@
 #include "gemm_params.h"
 #include <type_traits>
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
+// NS = LDS stages.  2 (one K-step of look-ahead) is enough when several blocks share a SIMD: one block's load latency hides behind
+// the others' MFMAs.  A launch of about one block per CU has nothing to hide behind -- every K-step then costs a full memory
+// latency (rocprof: 14 us for 16 K-steps of a [5292,256]x[256,256] product, ~0.8 us per step) -- so small grids take NS = 4:
+// three K-steps in flight, `s_waitcnt vmcnt` counting the stages issued behind the one about to be consumed.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false, int NS = 2>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN > 4) ? 2 : 4)
 gemm_nt_f32_k16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
@@ -118,12 +124,20 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) { const int row = BM + wn * (BN / WN) + j * 32 + lr; fb[j] = row * BK + ((lh ^ ((row >> 2) & 3)) << 2); }
 
-  issue(kt0, 0);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(kt0 + s, s);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for step kt has landed
-    __syncthreads();                                   // ... and everybody else's; all reads of the other buffer are done
-    if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
-    const float* sI = lds + (kt & 1) * (ROWS * BK);
+    // this wave's LDS-DMA for step kt has landed: at most the loads of the stages issued after it may still be in flight
+    if constexpr (NS == 2) {
+      wait_vmcnt<0>();
+    } else {
+      const int behind = nk - 1 - kt;                  // stages already issued behind step kt: min(NS - 2, behind)
+      if (behind >= 2) wait_vmcnt<2 * IPW>(); else if (behind == 1) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
+    }
+    __syncthreads();                                   // ... and everybody else's; all reads of the buffer refilled next are done
+    if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
+    const float* sI = lds + (kt % NS) * (ROWS * BK);
     f32x4 a0[MT], b0[NT], a1[MT], b1[NT];              // both 8-wide halves up front: the second hides behind 16 MFMAs
 #pragma unroll
     for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(sI + fa[i]);
@@ -307,14 +321,28 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   if constexpr (MT > 1 && NT > 1) sub(I1{}, I1{});
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
-static int launch_k16_(const GemmParams& p, hipStream_t st) {
+static int g_k16_stages = 0;       // tools/ A/B: 0 = by grid size, 2 / 4 = forced
+extern "C" int mdqe_debug_gemm_stages(int v) { g_k16_stages = v; return MDQE_OK; }
+
+template <int BM, int BN, int WM, int WN, bool CONV, bool LN, int NS>
+static int launch_k16_ns_(const GemmParams& p, hipStream_t st) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  size_t smem = 2 * (BM + BN) * 16 * sizeof(float);
+  size_t smem = (size_t)NS * (BM + BN) * 16 * sizeof(float);
   if (smem < (size_t)WM * WN * 4096) smem = (size_t)WM * WN * 4096;        // per-wave epilogue slices
-  auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV, LN>;
+  auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV, LN, NS>;
   hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(64 * WM * WN), smem, st, p);
   return mdqe_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
+static int launch_k16_(const GemmParams& p, hipStream_t st) {
+  if constexpr (!LN && BM * BN <= 64 * 64) {
+    // small tiles on a small grid (about one block per CU or less per SIMD wave slot): deep look-ahead
+    const long blocks = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.ksplit > 1 ? p.ksplit : 1);
+    const bool deep = g_k16_stages == 4 || (g_k16_stages == 0 && blocks <= 1024 && p.K >= 64);
+    if (deep) return launch_k16_ns_<BM, BN, WM, WN, CONV, LN, 4>(p, st);
+  }
+  return launch_k16_ns_<BM, BN, WM, WN, CONV, LN, 2>(p, st);
 }
 
 // tile: 1 128x128, 2 128x64, 3 64x64 (as gemm.hip), 7 32x64, 8 32x128, 9 64x128; the split-K reduce pass is launched by the caller

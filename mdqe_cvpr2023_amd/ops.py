@@ -11,6 +11,9 @@ from ._lib import check, cur_stream, lib, ptr, raw_stream
 
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "tanh": 4}
 
+if os.environ.get("MDQE_MSDA_VARIANT"):                 # tools/ A/B of the fused MSDA's block-to-query map (csrc/msda_fused.hip)
+    check(lib.mdqe_debug_msda_variant(int(os.environ["MDQE_MSDA_VARIANT"])), "msda_variant")
+
 _ws = {}
 
 
