@@ -11,10 +11,10 @@
 #include "gemm_params.h"
 #include <type_traits>
 
-// NS = LDS stages.  2 (one K-step of look-ahead) is enough when several blocks share a SIMD: one block's load latency hides behind
-// the others' MFMAs.  A launch of about one block per CU has nothing to hide behind -- every K-step then costs a full memory
-// latency (rocprof: 14 us for 16 K-steps of a [5292,256]x[256,256] product, ~0.8 us per step) -- so small grids take NS = 4:
-// three K-steps in flight, `s_waitcnt vmcnt` counting the stages issued behind the one about to be consumed.
+// NS = LDS stages.  2 (one K-step of look-ahead) is the default: several blocks share a SIMD and one block's load latency hides
+// behind the others' MFMAs.  NS = 4 (three K-steps in flight, `s_waitcnt vmcnt` counting the stages issued behind the one about
+// to be consumed) was built for launches of about one block per CU (rocprof: 14 us for the 16 K-steps of a
+// [5292,256]x[256,256] product) and measured at no gain, so it stays behind mdqe_debug_gemm_stages(4).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false, int NS = 2>
@@ -339,8 +339,10 @@ static int launch_k16_(const GemmParams& p, hipStream_t st) {
   if constexpr (!LN && BM * BN <= 64 * 64) {
     // small tiles on a small grid (about one block per CU or less per SIMD wave slot): deep look-ahead
     const long blocks = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.ksplit > 1 ? p.ksplit : 1);
-    const bool deep = g_k16_stages == 4 || (g_k16_stages == 0 && blocks <= 1024 && p.K >= 64);
-    if (deep) return launch_k16_ns_<BM, BN, WM, WN, CONV, LN, 4>(p, st);
+    // measured (tools/gemm_stages_ab.py, r02): no gain -- 14.8 vs 14.9 us on [5292,256]x[256,256], 10 us even for 16 blocks: the
+    // floor of these launches is not the look-ahead depth.  Kept as a measured alternative behind the debug switch.
+    (void)blocks;
+    if (g_k16_stages == 4) return launch_k16_ns_<BM, BN, WM, WN, CONV, LN, 4>(p, st);
   }
   return launch_k16_ns_<BM, BN, WM, WN, CONV, LN, 2>(p, st);
 }

@@ -280,7 +280,9 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
     // Q == sum H*W); everything else keeps the plain order
     long ntok = 0;
     for (int l = 0; l < L; ++l) ntok += (long)lv.H[l] * lv.W[l];
-    int var = g_msda_variant >= 0 ? g_msda_variant : MSDA_DEFAULT_VARIANT;
+    // default: the encoder (mode 0: the queries are the level tokens in raster order) takes map 1 -- 608 vs 635 us on the
+    // 40-frame launch with unstructured offsets (tools/pmc_msda.py variants), no difference end to end; the decoder keeps map 0
+    int var = g_msda_variant >= 0 ? g_msda_variant : (mode == 0 ? 1 : MSDA_DEFAULT_VARIANT);
     int map = var & 3;
     if (map == 2 && !(mode == 0 && G == 1 && ntok == Q)) map = (mode == 0) ? 1 : 0;
     long nbq;

@@ -71,7 +71,7 @@ class MDQE(nn.Module):
         self.clip_priority = os.environ.get("MDQE_CLIP_PRIORITY", "1") != "0"       # per-clip stages on a high-priority stream
         self._work_stream = None
         self.stage_times = None
-        self.taper_passes = os.environ.get("MDQE_TAPER_PASSES", "0") != "0"   # half-size first / last frame pass (pipeline fill / drain)
+        self.taper_passes = os.environ.get("MDQE_TAPER_PASSES", "1") != "0"   # half-size first / last frame pass (pipeline fill / drain)
 
     # ---- checkpoint contract ---------------------------------------------------------------------
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
