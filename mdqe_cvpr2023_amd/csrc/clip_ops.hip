@@ -415,9 +415,10 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
         f[m] = v[0]; f[m + 1] = v[1]; f[m + 2] = v[2]; f[m + 3] = v[3];
       }
   }
-  const int xx = (int)(pix % W);
-  const long t2 = pix / W;
-  const int yy = (int)(t2 % H), tt = (int)(t2 / H);
+  const int pix_i = (int)pix;                      // T*H*W < 2^31 (checked by the launcher): 32-bit divisions
+  const int xx = pix_i % W;
+  const int t2 = pix_i / W;
+  const int yy = t2 % H, tt = t2 / H;
   const bool grid_px = in && ((xx | yy) & 1) == 0 && (xx >> 1) < Wh && (yy >> 1) < Hh && (tt % t_step) == 0;
   const long Ph = (long)((T + t_step - 1) / t_step) * Hh * Wh;
   const long ho = ((long)(tt / t_step) * Hh + (yy >> 1)) * Wh + (xx >> 1);      // index on the half-resolution grid
@@ -460,10 +461,10 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
 // stats[r, k] = partials of instance r added in tile order (k = 0: any -> max)
 __global__ void __launch_bounds__(256)
 mask_stats_reduce_kernel(const float* __restrict__ part, int n_tiles, long n_rows, float* __restrict__ stats) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows * 5) return;
   const long r = i / 5;
-  const int k = (int)(i % 5);
+  const int k = i % 5;
   const float* p = part + r * n_tiles * 5 + k;
   float a = p[0];
   for (int t = 1; t < n_tiles; ++t) a = (k == 0) ? fmaxf(a, p[(long)t * 5]) : a + p[(long)t * 5];
@@ -500,17 +501,24 @@ mask_nms_kernel(const float* __restrict__ logits, const unsigned* __restrict__ h
   const int wq = act ? (q >> 5) : 0;
   const unsigned bit = act ? (1u << (q & 31)) : 0u;
   float num = 0.f;
-  for (long c0 = 0; c0 < Ph; c0 += 1024) {
-    const int cn = (int)((Ph - c0) < 1024 ? (Ph - c0) : 1024);
+  // chunks of whole half-resolution rows (<= 1024 pixels): no per-pixel index division
+  const int n_rows_h = (int)(Ph / Wh);                     // ceil(T/t_step) * Hh
+  const int R = Wh >= 1024 ? 1 : 1024 / Wh;
+  for (int r0 = 0; r0 < n_rows_h; r0 += R) {
+    const int rows = n_rows_h - r0 < R ? n_rows_h - r0 : R;
+    const int cn = rows * (Wh < 1024 ? Wh : 1024);
+    const long c0 = (long)r0 * Wh;
     __syncthreads();
-    for (int i = threadIdx.x; i < cn; i += blockDim.x) {
-      const long h = c0 + i;
-      const int x2 = (int)(h % Wh);
-      const long r2 = h / Wh;
-      const int y2 = (int)(r2 % Hh), t2 = (int)(r2 / Hh);
-      sS[i] = 1.0f / (1.0f + expf(-lp[((long)t2 * t_step * H + 2 * y2) * W + 2 * x2]));
+    for (int rr = 0; rr < rows; ++rr) {
+      const int grow = r0 + rr;
+      const int t2 = grow / Hh, y2 = grow - t2 * Hh;       // block-uniform
+      const float* src = lp + ((long)(t2 * t_step) * H + 2 * y2) * W;
+      for (int x2 = threadIdx.x; x2 < Wh && x2 < 1024; x2 += blockDim.x) sS[rr * Wh + x2] = 1.0f / (1.0f + expf(-src[2 * x2]));
     }
-    for (int i = threadIdx.x; i < cn * nwu; i += blockDim.x) sH[i] = hb[(c0 + i / nwu) * nw + i % nwu];
+    for (int i = threadIdx.x; i < cn; i += blockDim.x) {
+      const unsigned* hw = hb + (c0 + i) * nw;
+      for (int w = 0; w < nwu; ++w) sH[i * nwu + w] = hw[w];
+    }
     __syncthreads();
     if (act) {
       const unsigned* hq = sH + wq;
@@ -594,7 +602,8 @@ extern "C" long mdqe_dyn_mask_workspace_floats(int n_rows, int T, int H, int W) 
 extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const float* feats, int B, int Q, int M, int T, int H,
                                      int W, const int* row0_host, const int* n_host, const int* f0_host, float* logits,
                                      unsigned* hard_t, float* part, float* stats, float* mi, void* stream) {
-  MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && M > 0 && M <= 32 && M % 4 == 0 && T > 0 && H > 1 && W > 1);
+  MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && M > 0 && M <= 32 && M % 4 == 0 && T > 0 && H > 1 && W > 1 && W / 2 <= 1024);
+  MDQE_REQUIRE((long)T * H * W < (1L << 30));
   if (B == 0) return MDQE_OK;
   MDQE_CHECK_PTR(row0_host); MDQE_CHECK_PTR(n_host); MDQE_CHECK_PTR(f0_host);
   long n_rows = 0;
