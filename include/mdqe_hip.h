@@ -278,8 +278,9 @@ int mdqe_time_fuse_f32(const float* w, const float* x, int Bc, int T, int Q, int
  *   first cache frame of the clip).  coef [B,Q,M], feats [frames,H,W,M] channels-last ->
  *   logits [n_rows,T,H,W] = einsum 'qm,mthw->qthw' (:384); stats [n_rows,5] = (any(x>0), sum sigmoid(x)[hard], count(hard),
  *   sum_half sigmoid(x), count_half(hard)), hard = sigmoid(x) > 0.5, half = F.interpolate(scale_factor=0.5) grid of :394-396
- *   (every 2nd frame when T >= 5); mi [n_rows] = max_{p<q} soft-IoU (:398-405).  Scratch: hard_t [B * Ph * ceil(Q/32)] words
- *   (hard bits per half-grid pixel, Ph = ceil(T/t_step)*(H/2)*(W/2)), part [mdqe_dyn_mask_workspace_floats()].
+ *   (every 2nd frame when T >= 5); mi [n_rows] = max_{p<q} soft-IoU (:398-405): `soft @ hard.t()` as one batched MFMA launch.
+ *   Scratch: soft_h / hard_h [n_rows, Ph] (Ph = ceil(T/t_step)*(H/2)*(W/2)), part [mdqe_dyn_mask_workspace_floats()],
+ *   gram [mdqe_nms_workspace_floats(max kept per clip)].
  * clip_finalize (:408-419): out [n_rows, 2+K+C] = (score, label, class scores, embedding) of the j-th selected row of clip b at
  *   row row0[b]+j, sel [n_rows] its instance row, n_sel [B].
  * rows_gather: out[i,:] = src[idx[i],:]. */
@@ -287,8 +288,9 @@ int mdqe_clip_select_f32(const float* cls, const float* emb, int B, int Q, int K
                          int* order_ws, int* n_thr_ws, float* inv_norm_ws, float* sim_ws, int* kept, int* n_keep, void* stream);
 long mdqe_dyn_mask_workspace_floats(int n_rows, int T, int H, int W);
 int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const float* feats, int B, int Q, int M, int T, int H, int W,
-                          const int* row0_host, const int* n_host, const int* f0_host, float* logits,
-                          unsigned* hard_t, float* part, float* stats, float* mi, void* stream);
+                          const int* row0_host, const int* n_host, const int* f0_host, float* logits, float* soft_h,
+                          float* hard_h, float* part, float* gram, float* stats, float* mi, void* stream);
+long mdqe_nms_workspace_floats(int n_max);
 int mdqe_clip_finalize_f32(const float* cls, const float* emb, const int* kept, const float* stats, const float* mi, int B,
                            int Q, int K, int C, float thr, const int* row0_host, const int* n_host, int* sel, int* n_sel,
                            float* out, void* stream);

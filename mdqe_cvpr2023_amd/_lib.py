@@ -35,7 +35,7 @@ SIGNATURES = {
     "mdqe_add_rows_f32": [p, l, p, l, p, l, l, i, p],
     "mdqe_time_fuse_f32": [p, p, i, i, i, i, p, p, p, p],
     "mdqe_clip_select_f32": [p, p, i, i, i, i, f, i, p, p, p, p, p, p, p],
-    "mdqe_dyn_mask_nms_f32": [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p],
+    "mdqe_dyn_mask_nms_f32": [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p],
     "mdqe_clip_finalize_f32": [p, p, p, p, p, i, i, i, i, f, p, p, p, p, p, p],
     "mdqe_rows_gather_f32": [p, p, i, l, p, p],
     "mdqe_mha_small_f32": [p, l, p, l, p, l, i, i, i, i, p],
@@ -105,6 +105,8 @@ def load_library(path=None):
     h.mdqe_strerror.argtypes = [c_int]
     h.mdqe_get_gemm_precision.restype = c_int
     h.mdqe_get_gemm_precision.argtypes = []
+    h.mdqe_nms_workspace_floats.restype = c_long
+    h.mdqe_nms_workspace_floats.argtypes = [c_int]
     h.mdqe_dyn_mask_workspace_floats.restype = c_long
     h.mdqe_dyn_mask_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     h.mdqe_groupnorm_workspace_bytes.restype = c_long

@@ -384,8 +384,8 @@ struct ClipMeta { int row0[64]; int n[64]; int f0[64]; };
 template <int M>
 __global__ void __launch_bounds__(256)
 dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, const float* __restrict__ feats, int Q, int T, int H,
-                int W, int t_step, int c0, ClipMeta meta, float* __restrict__ logits, unsigned* __restrict__ hard_t, int nw,
-                float* __restrict__ part, int n_tiles, int Mreal) {
+                int W, int t_step, int c0, ClipMeta meta, float* __restrict__ logits, float* __restrict__ soft_h,
+                float* __restrict__ hard_h, float* __restrict__ part, int n_tiles, int Mreal) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int bl = blockIdx.y;                       // clip within this launch
   const int b = c0 + bl;
@@ -422,7 +422,6 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
   const bool grid_px = in && ((xx | yy) & 1) == 0 && (xx >> 1) < Wh && (yy >> 1) < Hh && (tt % t_step) == 0;
   const long Ph = (long)((T + t_step - 1) / t_step) * Hh * Wh;
   const long ho = ((long)(tt / t_step) * Hh + (yy >> 1)) * Wh + (xx >> 1);      // index on the half-resolution grid
-  unsigned bits = 0;
   for (int r = 0; r < n; ++r) {
     const float* c = sC + r * M;
     float v = 0.f;
@@ -443,11 +442,7 @@ dyn_mask_kernel(const float* __restrict__ coef, const int* __restrict__ kept, co
       float* p = sP + (r * 4 + wave) * 5;
       p[0] = any_m ? 1.f : 0.f; p[1] = qn; p[2] = (float)__popcll(hard_m); p[3] = ss; p[4] = (float)__popcll(hg_m);
     }
-    if (hg) bits |= 1u << (r & 31);
-    if ((r & 31) == 31 || r == n - 1) {            // the hard bits of 32 instances of the clip at this half-resolution pixel
-      if (grid_px) hard_t[((long)bl * Ph + ho) * nw + (r >> 5)] = bits;
-      bits = 0;
-    }
+    if (grid_px) { soft_h[(long)(row0 + r) * Ph + ho] = s; hard_h[(long)(row0 + r) * Ph + ho] = hg ? 1.f : 0.f; }
   }
   __syncthreads();
   for (int i = tid; i < n * 5; i += 256) {
@@ -471,66 +466,76 @@ mask_stats_reduce_kernel(const float* __restrict__ part, int n_tiles, long n_row
   stats[i] = a;
 }
 
-// Soft-IoU NMS inside each clip (mdqe/mdqe.py:398-408), rows in score order.  Block = instance p of a clip; thread = a
-// lower-ranked instance q > p of the same clip:
-//   num = sum over the half-resolution pixels of sigmoid(logits[p, pix]) where hard[q, pix]     (ascending pixel order)
-//   iou = num / (sum soft_h[p] + sum hard[q] - num + 1);  mi[q] = max_p iou          (non-negative floats: integer atomicMax)
-// The block walks the half-resolution grid in chunks of 1024 pixels: all threads stage row p's sigmoids and the clip's hard
-// words (dyn_mask_kernel: one word per 32 instances per pixel) in LDS with coalesced loads, then every thread runs over the
-// chunk reading both from LDS (the lanes of a wave read the same sigmoid and at most two distinct words: broadcasts).
-// Blank rows p (no positive logit) take no part (:387-390).
-__global__ void __launch_bounds__(256)
-mask_nms_kernel(const float* __restrict__ logits, const unsigned* __restrict__ hard_t, int nw, int T, int H, int W, int t_step,
-                const float* __restrict__ stats, ClipMeta meta, int n_clips, float* __restrict__ mi) {
-  __shared__ float sS[1024];
-  __shared__ unsigned sH[1024 * 8];
-  int bl = 0;
-  const int row = blockIdx.x + meta.row0[0];
-  while (bl + 1 < n_clips && row >= meta.row0[bl + 1]) ++bl;
+// Soft-IoU NMS inside each clip (mdqe/mdqe.py:398-408), rows in score order: num[p,q] = soft_h[p,:] . hard_h[q,:] over the
+// half-resolution pixels is the reference's own `soft @ hard.t()` -- a skinny NT GEMM per clip (n x n outputs, K = Ph ~ 15k).
+// One launch for all clips: block = one wave = one 32x32 tile (ti <= tj) of one clip over one of KS slices of K, on
+// v_mfma_f32_32x32x2_f32; the two k values of an instruction come from the two halves of the slice (the pairing of k's is
+// free in a dot product), so every lane streams its own row contiguously with 16-B loads.  Partial tiles go to
+// part[clip][tile][slice][32x32] and are added in slice order by mask_iou_kernel: deterministic.
+__global__ void __launch_bounds__(64)
+mask_gram_kernel(const float* __restrict__ soft_h, const float* __restrict__ hard_h, int Ph, int KS, ClipMeta meta,
+                 int max_tiles, float* __restrict__ part) {
+  const int bl = blockIdx.z;
   const int n = meta.n[bl], row0 = meta.row0[bl];
-  const int p = row - row0;
-  if (p >= n - 1) return;                                   // nothing ranks below the last row
-  if (!(stats[(long)row * 5] > 0.f)) return;                // blank p
-  const int Hh = H / 2, Wh = W / 2;
-  const long Ph = (long)((T + t_step - 1) / t_step) * Hh * Wh;
-  const float* lp = logits + (long)row * T * H * W;
-  const unsigned* hb = hard_t + (long)bl * Ph * nw;
-  const int nwu = (n + 31) >> 5;                            // words in use (<= 8: n <= 256)
-  const int q = p + 1 + (int)threadIdx.x;
-  const bool act = q < n;
-  const int wq = act ? (q >> 5) : 0;
-  const unsigned bit = act ? (1u << (q & 31)) : 0u;
-  float num = 0.f;
-  // chunks of whole half-resolution rows (<= 1024 pixels): no per-pixel index division
-  const int n_rows_h = (int)(Ph / Wh);                     // ceil(T/t_step) * Hh
-  const int R = Wh >= 1024 ? 1 : 1024 / Wh;
-  for (int r0 = 0; r0 < n_rows_h; r0 += R) {
-    const int rows = n_rows_h - r0 < R ? n_rows_h - r0 : R;
-    const int cn = rows * (Wh < 1024 ? Wh : 1024);
-    const long c0 = (long)r0 * Wh;
-    __syncthreads();
-    for (int rr = 0; rr < rows; ++rr) {
-      const int grow = r0 + rr;
-      const int t2 = grow / Hh, y2 = grow - t2 * Hh;       // block-uniform
-      const float* src = lp + ((long)(t2 * t_step) * H + 2 * y2) * W;
-      for (int x2 = threadIdx.x; x2 < Wh && x2 < 1024; x2 += blockDim.x) sS[rr * Wh + x2] = 1.0f / (1.0f + expf(-src[2 * x2]));
+  const int nt = (n + 31) >> 5;
+  int tile = blockIdx.y;
+  if (n < 2 || tile >= nt * (nt + 1) / 2) return;
+  int ti = 0;
+  while (tile >= nt - ti) { tile -= nt - ti; ++ti; }
+  const int tj = ti + tile;
+  const int lane = threadIdx.x, lr = lane & 31, lh = lane >> 5;
+  const int ks = blockIdx.x;
+  const int per = ((Ph + KS - 1) / KS + 7) & ~7;             // slice length, multiple of 8 (two halves of 4-wide loads)
+  const int k0 = ks * per + lh * (per / 2);
+  const int kend = min(Ph, ks * per + (lh + 1) * (per / 2));
+  const int ra = min(ti * 32 + lr, n - 1), rb = min(tj * 32 + lr, n - 1);
+  const float* pa = soft_h + (long)(row0 + ra) * Ph;
+  const float* pb = hard_h + (long)(row0 + rb) * Ph;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k = k0; k < k0 + per / 2; k += 4) {                 // both halves run the same trip count (MFMA is wave-wide)
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (k + 3 < kend && (Ph & 3) == 0) {
+      a = *reinterpret_cast<const f32x4*>(pa + k);
+      b = *reinterpret_cast<const f32x4*>(pb + k);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < kend) { a[e] = pa[k + e]; b[e] = pb[k + e]; }
     }
-    for (int i = threadIdx.x; i < cn; i += blockDim.x) {
-      const unsigned* hw = hb + (c0 + i) * nw;
-      for (int w = 0; w < nwu; ++w) sH[i * nwu + w] = hw[w];
-    }
-    __syncthreads();
-    if (act) {
-      const unsigned* hq = sH + wq;
-#pragma unroll 8
-      for (int i = 0; i < cn; ++i) num += (hq[i * nwu] & bit) ? sS[i] : 0.f;
-    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
   }
-  if (act) {
-    const float den = stats[(long)row * 5 + 3] + stats[(long)(row0 + q) * 5 + 4] - num;
-    const float iou = num / (den + 1.f);
-    atomicMax(reinterpret_cast<unsigned*>(mi + row0 + q), __float_as_uint(iou));
+  float* o = part + (((long)(bl * max_tiles + blockIdx.y) * KS + ks) << 10);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[r];     // C(row, col = lr) of the tile
+}
+
+// iou[p,q] = num / (sum soft_h[p] + sum hard_h[q] - num + 1) for p < q, blank rows p excluded; mi[q] = max_p iou (>= 0).
+// Block per clip, thread per q; the slices of a tile are added in order.
+__global__ void __launch_bounds__(256)
+mask_iou_kernel(const float* __restrict__ part, int KS, int max_tiles, const float* __restrict__ stats, ClipMeta meta,
+                float* __restrict__ mi) {
+  const int bl = blockIdx.x;
+  const int n = meta.n[bl], row0 = meta.row0[bl];
+  const int q = threadIdx.x;
+  if (q >= n) return;
+  const int nt = (n + 31) >> 5;
+  const int tj = q >> 5, cq = q & 31;
+  const float hq = stats[(long)(row0 + q) * 5 + 4];
+  float best = 0.f;
+  for (int p = 0; p < q; ++p) {
+    if (!(stats[(long)(row0 + p) * 5] > 0.f)) continue;        // blank p takes no part (:387-390)
+    const int ti = p >> 5;
+    const int tile = ti * nt - ti * (ti - 1) / 2 + (tj - ti);
+    const float* t = part + (((long)(bl * max_tiles + tile) * KS) << 10) + (p & 31) * 32 + cq;
+    float num = 0.f;
+    for (int s = 0; s < KS; ++s) num += t[(long)s << 10];
+    const float den = stats[(long)(row0 + p) * 5 + 3] + hq - num;
+    best = fmaxf(best, num / (den + 1.f));
   }
+  mi[row0 + q] = best;
 }
 
 // a15, last step (:408-419) per clip: class scores x (1 - max IoU) x mask quality, best class, drop blank / suppressed rows,
@@ -589,6 +594,13 @@ clip_finalize_kernel(const float* __restrict__ cls, const float* __restrict__ em
   }
 }
 
+#define MDQE_NMS_KS 16
+// floats of the NMS partial-tile workspace for a batch whose largest clip keeps n_max instances (<= 64 clips per launch)
+extern "C" long mdqe_nms_workspace_floats(int n_max) {
+  const long nt = (n_max + 31) / 32;
+  return 64L * (nt * (nt + 1) / 2) * MDQE_NMS_KS * 1024;
+}
+
 extern "C" long mdqe_dyn_mask_workspace_floats(int n_rows, int T, int H, int W) {
   const long P = (long)T * H * W;
   return (long)n_rows * ((P + 255) / 256) * 5;
@@ -601,7 +613,7 @@ extern "C" long mdqe_dyn_mask_workspace_floats(int n_rows, int T, int H, int W) 
 // t_step = 2 when T >= 5.
 extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const float* feats, int B, int Q, int M, int T, int H,
                                      int W, const int* row0_host, const int* n_host, const int* f0_host, float* logits,
-                                     unsigned* hard_t, float* part, float* stats, float* mi, void* stream) {
+                                     float* soft_h, float* hard_h, float* part, float* gram, float* stats, float* mi, void* stream) {
   MDQE_REQUIRE(B >= 0 && Q > 0 && Q <= 256 && M > 0 && M <= 32 && M % 4 == 0 && T > 0 && H > 1 && W > 1 && W / 2 <= 1024);
   MDQE_REQUIRE((long)T * H * W < (1L << 30));
   if (B == 0) return MDQE_OK;
@@ -609,7 +621,7 @@ extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const f
   long n_rows = 0;
   for (int b = 0; b < B; ++b) { MDQE_REQUIRE(n_host[b] >= 0 && n_host[b] <= Q && row0_host[b] == n_rows); n_rows += n_host[b]; }
   if (n_rows == 0) return MDQE_OK;
-  MDQE_CHECK_PTR(coef); MDQE_CHECK_PTR(kept); MDQE_CHECK_PTR(feats); MDQE_CHECK_PTR(logits); MDQE_CHECK_PTR(hard_t);
+  MDQE_CHECK_PTR(coef); MDQE_CHECK_PTR(kept); MDQE_CHECK_PTR(feats); MDQE_CHECK_PTR(logits); MDQE_CHECK_PTR(soft_h); MDQE_CHECK_PTR(hard_h); MDQE_CHECK_PTR(gram);
   MDQE_CHECK_PTR(part); MDQE_CHECK_PTR(stats); MDQE_CHECK_PTR(mi);
   hipStream_t st = (hipStream_t)stream;
   mdqe_clear_error();
@@ -617,7 +629,6 @@ extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const f
   const long P = (long)T * H * W;
   const long Ph = (long)((T + t_step - 1) / t_step) * (H / 2) * (W / 2);
   const int n_tiles = (int)((P + 255) / 256);
-  const int nw = (Q + 31) / 32;
   if (hipMemsetAsync(mi, 0, (size_t)n_rows * sizeof(float), st) != hipSuccess) return MDQE_ELAUNCH;
   for (int c0 = 0; c0 < B; c0 += 64) {
     const int nc = B - c0 < 64 ? B - c0 : 64;
@@ -632,13 +643,13 @@ extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const f
     const size_t sm = ((size_t)nmax * Mp + (size_t)nmax * 20) * sizeof(float);
     if (M == 32)
       hipLaunchKernelGGL(dyn_mask_kernel<32>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
-                         logits, hard_t + (long)c0 * Ph * nw, nw, part, n_tiles, M);
+                         logits, soft_h, hard_h, part, n_tiles, M);
     else if (M == 24)
       hipLaunchKernelGGL(dyn_mask_kernel<24>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
-                         logits, hard_t + (long)c0 * Ph * nw, nw, part, n_tiles, M);
+                         logits, soft_h, hard_h, part, n_tiles, M);
     else
       hipLaunchKernelGGL(dyn_mask_kernel<32>, dim3(n_tiles, nc), dim3(256), sm, st, coef, kept, feats, Q, T, H, W, t_step, c0, meta,
-                         logits, hard_t + (long)c0 * Ph * nw, nw, part, n_tiles, M);
+                         logits, soft_h, hard_h, part, n_tiles, M);
   }
   hipLaunchKernelGGL(mask_stats_reduce_kernel, dim3((unsigned)((n_rows * 5 + 255) / 256)), dim3(256), 0, st, part, n_tiles, n_rows, stats);
   for (int c0 = 0; c0 < B; c0 += 64) {
@@ -652,9 +663,11 @@ extern "C" int mdqe_dyn_mask_nms_f32(const float* coef, const int* kept, const f
     if (rows == 0) continue;
     int nmax = 0;
     for (int i = 0; i < nc; ++i) if (meta.n[i] > nmax) nmax = meta.n[i];
-    const int threads = nmax <= 65 ? 64 : nmax <= 129 ? 128 : 256;       // one thread per lower-ranked instance of the clip
-    hipLaunchKernelGGL(mask_nms_kernel, dim3(rows), dim3(threads), 0, st, logits, hard_t + (long)c0 * Ph * nw, nw, T, H, W, t_step, stats,
-                       meta, nc, mi);
+    if (nmax < 2) continue;
+    const int ntm = (nmax + 31) / 32, max_tiles = ntm * (ntm + 1) / 2;
+    hipLaunchKernelGGL(mask_gram_kernel, dim3(MDQE_NMS_KS, max_tiles, nc), dim3(64), 0, st, soft_h, hard_h, (int)Ph, MDQE_NMS_KS, meta,
+                       max_tiles, gram);
+    hipLaunchKernelGGL(mask_iou_kernel, dim3(nc), dim3(256), 0, st, gram, MDQE_NMS_KS, max_tiles, stats, meta, mi);
   }
   return mdqe_launch_status();
 }

@@ -550,11 +550,13 @@ def dyn_mask_nms(coef, kept, feats, row0, n, f0, T):
         return logits, stats, mi
     t_step = 2 if T >= 5 else 1
     Ph = ((T + t_step - 1) // t_step) * (H // 2) * (W // 2)
-    hard_t = torch.empty(B * Ph * ((Q + 31) // 32), dtype=torch.int32, device=dev)
+    soft_h = torch.empty(n_rows, Ph, device=dev)
+    hard_h = torch.empty(n_rows, Ph, device=dev)
+    gram = torch.empty(lib.mdqe_nms_workspace_floats(int(n.max())), device=dev)
     part = torch.empty(lib.mdqe_dyn_mask_workspace_floats(n_rows, T, H, W), device=dev)
     row0 = np.ascontiguousarray(row0, dtype=np.int32); n = np.ascontiguousarray(n, dtype=np.int32); f0 = np.ascontiguousarray(f0, dtype=np.int32)
     check(lib.mdqe_dyn_mask_nms_f32(ptr(coef), ptr(kept), ptr(feats), B, Q, M, T, H, W, row0.ctypes.data, n.ctypes.data, f0.ctypes.data,
-                                    ptr(logits), ptr(hard_t), ptr(part), ptr(stats), ptr(mi), cur_stream()), "dyn_mask_nms")
+                                    ptr(logits), ptr(soft_h), ptr(hard_h), ptr(part), ptr(gram), ptr(stats), ptr(mi), cur_stream()), "dyn_mask_nms")
     return logits, stats, mi
 
 
