@@ -383,7 +383,7 @@ def main():
                        "instances_out": len(out["pred_scores"]),
                        "tracked_instances": len(set(m.data_ptr() for m in out["pred_masks"])) if "pred_masks" in out else None,
                        "output": "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
-                       "merge_on_cpu": bool(cfg.merge_on_cpu),
+                       "merge_on_cpu": bool(cfg.merge_on_cpu) if world == 1 else True,     # (sharded videos stream their windows out: sharding._Job)
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
                        "parallelism": ("1 process/GPU; %d-frame chunks dealt round-robin (pinned host, uploaded per chunk), per-round RCCL gather of the "

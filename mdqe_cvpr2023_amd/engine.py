@@ -633,7 +633,9 @@ class Engine:
             Hm, Wm, Md = (int(v) for v in mask_feats[0].shape[1:])
             fbytes = Hm * Wm * Md * 4
             p0 = min(m.data_ptr() for m in mask_feats)
-            if any((not m.is_contiguous()) or tuple(m.shape) != (T, Hm, Wm, Md) or (m.data_ptr() - p0) % fbytes for m in mask_feats):
+            st0 = mask_feats[0].untyped_storage().data_ptr()
+            if any((not m.is_contiguous()) or tuple(m.shape) != (T, Hm, Wm, Md) or (m.data_ptr() - p0) % fbytes
+                   or m.untyped_storage().data_ptr() != st0 for m in mask_feats):
                 raise RuntimeError("inference_clips: mask_feats must be contiguous [T,Hm,Wm,M] views of one channels-last buffer")
             f0 = np.asarray([(m.data_ptr() - p0) // fbytes for m in mask_feats], dtype=np.int32)
             nfr = int(f0.max()) + T

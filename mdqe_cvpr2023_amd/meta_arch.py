@@ -72,6 +72,7 @@ class MDQE(nn.Module):
         self._work_stream = None
         self.stage_times = None
         self.taper_passes = os.environ.get("MDQE_TAPER_PASSES", "1") != "0"   # half-size first / last frame pass (pipeline fill / drain)
+        self.taper_tail = int(os.environ.get("MDQE_TAPER_TAIL", "0"))          # frames of the last pass (0: half a pass)
 
     # ---- checkpoint contract ---------------------------------------------------------------------
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -190,9 +191,10 @@ class MDQE(nn.Module):
         bounds = list(range(fbatch, n_local, fbatch)) + [n_local]
         if self.taper_passes and n_local > fbatch:
             h = max(fbatch // 2, 1)
+            tail = max(min(self.taper_tail, h), 1) if self.taper_tail > 0 else h
             bounds = [h] + list(range(h + fbatch, n_local, fbatch)) + [n_local]
-            if len(bounds) >= 2 and bounds[-1] - bounds[-2] > h and n_local - h - bounds[-2] >= 4:
-                bounds.insert(-1, n_local - h)
+            if len(bounds) >= 2 and bounds[-1] - bounds[-2] > tail and n_local - tail - bounds[-2] >= 4:
+                bounds.insert(-1, n_local - tail)
         cuda = frames_dev.is_cuda
         clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
         if cuda and self._frame_stream is None:

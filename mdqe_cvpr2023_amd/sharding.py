@@ -230,6 +230,11 @@ class _Job:
         self.merger = self.replay = None
         if not root_only or rank == 0:
             self.merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
+            if getattr(model, "merge_on_cpu", None) is None and hasattr(self.merger, "merge_on_cpu"):
+                # a video long enough to be sharded is the case MERGE_ON_CPU exists for (mdqe/mdqe.py:455-456): its windows' final
+                # masks stream to the host as they are flushed, under the next rounds' compute, whatever the config's default says
+                # (an explicit model.merge_on_cpu wins); at N = 8 the one-shot copy of 960 frames x 7 tracks would be 1.5 GB at the end
+                self.merger.merge_on_cpu = True
             if root_only:
                 self.replay = ReplayThread(self.merger, self.device)
         self.rounds = (len(plan) + world - 1) // world
