@@ -158,6 +158,37 @@ class MDQE(nn.Module):
         return None
 
     @staticmethod
+    def pass_bounds(n_frames, fbatch, taper=True, tail=0):
+        """End frames of the passes of the per-frame stages over a chunk of `n_frames`: uniform passes of `fbatch` frames, or
+        (taper) a half-size first pass -- the clip stream starts after half a pass instead of a whole one -- and a last pass of
+        at most `tail` frames (0: half a pass) -- the tail that runs with an idle frame stream (last decoder batch, tracker,
+        mask read-back) is shorter.  Measured: 20/40/40/20 at 360p +0.2-1.1 %; shorter tails lose to the extra pass."""
+        bounds = list(range(fbatch, n_frames, fbatch)) + [n_frames]
+        if taper and n_frames > fbatch:
+            h = max(fbatch // 2, 1)
+            t = max(min(tail, h), 1) if tail > 0 else h
+            bounds = [h] + list(range(h + fbatch, n_frames, fbatch)) + [n_frames]
+            if len(bounds) >= 2 and bounds[-1] - bounds[-2] > t and n_frames - t - bounds[-2] >= 4:
+                bounds.insert(-1, n_frames - t)
+        return bounds
+
+    @staticmethod
+    def stacked_view(imgs):
+        """A list of per-frame host tensors that are consecutive views of ONE buffer (a loader that decoded into one block,
+        `list(video)` of a stacked tensor) as a single [L, ...] view of that buffer, else None."""
+        f0 = imgs[0]
+        if f0.is_cuda or not f0.is_contiguous() or len(imgs) < 2:
+            return None
+        nb = f0.numel() * f0.element_size()
+        if not all(f.dtype == f0.dtype and f.shape == f0.shape and f.is_contiguous() and f.data_ptr() == f0.data_ptr() + i * nb
+                   for i, f in enumerate(imgs)):
+            return None
+        try:                                               # (as_strided checks the storage bounds)
+            return f0.as_strided((len(imgs),) + tuple(f0.shape), (f0.numel(),) + tuple(f0.stride()))
+        except RuntimeError:
+            return None
+
+    @staticmethod
     def clip_schedule(L, T, stride):
         """Clip list of mdqe/mdqe.py:308-312: (start, end, is_last); the loop ends at the first clip that
         reaches past the video (it is clamped and may be shorter than T)."""
@@ -185,16 +216,7 @@ class MDQE(nn.Module):
         Tmax = max((c[1] - c[0] for c in clips), default=1)
         fbatch = self.frame_batch if self.frame_batch > 0 else max(8, min(40, 306000 // max(geo.N, 1)))
         cap = Tmax - 1 + fbatch
-        # pass boundaries: uniform passes of `fbatch` frames, or (taper) a half-size first pass -- the clip stream starts after
-        # half a pass instead of a whole one -- and a last pass of at most half size -- the tail that runs with an idle frame
-        # stream (last decoder batch, tracker, mask read-back) is shorter
-        bounds = list(range(fbatch, n_local, fbatch)) + [n_local]
-        if self.taper_passes and n_local > fbatch:
-            h = max(fbatch // 2, 1)
-            tail = max(min(self.taper_tail, h), 1) if self.taper_tail > 0 else h
-            bounds = [h] + list(range(h + fbatch, n_local, fbatch)) + [n_local]
-            if len(bounds) >= 2 and bounds[-1] - bounds[-2] > tail and n_local - tail - bounds[-2] >= 4:
-                bounds.insert(-1, n_local - tail)
+        bounds = self.pass_bounds(n_local, fbatch, self.taper_passes, self.taper_tail)
         cuda = frames_dev.is_cuda
         clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
         if cuda and self._frame_stream is None:
@@ -327,16 +349,8 @@ class MDQE(nn.Module):
             imgs = list(imgs)
             if len(imgs) == 0:
                 raise RuntimeError("MDQE: a video needs at least one frame")
-            stack = None
             f0 = imgs[0]
-            if not f0.is_cuda and f0.is_contiguous() and len(imgs) > 1:
-                nb = f0.numel() * f0.element_size()
-                if all(f.dtype == f0.dtype and f.shape == f0.shape and f.is_contiguous() and f.data_ptr() == f0.data_ptr() + i * nb
-                       for i, f in enumerate(imgs)):
-                    try:                                           # (as_strided checks the storage bounds)
-                        stack = f0.as_strided((len(imgs),) + tuple(f0.shape), (f0.numel(),) + tuple(f0.stride()))
-                    except RuntimeError:
-                        stack = None
+            stack = self.stacked_view(imgs)
             if stack is None and f0.is_cuda:
                 stack = torch.stack(imgs)
         if self.device.type != "cuda" and stack is None:

@@ -119,3 +119,30 @@ def test_top_level_msda_shim_exports_the_extensions_two_functions():
     with pytest.raises(RuntimeError):                                          # CPU tensors: the reference's AT_ASSERTM(.is_cuda())
         v = torch.zeros(1, 4, 2, 8)
         MSDA.ms_deform_attn_forward(v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 2, 1, 1, 2), torch.zeros(1, 1, 2, 1, 1), 64)
+
+
+def test_pass_bounds_cover_the_chunk():
+    """Frame passes: every frame exactly once, no pass longer than `fbatch`, tapered head / tail only when there is room."""
+    for n in (1, 3, 17, 40, 41, 44, 63, 100, 120, 240):
+        for fb in (8, 20, 40):
+            for taper in (False, True):
+                b = MDQE.pass_bounds(n, fb, taper)
+                assert b[-1] == n and b == sorted(set(b)) and all(y - x <= fb for x, y in zip([0] + b, b)), (n, fb, taper, b)
+    assert MDQE.pass_bounds(120, 40, True) == [20, 60, 100, 120]
+    assert MDQE.pass_bounds(120, 40, False) == [40, 80, 120]
+    assert MDQE.pass_bounds(120, 40, True, tail=8) == [20, 60, 100, 112, 120]
+    assert MDQE.pass_bounds(30, 40, True) == [30]
+
+
+def test_stacked_view_of_per_frame_tensors():
+    """The mapper hands over a list of frames; when they are consecutive views of one block the upload copies chunks of it."""
+    v = torch.arange(5 * 3 * 4 * 6, dtype=torch.uint8).reshape(5, 3, 4, 6)
+    s = MDQE.stacked_view(list(v))
+    assert s is not None and s.shape == v.shape and s.data_ptr() == v.data_ptr() and torch.equal(s, v)
+    assert MDQE.stacked_view([v[0], v[2], v[3]]) is None                       # a gap
+    assert MDQE.stacked_view([f.clone() for f in v]) is None                   # separate allocations
+    assert MDQE.stacked_view([v[0]]) is None
+    assert MDQE.stacked_view(list(v[:, :, :, :3])) is None                      # non-contiguous frames
+    tail = list(v[3:])                                                         # a suffix of the block: still one view
+    s = MDQE.stacked_view(tail)
+    assert s is not None and torch.equal(s, v[3:])
