@@ -73,6 +73,7 @@ class MDQE(nn.Module):
         self.stage_times = None
         self.taper_passes = os.environ.get("MDQE_TAPER_PASSES", "1") != "0"   # half-size first / last frame pass (pipeline fill / drain)
         self.taper_tail = int(os.environ.get("MDQE_TAPER_TAIL", "0"))          # frames of the last pass (0: half a pass)
+        self.lookahead = max(1, int(os.environ.get("MDQE_LOOKAHEAD", "2")))   # frame passes queued ahead of the group being decoded
 
     # ---- checkpoint contract ---------------------------------------------------------------------
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -205,10 +206,10 @@ class MDQE(nn.Module):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
-        Two HIP streams: the per-frame stages (backbone .. decoder value cache: large GEMMs) of chunk k+1 run on a frame
-        stream while the decoder + inference_clip of chunk k (many small kernels and three host syncs) run on the caller's
-        stream, so the matrix cores stay fed through the data-dependent part.  The frame cache is double buffered (two
-        rings of T-1 carried + frame_batch new frames); events order ring reuse."""
+        Two HIP streams: the per-frame stages (backbone .. decoder value cache: large GEMMs) of the next passes run on a frame
+        stream while the decoder + inference_clip of group k (small kernels and two host syncs) run on the caller's
+        stream, so the matrix cores stay fed through the data-dependent part.  The frame cache is a ring of `lookahead + 1`
+        buffers (T-1 carried + frame_batch new frames each); events order their reuse."""
         eng = self.engine
         h, w = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
         geo = eng.geometry(h, w)
@@ -222,8 +223,9 @@ class MDQE(nn.Module):
         if cuda and self._frame_stream is None:
             self._frame_stream = torch.cuda.Stream(frames_dev.device)
         fstream = (self._frame_stream if self.overlap_streams else clip_stream) if cuda else None
-        rings = [None, None]                      # slot -> {name: [cap, ...] buffer}
-        free_ev = [None, None]                    # slot -> event: the clip work that read this ring has finished
+        NR = max(2, self.lookahead + 1)           # rings: the group being decoded + `lookahead` frame passes queued behind it
+        rings = [None] * NR                       # slot -> {name: [cap, ...] buffer}
+        free_ev = [None] * NR                     # slot -> event: the clip work that read this ring has finished
         nxt = 0                                   # local frames [0, nxt) have been through the per-frame stages
 
         def prepare(ci, slot, prev):
@@ -284,23 +286,41 @@ class MDQE(nn.Module):
                 cb, on_frames_queued = on_frames_queued, None
                 cb()
 
-        i, k = 0, 0
-        cur = prepare(0, 0, None) if clips else None
+        from collections import deque
+        states = deque()                          # prepared (queued on the frame stream) and not yet decoded, in clip order
+        plan = {"ci": 0, "k": 0, "last": None}
+
+        def plan_next():
+            """Queue the frame passes of the next group of clips (ring k mod NR) and fix the group: every further clip of the
+            same length whose frames are then cached joins the batch -- clips are independent through the decoder, so they run
+            as ONE pass (M = clips*T*Q rows)."""
+            ci = plan["ci"]
+            if ci >= len(clips):
+                return False
+            st = prepare(ci, plan["k"] % NR, plan["last"])
+            T = clips[ci][1] - clips[ci][0]
+            j = ci
+            while j < len(clips) and clips[j][1] - frame_offset <= st["covered"] and clips[j][1] - clips[j][0] == T:
+                j += 1
+            st["i"], st["j"], st["T"] = ci, j, T
+            plan["ci"], plan["k"], plan["last"] = j, plan["k"] + 1, st
+            states.append(st)
+            frames_queued()
+            return True
+
+        plan_next()
         if primed:
             yield None                            # per-frame work of the first chunk is queued; the caller resumes later
-        frames_queued()
-        while i < len(clips):
-            cache, base, covered = cur["cache"], cur["base"], cur["covered"]
-            ls, le = clips[i][0] - frame_offset, clips[i][1] - frame_offset
-            # every further clip of the same length whose frames are already cached joins the batch:
-            # clips are independent through the decoder, so they run as ONE pass (M = clips*T*Q rows)
-            T = le - ls
-            j = i
-            while j < len(clips) and clips[j][1] - frame_offset <= covered and clips[j][1] - clips[j][0] == T:
-                j += 1
-            group = clips[i:j]
-            nxt_state = prepare(j, (k + 1) % 2, cur) if j < len(clips) else None     # queued BEFORE this group's clip work
-            frames_queued()
+        while states:
+            # `lookahead` passes are queued BEFORE this group's clip work: with one, the frame stream ran dry at every group
+            # boundary -- the clip kernels share the chip with the pass queued behind them and finish together with it, and
+            # the next pass was only queued after the host had consumed the group (2-3 ms of whole-GPU idle per boundary in
+            # the HIP trace, tools/trace_gaps.py)
+            while len(states) < NR and plan_next():
+                pass
+            cur = states.popleft()
+            cache, base, T = cur["cache"], cur["base"], cur["T"]
+            group = clips[cur["i"]:cur["j"]]
             if cuda:
                 clip_stream.wait_event(cur["ready"])
             starts = [c[0] - frame_offset - base for c in group]
@@ -317,7 +337,6 @@ class MDQE(nn.Module):
                 res["ready"] = ready
                 res["batch_end"] = gi == len(group) - 1
                 yield start, end, last, res
-            i, k, cur = j, k + 1, nxt_state
 
     def merge_clips(self, results, frame_hw, out_size, mask_hw, n_frames=None):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""
