@@ -117,7 +117,9 @@ msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows, const
 // 1: 32 consecutive queries of ONE head -- a head samples along its own direction (ms_deform_attn.py:81-87), so neighbouring
 // queries of the same head read neighbouring pixels of the same 128-B head slice: the block's lines overlap in L1.
 // 2: as 1 with the 32 queries an 8 x 4 patch of their level (overlap in y as well).
-template <int L, int P, int MAP, int WPE>
+// DD = head width: 32 (8 lanes x 4 channels) or 24 (Swin-L's hidden 192: the group keeps its 8 lanes for the sample set-up, lanes
+// 6 and 7 carry out-of-range offsets in the gather -- they read zeros -- and do not store).
+template <int L, int P, int MAP, int WPE, int DD = 32>
 __global__ void __launch_bounds__(256, WPE)
 msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
@@ -125,7 +127,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
                      const float* __restrict__ grid, MsdaLevels lv,
                      int B, int M, int G, int Q, float scale, float* __restrict__ out, long ldout, long total, int xcd_order) {
   constexpr int LP = L * P;                    // 16
-  constexpr int D = 32, DV = 8;
+  constexpr int D = DD, DV = 8;               // DV: lanes of a (query, head) group (D / 4 of them carry channels)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   // [group in block][sample (+1 pad)][corner]: the pad makes the group stride 272 B, so the two groups served by one 16-lane
   // pass of a ds_read/write_b128 fall on disjoint banks (a 256-B stride put every group on the same 4 banks: r01 PMC showed
@@ -191,7 +193,8 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
     float bw = 0.f, bh = 0.f;
     if (mode == 1) { bw = rp[2]; bh = rp[3]; }
     const long brow = vidx != nullptr ? (long)vidx[b] * v_brows : (long)b * v_brows;
-    const unsigned lane_off = (unsigned)((m * D + j * 4) * 4);
+    const bool chan = j * 4 < D;
+    const unsigned lane_off = chan ? (unsigned)((m * D + j * 4) * 4) : MSDA_OOB;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -236,14 +239,14 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
         const f32x4 wv = *reinterpret_cast<const f32x4*>(&swgt[grp][i][0]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const unsigned o = offv[c] + lane_off;
+          const unsigned o = chan ? offv[c] + lane_off : MSDA_OOB;
           const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
           acc += v * wv[c];
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
-    __builtin_nontemporal_store(acc * scale, reinterpret_cast<f32x4*>(out + t * ldout + m * D + j * 4));
+    if (chan) __builtin_nontemporal_store(acc * scale, reinterpret_cast<f32x4*>(out + t * ldout + m * D + j * 4));
   }
 }
 
@@ -275,7 +278,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
   mdqe_clear_error();
   // v2 (cooperative sample set-up, buffer loads): D == 32, 16 samples, value buffer addressable with 32-bit offsets
   const long vbytes = value_rows > 0 ? ((value_rows - 1) * ldv + (long)M * D) * 4 : 0;
-  if (D == 32 && L * P == 16 && vbytes > 0 && vbytes < 0xF0000000L) {
+  if ((D == 32 || D == 24) && L * P == 16 && vbytes > 0 && vbytes < 0xF0000000L) {
     // block-to-query map: the patch / row forms need the queries to be the level tokens in raster order (encoder: mode 0, G == 1,
     // Q == sum H*W); everything else keeps the plain order
     long ntok = 0;
@@ -290,8 +293,10 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
     else if (map == 1) nbq = (long)((Q + 31) / 32) * M;
     else { nbq = 0; for (int l = 0; l < L; ++l) nbq += (long)((lv.W[l] + 7) / 8) * ((lv.H[l] + 3) / 4); nbq *= M; }
     const long nb2 = (long)B * nbq;                                            // exact grid: blocks per batch element x B
-#define LAUNCH2(LL, PP, MP, WP) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP, MP, WP>), dim3((unsigned)nb2), dim3(256), 0, st, value, (unsigned)vbytes, \
-      ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total, g_msda_xcd_order)
+#define LAUNCH2D(LL, PP, MP, WP, DDD) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP, MP, WP, DDD>), dim3((unsigned)nb2), dim3(256), 0, st, value, \
+      (unsigned)vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total, \
+      g_msda_xcd_order)
+#define LAUNCH2(LL, PP, MP, WP) do { if (D == 32) LAUNCH2D(LL, PP, MP, WP, 32); else LAUNCH2D(LL, PP, MP, WP, 24); } while (0)
 #define LAUNCH2M(LL, PP) do { const bool w8 = (var & 4) != 0; \
       if (map == 0) { if (w8) LAUNCH2(LL, PP, 0, 8); else LAUNCH2(LL, PP, 0, 1); } \
       else if (map == 1) { if (w8) LAUNCH2(LL, PP, 1, 8); else LAUNCH2(LL, PP, 1, 1); } \

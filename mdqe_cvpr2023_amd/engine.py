@@ -10,10 +10,10 @@ MI355X-first organisation (not the reference's module graph):
     points) are built once per resolution;
   * per-clip work = query association + 6 decoder layers + heads + dynamic mask product.
 
-Each method cites the reference code whose arithmetic it reproduces.  Arithmetic on O(N*C) data
-runs in libmdqe_hip.so (ops.*); `torch.*` calls below act on <=196-row index/score tensors
-(host-side control the reference also does in Python) unless tagged INTERIM-TORCH, which marks
-device-side torch math still to be replaced by HIP kernels (tracked in DESIGN.md).
+Each method cites the reference code whose arithmetic it reproduces.  All device arithmetic of the video
+path runs in libmdqe_hip.so (ops.*): torch supplies memory, streams and the host-side bookkeeping
+(numpy index arrays, the two host syncs of a decoder batch).  What is left on torch device ops is
+listed in DESIGN.md §4.
 """
 import math
 import os
