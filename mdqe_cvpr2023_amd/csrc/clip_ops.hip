@@ -513,29 +513,30 @@ mask_gram_kernel(const float* __restrict__ soft_h, const float* __restrict__ har
 }
 
 // iou[p,q] = num / (sum soft_h[p] + sum hard_h[q] - num + 1) for p < q, blank rows p excluded; mi[q] = max_p iou (>= 0).
-// Block per clip, thread per q; the slices of a tile are added in order.
+// Block per clip; the (p, q) pairs are spread over the threads, the slices of a tile are added in order, the per-q maximum goes
+// through an integer atomicMax in LDS (non-negative floats order like their bit patterns: order-independent).
 __global__ void __launch_bounds__(256)
 mask_iou_kernel(const float* __restrict__ part, int KS, int max_tiles, const float* __restrict__ stats, ClipMeta meta,
                 float* __restrict__ mi) {
+  __shared__ unsigned best[256];
   const int bl = blockIdx.x;
   const int n = meta.n[bl], row0 = meta.row0[bl];
-  const int q = threadIdx.x;
-  if (q >= n) return;
+  best[threadIdx.x] = 0u;
+  __syncthreads();
   const int nt = (n + 31) >> 5;
-  const int tj = q >> 5, cq = q & 31;
-  const float hq = stats[(long)(row0 + q) * 5 + 4];
-  float best = 0.f;
-  for (int p = 0; p < q; ++p) {
-    if (!(stats[(long)(row0 + p) * 5] > 0.f)) continue;        // blank p takes no part (:387-390)
-    const int ti = p >> 5;
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int p = idx / n, q = idx - p * n;
+    if (p >= q || !(stats[(long)(row0 + p) * 5] > 0.f)) continue;          // blank p takes no part (:387-390)
+    const int ti = p >> 5, tj = q >> 5;
     const int tile = ti * nt - ti * (ti - 1) / 2 + (tj - ti);
-    const float* t = part + (((long)(bl * max_tiles + tile) * KS) << 10) + (p & 31) * 32 + cq;
+    const float* t = part + (((long)(bl * max_tiles + tile) * KS) << 10) + (p & 31) * 32 + (q & 31);
     float num = 0.f;
     for (int s = 0; s < KS; ++s) num += t[(long)s << 10];
-    const float den = stats[(long)(row0 + p) * 5 + 3] + hq - num;
-    best = fmaxf(best, num / (den + 1.f));
+    const float den = stats[(long)(row0 + p) * 5 + 3] + stats[(long)(row0 + q) * 5 + 4] - num;
+    atomicMax(&best[q], __float_as_uint(num / (den + 1.f)));
   }
-  mi[row0 + q] = best;
+  __syncthreads();
+  if ((int)threadIdx.x < n) mi[row0 + threadIdx.x] = __uint_as_float(best[threadIdx.x]);
 }
 
 // a15, last step (:408-419) per clip: class scores x (1 - max IoU) x mask quality, best class, drop blank / suppressed rows,
