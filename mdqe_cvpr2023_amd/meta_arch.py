@@ -140,10 +140,11 @@ class MDQE(nn.Module):
                 return self.inference_image(batched_inputs)
             return self.inference_vis(batched_inputs)
 
-    def _frame_cache(self, frames, geo, ring=None, at=0):
+    def _frame_cache(self, frames, geo, ring=None, at=0, keep_enc=False):
         """Per-frame stages a1-a11 for a batch of frames: everything a clip needs, computed once.  With `ring`
         (preallocated per-frame buffers) the results land in ring[k][at:at+n] -- the 63 MB/frame decoder value
-        cache is written there directly by its GEMM."""
+        cache is written there directly by its GEMM.  keep_enc: the encoder tokens stay in the cache too (5.2 MB per frame;
+        a sharded video ships the tokens of a chunk's last T-1 frames to the neighbour, sharding._Halo)."""
         eng = self.engine
         n = frames.shape[0]
         feats = eng.backbone(frames, geo)
@@ -151,12 +152,24 @@ class MDQE(nn.Module):
         del feats
         mf = eng.mask_features(enc, geo)
         coords, content, emb = eng.frame_queries(enc, geo)
+        extra = (("enc", enc),) if keep_enc else ()
         if ring is None:
-            return {"mf": mf, "coords": coords, "content": content, "emb": emb, "vals": eng.dec_values(enc, geo)}
+            return dict({"mf": mf, "coords": coords, "content": content, "emb": emb, "vals": eng.dec_values(enc, geo)}, **dict(extra))
         eng.dec_values(enc, geo, out=ring["vals"][at:at + n])
-        for k, v in (("mf", mf), ("coords", coords), ("content", content), ("emb", emb)):
+        for k, v in (("mf", mf), ("coords", coords), ("content", content), ("emb", emb)) + extra:
             ring[k][at:at + n].copy_(v)
         return None
+
+    def _cache_from_tokens(self, enc, mf, geo, ring, at):
+        """Cache entries of frames whose encoder tokens and mask features were computed elsewhere (a neighbour rank's halo):
+        only query selection / content sampling and the decoder value projections are redone here."""
+        eng = self.engine
+        n = enc.shape[0]
+        coords, content, emb = eng.frame_queries(enc, geo)
+        eng.dec_values(enc, geo, out=ring["vals"][at:at + n])
+        for k, v in (("mf", mf), ("coords", coords), ("content", content), ("emb", emb), ("enc", enc)):
+            if k in ring:
+                ring[k][at:at + n].copy_(v)
 
     @staticmethod
     def pass_bounds(n_frames, fbatch, taper=True, tail=0):
@@ -202,7 +215,8 @@ class MDQE(nn.Module):
                 break
         return clips
 
-    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None, h2d=None):
+    def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None, h2d=None,
+                          halo=None):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
@@ -217,7 +231,22 @@ class MDQE(nn.Module):
         Tmax = max((c[1] - c[0] for c in clips), default=1)
         fbatch = self.frame_batch if self.frame_batch > 0 else max(8, min(40, 306000 // max(geo.N, 1)))
         cap = Tmax - 1 + fbatch
+        # halo exchange (sharded videos, sharding._Halo): `clips` may START up to T-1 frames before this chunk; those clips read
+        # the LEFT neighbour's last T-1 frames, which arrive as encoder tokens + mask features and get their cache entries
+        # (with a copy of this chunk's first T-1) behind the frames of the last full-length group; in return the tokens of this
+        # chunk's last T-1 frames are handed to `halo.on_tail` as soon as the last pass is queued.
+        strad = []
+        if halo is not None:
+            Tn = self.cfg.n_frames_test
+            strad = [c for c in clips if c[0] < frame_offset]
+            clips = [c for c in clips if c[0] >= frame_offset]
+            if any(c[1] - c[0] != Tn or c[0] < frame_offset - (Tn - 1) for c in strad) or not clips:
+                raise RuntimeError("halo exchange: a chunk must hold at least one whole clip and its straddling clips T frames")
+            cap += 2 * (Tn - 1)
+            own_first = {}
         bounds = self.pass_bounds(n_local, fbatch, self.taper_passes, self.taper_tail)
+        if strad and bounds[0] < self.cfg.n_frames_test - 1:
+            raise RuntimeError("halo exchange: the first frame pass must cover the chunk's first T-1 frames")
         cuda = frames_dev.is_cuda
         clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
         if cuda and self._frame_stream is None:
@@ -262,15 +291,21 @@ class MDQE(nn.Module):
                             if end >= c1:
                                 break
                     if rings[slot] is None:
-                        first = self._frame_cache(frames_dev[nxt:c1], geo)
+                        first = self._frame_cache(frames_dev[nxt:c1], geo, keep_enc=halo is not None)
                         rings[slot] = {k: torch.empty((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for k, v in first.items()}
                         for k, v in first.items():
                             rings[slot][k][count:count + n_new].copy_(v)
                         del first
                     else:
-                        self._frame_cache(frames_dev[nxt:c1], geo, ring=rings[slot], at=count)
+                        self._frame_cache(frames_dev[nxt:c1], geo, ring=rings[slot], at=count, keep_enc=halo is not None)
+                    if halo is not None and strad and nxt == 0:        # this chunk's first T-1 frames: the straddling clips read them
+                        for k, v in rings[slot].items():
+                            own_first[k] = v[count:count + Tn - 1].clone()
                     count += n_new
                     nxt = c1
+                if halo is not None and nxt >= n_local and not halo.tail_sent:      # (issued on the frame stream: ordered behind the last pass)
+                    k_t = min(Tn - 1, count)
+                    halo.on_tail(rings[slot]["enc"][count - k_t:count], rings[slot]["mf"][count - k_t:count])
                 ready = None
                 if cuda:
                     ready = torch.cuda.Event()
@@ -324,6 +359,18 @@ class MDQE(nn.Module):
             if cuda:
                 clip_stream.wait_event(cur["ready"])
             starts = [c[0] - frame_offset - base for c in group]
+            if strad and T == Tn and (cur["j"] >= len(clips) or clips[cur["j"]][1] - clips[cur["j"]][0] != Tn):
+                # the last full-length group of the chunk: the straddling clips join it.  Cache rows [count, count + 2(T-1)) of
+                # its ring = [the left neighbour's last T-1 frames | this chunk's first T-1 frames]
+                ring, cnt = rings[cur["slot"]], cur["count"]
+                enc_h, mf_h = halo.head()                      # (waits for the neighbour's message on this stream)
+                self._cache_from_tokens(enc_h, mf_h, geo, ring, cnt)
+                for k, v in own_first.items():
+                    ring[k][cnt + Tn - 1:cnt + 2 * (Tn - 1)].copy_(v)
+                cache = {k: v[:cnt + 2 * (Tn - 1)] for k, v in ring.items()}
+                starts = starts + [cnt + c[0] - (frame_offset - (Tn - 1)) for c in strad]
+                group = group + strad
+                strad = []
             outs = eng.decode_clips(cache, starts, T, geo)
             ress = eng.inference_clips(outs, cache["mf"], starts, T)
             ready = None
@@ -337,6 +384,9 @@ class MDQE(nn.Module):
                 res["ready"] = ready
                 res["batch_end"] = gi == len(group) - 1
                 yield start, end, last, res
+        if strad:
+            raise RuntimeError("halo exchange: the chunk has no full-length group for its straddling clips (chunk_plan(..., halo_exchange=True) "
+                               "merges a short last chunk into its neighbour)")
 
     def merge_clips(self, results, frame_hw, out_size, mask_hw, n_frames=None):
         """Tracker + window flushes + video merge (mdqe/mdqe.py:337-366) over clip results in global order."""

@@ -178,11 +178,20 @@ class ReplayThread:
 # ------------------------------------------------------------------------------------------------
 # Round-robin chunks: overlap the (inherently sequential) tracker replay with compute
 # ------------------------------------------------------------------------------------------------
-def chunk_plan(L, T, stride, chunk):
+def chunk_plan(L, T, stride, chunk, halo_exchange=False):
     """Global chunks in clip order: [(clips, f0, f1)] with clips = those that START in frames [g*chunk, (g+1)*chunk) and
-    [f0, f1) the frames they need (chunk + (T-1)-frame halo)."""
+    [f0, f1) the frames they need (chunk + (T-1)-frame halo, which the owner computes again).
+    halo_exchange=True: no frame is computed twice.  Chunk g holds exactly the frames [g*chunk, (g+1)*chunk) and owns the clips
+    whose LAST frame falls there; its first clips start up to T-1 frames earlier, in the left neighbour's chunk, whose
+    encoder tokens + mask features of those frames arrive by send/recv (_Halo).  A last chunk shorter than T frames is merged
+    into its neighbour (every chunk needs a whole clip of its own)."""
     from .meta_arch import MDQE
     clips = MDQE.clip_schedule(L, T, stride)
+    if halo_exchange:
+        edges = list(range(0, L, chunk)) + [L]
+        if len(edges) > 2 and edges[-1] - edges[-2] < T:
+            del edges[-2]
+        return [([c for c in clips if a <= c[1] - 1 < b], a, b) for a, b in zip(edges[:-1], edges[1:])]
     plan = []
     g = 0
     while g * chunk < L:
@@ -199,20 +208,70 @@ def owned_chunks(plan, world, rank):
     return [g for g in range(len(plan)) if g % world == rank]
 
 
-def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False):
+def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False):
     """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
     Default: every rank all-gathers each round and replays the tracker (all ranks return the video result;
     emit_masks=False skips the mask production on ranks that only keep the tracker in step).
     root_only=True (bench.py): the rounds are gathered to rank 0 only, which replays the tracker on a worker thread while
     its main thread goes on with the next round; the other ranks only compute and send, and return None."""
     return next(run_round_robin_stream(model, [(chunk_frames, plan)], rank, world, dist, out_size, emit_masks=emit_masks,
-                                       root_only=root_only))
+                                       root_only=root_only, halo_exchange=halo_exchange))
+
+
+class _Halo:
+    """The halo exchange of one (rank, round): this chunk's last T-1 frames go to the right neighbour as [encoder tokens | mask
+    features] (7.5 MB per frame at 360p instead of 1.1 ms of per-frame work each), the left neighbour's arrive the same way.
+    Every rank of a round issues ONE grouped send/recv (`batch_isend_irecv`: RCCL runs the pair concurrently, so the ring
+    of sends cannot deadlock) when its last frame pass is queued -- the same program point on every rank, between the gathers
+    of two rounds.  Rank 0's left neighbour is the LAST rank of the previous round: what rank 0 receives in round q it uses in
+    round q+1 (`carry`).  gloo (the 1-GPU tests) moves host copies."""
+
+    def __init__(self, dist, send_to, recv_from, dims, device, carry_src=None):
+        self.dist, self.send_to, self.recv_from, self.dims, self.device = dist, send_to, recv_from, dims, device
+        self.tail_sent = False
+        self.works, self.recv_buf, self.send_buf = [], None, None
+        self.carry_src = carry_src                 # rank 0: the _Halo of the previous round (its message is this round's head)
+        self.host = dist is not None and getattr(dist, "get_backend", lambda: "")() == "gloo"
+
+    def on_tail(self, enc_tail, mf_tail):
+        """Called on the frame stream once the chunk's last pass is queued."""
+        self.tail_sent = True
+        T1, N, C, Hm, Wm, M = self.dims
+        ops = []
+        if self.send_to is not None:
+            k = enc_tail.shape[0]
+            flat = torch.cat([enc_tail.reshape(k, -1), mf_tail.reshape(k, -1)], 1).contiguous()
+            self.send_buf = flat.cpu() if self.host else flat
+            ops.append(self.dist.P2POp(self.dist.isend, self.send_buf, self.send_to))
+        if self.recv_from is not None:
+            self.recv_buf = torch.empty(T1, N * C + Hm * Wm * M, dtype=torch.float32, device="cpu" if self.host else self.device)
+            ops.append(self.dist.P2POp(self.dist.irecv, self.recv_buf, self.recv_from))
+        if ops:
+            self.works = self.dist.batch_isend_irecv(ops)
+
+    def received(self):
+        """The message this rank received in this round (complete on the current stream), or None."""
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.recv_buf is None:
+            return None
+        return self.recv_buf.to(self.device, non_blocking=True) if self.host else self.recv_buf
+
+    def head(self):
+        """(encoder tokens [T-1, N, C], mask features [T-1, Hm, Wm, M]) of the T-1 frames before this chunk."""
+        flat = self.carry_src.received() if self.carry_src is not None else self.received()
+        if flat is None:
+            raise RuntimeError("halo exchange: no message from the left neighbour")
+        T1, N, C, Hm, Wm, M = self.dims
+        return flat[:, :N * C].reshape(T1, N, C).contiguous(), flat[:, N * C:].reshape(T1, Hm, Wm, M).contiguous()
 
 
 class _Job:
     """One video of the round-robin schedule on this rank: its chunks, its merger and (root-only form) its replay thread."""
 
-    def __init__(self, model, chunk_frames, plan, rank, world, out_size, emit_masks, root_only, like=None):
+    def __init__(self, model, chunk_frames, plan, rank, world, out_size, emit_masks, root_only, like=None, dist=None,
+                 halo_exchange=False):
         from .meta_arch import ClipMerger
         cfg = model.cfg
         self.model, self.chunk_frames, self.plan, self.rank, self.world = model, chunk_frames, plan, rank, world
@@ -227,6 +286,10 @@ class _Job:
         mask_hw = (geo.Hp // ms, geo.Wp // ms)
         self.proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
                       "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((self.T,) + tuple(mask_hw), torch.float32)}
+        self.dist, self.halo_exchange = dist, bool(halo_exchange)
+        self.halo_carry = None                     # rank 0: the last rank's tail of the previous round
+        self.halos = {}
+        self.halo_dims = (geo.N, cfg.hidden_dim, mask_hw[0], mask_hw[1], cfg.mask_dim) if halo_exchange else None
         self.merger = self.replay = None
         if not root_only or rank == 0:
             self.merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
@@ -248,9 +311,29 @@ class _Job:
         if not fr.is_cuda and self.device.type == "cuda":          # a1's host->device copy of this chunk, chunked on the copy stream
             fr, h2d = self.model.upload_frames(fr)
         kw = {"h2d": h2d} if h2d else {}
+        if self.halo_exchange:
+            kw["halo"] = self._halo(q, g)
         gen = self.model.iter_clip_results(fr, self.plan[g][0], self.plan[g][1], primed=True, **kw)
         next(gen)
         return gen
+
+    def _halo(self, q, g):
+        """Send to the owner of chunk g+1, receive from the owner of chunk g-1 -- or, on rank 0, the tail of the round's LAST
+        chunk, which the NEXT round's first chunk (rank 0 again) needs."""
+        world, rank = self.world, self.rank
+        send_to = (rank + 1) % world if g + 1 < len(self.plan) else None
+        carry_src = None
+        if rank > 0:
+            recv_from = rank - 1
+        else:
+            recv_from = world - 1 if q * world + world < len(self.plan) else None      # consumed in round q+1
+            carry_src = self.halos.get(q - 1) if g > 0 else None
+        if world == 1:
+            send_to = recv_from = None
+        h = _Halo(self.dist, send_to, recv_from, (self.T - 1,) + self.halo_dims, self.device, carry_src=carry_src)
+        self.halos[q] = h
+        self.halos.pop(q - 2, None)
+        return h
 
     def feed(self, merged):
         if self.replay is not None:
@@ -276,7 +359,7 @@ class _Job:
             self.replay = None
 
 
-def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False):
+def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False):
     """Videos as a stream through the round-robin schedule.  jobs: iterable of (chunk_frames, plan[, like]) as for
     run_round_robin (`like`: any [.., h, w] tensor on the device, for a rank that owns no chunk of a short video); yields each video's result in order (None on the ranks that do not replay).  Within a video the next round's per-frame
     work is queued before this round's clip work; ACROSS videos the first round of video k+1 is queued before the last round's
@@ -289,7 +372,7 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     def open_next():
         j = next(it, None)
         return None if j is None else _Job(model, j[0], j[1], rank, world, out_size, emit_masks, root_only,
-                                           like=j[2] if len(j) > 2 else None)
+                                           like=j[2] if len(j) > 2 else None, dist=dist, halo_exchange=halo_exchange)
 
     def finish(j):
         with ws():

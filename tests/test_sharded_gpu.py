@@ -49,28 +49,30 @@ def worker(rank, world, port, outdir):
         if os.environ.get("MDQE_TEST_SHARDING", "").startswith("stream"):
             root_only = os.environ["MDQE_TEST_SHARDING"] == "stream_root_only"
             jobs = []
+            halo = os.environ["MDQE_TEST_SHARDING"] == "stream_halo_exchange"
             for Lv, seed in STREAM:
                 v = _video(Lv, seed)
                 chunk = 8 if os.environ["MDQE_TEST_SHARDING"] == "stream_two_window_chunks" else 4     # tracker window = 4 frames
-                plan = sharding.chunk_plan(Lv, cfg.n_frames_test, cfg.clip_stride, chunk)
+                plan = sharding.chunk_plan(Lv, cfg.n_frames_test, cfg.clip_stride, chunk, halo_exchange=halo)
                 jobs.append(({g: v[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}, plan, v[:0].cuda()))
-            out = list(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (64, 96), root_only=root_only))
+            out = list(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (64, 96), root_only=root_only, halo_exchange=halo))
             assert len(out) == len(STREAM) and (not root_only or all((o is None) == (rank != 0) for o in out))
         elif os.environ.get("MDQE_TEST_SHARDING") == "contiguous":
             f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
             out = sharding.run_sharded(model, video[f0:f1].cuda(), f0, L, rank, world, dist, (64, 96))
         else:
-            plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, 4)       # 4-frame chunks -> 3 chunks, 2 rounds
+            halo = os.environ.get("MDQE_TEST_SHARDING") == "halo_exchange"
+            plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, 4, halo_exchange=halo)   # 4-frame chunks -> 3 chunks, 2 rounds
             frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}
             out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96),
-                                           root_only=os.environ.get("MDQE_TEST_SHARDING") == "root_only")
+                                           root_only=os.environ.get("MDQE_TEST_SHARDING") == "root_only", halo_exchange=halo)
             if os.environ.get("MDQE_TEST_SHARDING") == "root_only":
                 assert (out is None) == (rank != 0)
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["stream", "stream_root_only", "stream_two_window_chunks"])
+@pytest.mark.parametrize("mode", ["stream", "stream_root_only", "stream_two_window_chunks", "stream_halo_exchange"])
 def test_two_rank_stream_of_videos_equals_single_gpu(tmp_path, mode):
     """run_round_robin_stream over three videos of 3, 1 and 4 chunks (a rank sits out a last round, or a whole video): every video's
     result equals the single-process one, in order, on both ranks (all-ranks form) or on rank 0 (root-only form)."""
@@ -95,7 +97,7 @@ def test_two_rank_stream_of_videos_equals_single_gpu(tmp_path, mode):
             assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
 
 
-@pytest.mark.parametrize("mode", ["round_robin", "root_only", "contiguous"])
+@pytest.mark.parametrize("mode", ["round_robin", "root_only", "contiguous", "halo_exchange"])
 def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     os.environ["MDQE_TEST_SHARDING"] = mode

@@ -116,6 +116,19 @@ def test_round_robin_plan_covers_all_clips_in_order():
         assert owned == list(range(len(plan)))
 
 
+def test_halo_exchange_plan_partitions_frames_and_clips():
+    """chunk_plan(halo_exchange=True): the chunks partition the frames (no frame twice), every clip belongs to the chunk of its
+    LAST frame, a chunk's clips start at most T-1 frames before it, and every chunk holds a whole clip of its own."""
+    for L_, T, chunk in ((13, 3, 4), (120, 4, 30), (960, 4, 60), (61, 4, 30), (7, 4, 30), (33, 4, 30), (11, 3, 4), (14, 3, 4), (5, 3, 4)):
+        plan = sharding.chunk_plan(L_, T, 1, chunk, halo_exchange=True)
+        clips = clip_schedule(L_, T, 1)
+        assert [c for ch in plan for c in ch[0]] == clips
+        assert plan[0][1] == 0 and plan[-1][2] == L_ and all(a[2] == b[1] for a, b in zip(plan[:-1], plan[1:]))
+        for cl, f0, f1 in plan:
+            assert all(f0 <= e - 1 < f1 and s >= f0 - (T - 1) for s, e, _ in cl)
+            assert any(s >= f0 and e - s == min(T, L_) for s, e, _ in cl)
+
+
 def test_replay_thread_keeps_order_and_surfaces_errors():
     class Merger:
         def __init__(self):
