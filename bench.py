@@ -210,6 +210,10 @@ def main():
     ap.add_argument("--chunk-windows", type=int, default=2,
                     help="N > 1: frames per chunk, in tracker windows (a chunk carries a T-1 frame halo that is computed twice: "
                          "10 %% of a 30-frame chunk, 5 %% of a 60-frame one; the stream hides the longer replay tail)")
+    ap.add_argument("--halo-exchange", action="store_true",
+                    help="N > 1: no frame is computed twice -- a chunk's first clips read the left neighbour's last T-1 frames from shipped "
+                         "encoder tokens + mask features (one grouped send/recv per rank and round) instead of recomputing them "
+                         "(bit-identical; opt-in until it has been measured on a multi-GPU node)")
     ap.add_argument("--no-fast-mode", action="store_true",
                     help="skip the extra passes reported beside the headline (`stream_mode`, `fast_mode`, `init_reference`, `merge_on_cpu_alt`, `frames_resident`)")
     ap.add_argument("--config", choices=["R50_ovis_360", "R50_ovis_720", "swinl_ovis"], default="R50_ovis_360",
@@ -261,7 +265,7 @@ def main():
         chunk_frames = plan = None
     else:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
-        plan = sharding.chunk_plan(L, T, cfg.clip_stride, cfg.n_frames_window_test * args.chunk_windows)
+        plan = sharding.chunk_plan(L, T, cfg.clip_stride, cfg.n_frames_window_test * args.chunk_windows, halo_exchange=args.halo_exchange)
         chunk_frames = {g: synth_video(plan[g][1], plan[g][2], seed=0, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(plan, world, rank)}
     like = torch.zeros(0, 3, fh, fw, device="cuda")
     torch.cuda.synchronize()
@@ -288,10 +292,11 @@ def main():
                     pass
         elif not stream:
             for _ in range(k):
-                o = sharding.run_round_robin(mdl, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), root_only=True)
+                o = sharding.run_round_robin(mdl, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), root_only=True,
+                                             halo_exchange=args.halo_exchange)
         else:
             for o in sharding.run_round_robin_stream(mdl, ((chunk_frames, plan, like) for _ in range(k)), rank, world, dist,
-                                                     out_size=(fh, fw), root_only=True):
+                                                     out_size=(fh, fw), root_only=True, halo_exchange=args.halo_exchange):
                 pass
         return o
 
@@ -386,9 +391,11 @@ def main():
                        "merge_on_cpu": bool(cfg.merge_on_cpu) if world == 1 else True,     # (sharded videos stream their windows out: sharding._Job)
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
-                       "parallelism": ("1 process/GPU; %d-frame chunks dealt round-robin (pinned host, uploaded per chunk), per-round RCCL gather of the "
+                       "parallelism": ("1 process/GPU; %d-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
                                        "clip results to rank 0, whose native tracker replay runs on a worker thread under the next round"
-                                       % (cfg.n_frames_window_test * args.chunk_windows)) if world > 1 else "single GPU"},
+                                       % (cfg.n_frames_window_test * args.chunk_windows,
+                                          "halo exchange (T-1 frames of encoder tokens + mask features by send/recv)" if args.halo_exchange
+                                          else "a chunk's T-1 frame halo is computed by its owner again")) if world > 1 else "single GPU"},
         }
         if g:
             pk = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3
