@@ -40,26 +40,50 @@ stem_conv_kernel(const T* __restrict__ frames, long frame_stride, int h, int w, 
   const float* aP = sP + (wave * 2 + (lr >> 4)) * 2 * PITCH + (lr & 15) * 6 + lh;
   const float* bP = sW + lh * 64 + lr;
 
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // The patch of the NEXT tile is fetched into registers (raw values, 10 per thread) before the MFMA phase of the current one
+  // and normalised into LDS after it: the global-load latency hides behind the 154 MFMAs instead of sitting between two
+  // barriers (r01 PMC: matrix pipe busy 0.58).  A second LDS patch would cost the third block per CU.
+  constexpr int NE = (3 * PR * PCOL + 255) / 256;    // 10
+  T raw[NE];
+  unsigned ok = 0;
+  auto fetch = [&](long tile) __attribute__((always_inline)) {
     const int tx = (int)(tile % tiles_x);
     const long tt = tile / tiles_x;
     const int ty = (int)(tt % tiles_y), img = (int)(tt / tiles_y);
     const int iy0 = ty * TH * 2 - 3, ix0 = tx * TW * 2 - 3;
-    __syncthreads();                                   // previous tile's patch is no longer read (and sW is complete)
     const T* src = frames + (long)img * frame_stride;
-    for (int e = tid; e < 3 * PR * PCOL; e += 256) {
+    ok = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + i * 256;
       const int cc = e % PCOL, t = e / PCOL, r = t % PR, c = t / PR;
       const int iy = iy0 + r, ix = ix0 + cc;
-      float v = 0.f;
-      if (iy >= 0 && iy < h && ix >= 0 && ix < w) {    // the canvas beyond the real image is zero in normalised space
-        const float raw = (float)src[((long)c * h + iy) * w + ix];
+      raw[i] = (T)0;
+      if (e < 3 * PR * PCOL && iy >= 0 && iy < h && ix >= 0 && ix < w) {   // the canvas beyond the real image is zero in normalised space
+        raw[i] = src[((long)c * h + iy) * w + ix];
+        ok |= 1u << i;
+      }
+    }
+  };
+  if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tiles_x);
+    const long tt = tile / tiles_x;
+    const int ty = (int)(tt % tiles_y), img = (int)(tt / tiles_y);
+    __syncthreads();                                   // previous tile's patch is no longer read (and sW is complete)
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + i * 256;
+      if (e < 3 * PR * PCOL) {
+        const int cc = e % PCOL, t = e / PCOL, r = t % PR, c = t / PR;
         const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
         const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-        v = (raw - mean) / sd;
+        sP[r * PITCH + cc * 3 + c] = (ok >> i) & 1u ? ((float)raw[i] - mean) / sd : 0.f;
       }
-      sP[r * PITCH + cc * 3 + c] = v;
     }
     __syncthreads();
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);      // in flight during this tile's MFMAs
 
     f32x16 acc0, acc1;
 #pragma unroll
