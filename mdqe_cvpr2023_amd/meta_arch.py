@@ -303,9 +303,12 @@ class MDQE(nn.Module):
                             own_first[k] = v[count:count + Tn - 1].clone()
                     count += n_new
                     nxt = c1
-                if halo is not None and nxt >= n_local and not halo.tail_sent:      # (issued on the frame stream: ordered behind the last pass)
+                if halo is not None and nxt >= n_local and tail_state["views"] is None and not halo.tail_sent:
                     k_t = min(Tn - 1, count)
-                    halo.on_tail(rings[slot]["enc"][count - k_t:count], rings[slot]["mf"][count - k_t:count])
+                    tail_state["views"] = (rings[slot]["enc"][count - k_t:count], rings[slot]["mf"][count - k_t:count])
+                    tail_state["ev"] = torch.cuda.Event() if cuda else None
+                    if cuda:
+                        tail_state["ev"].record(fstream)
                 ready = None
                 if cuda:
                     ready = torch.cuda.Event()
@@ -320,6 +323,21 @@ class MDQE(nn.Module):
             if on_frames_queued is not None and nxt >= n_local:
                 cb, on_frames_queued = on_frames_queued, None
                 cb()
+
+        tail_state = {"views": None, "ev": None}
+
+        def send_tail():
+            """The grouped send/recv of the halo exchange, on the frame stream behind the chunk's last pass.  Never while the
+            generator is being primed: every rank must issue it at the same point of its program -- between the gathers of two
+            rounds -- or a rank whose chunk is a single pass would queue it BEFORE the previous round's gather and RCCL, which runs
+            a rank's operations in issue order, would deadlock against a rank that queued it after."""
+            if halo is None or halo.tail_sent or tail_state["views"] is None:
+                return
+            ctx = torch.cuda.stream(fstream) if cuda else contextlib.nullcontext()
+            with ctx:
+                if cuda:
+                    fstream.wait_event(tail_state["ev"])
+                halo.on_tail(*tail_state["views"])
 
         from collections import deque
         states = deque()                          # prepared (queued on the frame stream) and not yet decoded, in clip order
@@ -353,6 +371,7 @@ class MDQE(nn.Module):
             # the HIP trace, tools/trace_gaps.py)
             while len(states) < NR and plan_next():
                 pass
+            send_tail()
             cur = states.popleft()
             cache, base, T = cur["cache"], cur["base"], cur["T"]
             group = clips[cur["i"]:cur["j"]]
