@@ -65,7 +65,9 @@ mha_small_kernel(const float* __restrict__ qk, long ldqk, const float* __restric
 // NWV waves per (batch, head) (7 for D = 32, 4 for D = 24, by measurement), K and V in LDS (rows padded to 36 floats), S^T tiles = K_tile . (q * D^-0.5)^T on
 // v_mfma_f32_16x16x4_f32 with the head dimension walked as d = (D/4)*(lane>>4) + t, probabilities kept in the
 // accumulator registers and fed straight into the P . V product (its k index follows the same key order).
-template <int D, int NWV>
+// VG: V is read straight from global memory (L1 / L2) instead of LDS: the block then holds 30 KB instead of 60 KB of LDS and five
+// blocks instead of two share a CU -- the softmax between the two products of one wave hides behind the MFMAs of more others.
+template <int D, int NWV, bool VG = false>
 __global__ void __launch_bounds__(64 * NWV)
 mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __restrict__ v, long ldv, float* __restrict__ o,
                       long ldo, int Q, int C, int nh) {
@@ -73,7 +75,7 @@ mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __re
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NT = (Q + 15) / 16, NP = NT * 16;
   float* sK = sm;                                    // [NP][36] (rows >= Q zero)
-  float* sV = sm + NP * LDK;
+  float* sV = sm + (VG ? 0 : NP * LDK);
   const int b = blockIdx.x / nh, h = blockIdx.x % nh;
   const long row0 = (long)b * Q;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,9 +88,11 @@ mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __re
       vv = *reinterpret_cast<const f32x4*>(v + (row0 + r) * ldv + h * D + c4 * 4);
     }
     *reinterpret_cast<f32x4*>(sK + r * LDK + c4 * 4) = kk;
-    *reinterpret_cast<f32x4*>(sV + r * LDK + c4 * 4) = vv;
+    if (!VG) *reinterpret_cast<f32x4*>(sV + r * LDK + c4 * 4) = vv;
   }
   __syncthreads();
+  const float* vg = v + row0 * ldv + h * D + lc;     // VG: V[key][d = lc] = vg[key * ldv] (and d = 16 + lc at +16)
+  const bool d1 = 16 + lc < D;
   const float sc = rsqrtf((float)D) * 1.4426950408889634f;
   for (int rt = wave; rt < NT; rt += NWV) {
     const int i0 = rt * 16;
@@ -136,13 +140,20 @@ mha_small_mfma_kernel(const float* __restrict__ qk, long ldqk, const float* __re
       if (jt < NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float* vr = sV + (jt * 16 + 4 * g + r) * LDK + lc;
-          if (jt & 1) {
-            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], p1, 0, 0, 0);
+          float v0, v1;
+          if (VG) {                                  // keys >= Q carry probability 0: any finite row will do
+            const float* vr = vg + (long)min(jt * 16 + 4 * g + r, Q - 1) * ldv;
+            v0 = vr[0]; v1 = d1 ? vr[16] : 0.f;
           } else {
-            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[0], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], vr[16], o1, 0, 0, 0);   // columns >= D are zero in LDS
+            const float* vr = sV + (jt * 16 + 4 * g + r) * LDK + lc;
+            v0 = vr[0]; v1 = vr[16];                 // columns >= D are zero in LDS
+          }
+          if (jt & 1) {
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], v0, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], v1, p1, 0, 0, 0);
+          } else {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], v0, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[jt][r], v1, o1, 0, 0, 0);
           }
         }
       }
@@ -178,6 +189,14 @@ extern "C" int mdqe_mha_small_f32(const float* qk, long ldqk, const float* v, lo
     // 13: 100; D = 24: 4 waves win.  g_mha_variant 1 = that choice; 2 -> 3 waves, 3 -> 7, 4 -> 13, 5 -> 4 (A/B)
 #define LM(DD, NW_) hipLaunchKernelGGL((mha_small_mfma_kernel<DD, NW_>), dim3(B * nh), dim3(64 * NW_), smem2, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh)
     const int nwv = g_mha_variant == 2 ? 3 : g_mha_variant == 3 ? 7 : g_mha_variant == 4 ? 13 : g_mha_variant == 5 ? 4 : (D == 32 ? 7 : 4);
+    if (g_mha_variant >= 6 && g_mha_variant <= 8) {     // A/B: V from global memory (half the LDS), 7 / 4 / 3 waves
+      const size_t smem1 = (size_t)((Q + 15) / 16 * 16) * 36 * sizeof(float);
+#define LG(DD, NW_) hipLaunchKernelGGL((mha_small_mfma_kernel<DD, NW_, true>), dim3(B * nh), dim3(64 * NW_), smem1, st, qk, ldqk, v, ldv, o, ldo, Q, C, nh)
+      if (D == 32) { if (g_mha_variant == 6) LG(32, 7); else if (g_mha_variant == 7) LG(32, 4); else LG(32, 3); }
+      else         { if (g_mha_variant == 6) LG(24, 7); else if (g_mha_variant == 7) LG(24, 4); else LG(24, 3); }
+#undef LG
+      return mdqe_launch_status();
+    }
     if (D == 32) { if (nwv == 3) LM(32, 3); else if (nwv == 7) LM(32, 7); else if (nwv == 13) LM(32, 13); else LM(32, 4); }
     else         { if (nwv == 3) LM(24, 3); else if (nwv == 7) LM(24, 7); else if (nwv == 13) LM(24, 13); else LM(24, 4); }
 #undef LM

@@ -8,12 +8,15 @@ from kbench import time_ms
 for (B, Q, C, nh) in ((148, 196, 256, 8), (108, 196, 256, 8), (27, 196, 256, 8), (40, 196, 192, 8)):
     qk = torch.randn(B * Q, 2 * C, device="cuda"); v = torch.randn(B * Q, C, device="cuda")
     t = []
-    for var in (0, 2, 5, 3, 4):
+    outs = []
+    for var in (0, 2, 5, 3, 4, 6, 7, 8):
         lib.mdqe_debug_mha_variant(var)
+        outs.append(ops.mha_small(qk, v, B, Q, C, nh))
         t.append(time_ms(lambda: ops.mha_small(qk, v, B, Q, C, nh), iters=30, warm=5))
     fl = 4.0 * B * nh * Q * Q * (C // nh)
-    print("mha B=%d Q=%d D=%d: scalar %.1f us | mfma 3 waves %.1f | 4 waves %.1f us (%.1f TF) | 7 waves %.1f | 13 waves %.1f" % (
-        B, Q, C // nh, 1e3 * t[0], 1e3 * t[1], 1e3 * t[2], fl / t[2] / 1e9, 1e3 * t[3], 1e3 * t[4]))
+    same = all(torch.equal(outs[3], x) for x in outs[5:])
+    print("mha B=%d Q=%d D=%d: scalar %.1f us | mfma 3 waves %.1f | 4 waves %.1f us (%.1f TF) | 7 waves %.1f | 13 waves %.1f | V from global: 7 waves %.1f, 4 waves %.1f, 3 waves %.1f (bitwise equal to the LDS form: %s)" % (
+        B, Q, C // nh, 1e3 * t[0], 1e3 * t[1], 1e3 * t[2], fl / t[2] / 1e9, 1e3 * t[3], 1e3 * t[4], 1e3 * t[5], 1e3 * t[6], 1e3 * t[7], same))
 if len(sys.argv) > 1 and sys.argv[1] == "mha":
     sys.exit(0)
 cases = ((7200, 144, 6), (1800, 144, 12), (600, 144, 24), (1200, 36, 48))
