@@ -4,7 +4,7 @@
     video output -- per-clip mask logits, scores, labels, tracker windows and final boolean masks (mdqe/mdqe.py:291-471);
   * R50_ovis_720 geometry (640x1138 -> 640x1152, N=15300, levels 80x144 .. 10x18, 160x288 mask maps;
     configs/R50_ovis_720.yaml): the same chain stage by stage + size-independent MSDA properties on the 640p level table;
-  * swinl_ovis at 480x853 (-> 480x864, C=192, D=24, N=8617): Swin-L backbone + encoder.
+  * swinl_ovis at 480x853 (-> 480x864, C=192, D=24, N=8617, 2-frame clips): the same chain with the Swin-L backbone.
 
 Two kinds of comparison.  `direct`: product and oracle each run from the frames.  `chained`: every product stage is fed the
 ORACLE's output of the stage before it, so that a discrete decision that falls the other way on a near-tie (arg-max of a
@@ -43,6 +43,12 @@ def _hyper(cfg):
                    clip_stride=cfg.clip_stride)
 
 
+def _backbone_fn(cfg, sd):
+    if cfg.backbone == "SwinV2":
+        return lambda im: O.swinv2(sd, "detr.backbone.0.backbone", im, O.SwinHyper())
+    return lambda im: O.resnet(sd, "detr.backbone.0.backbone", im, 50)
+
+
 @functools.lru_cache(maxsize=None)
 def _workload(name, fh, fw, n_frames, window, max_inst=120):
     """Weights (random reference-style init, zero-init trap removed, class logits calibrated on the synthetic video so that
@@ -65,7 +71,7 @@ def _workload(name, fh, fw, n_frames, window, max_inst=120):
     ops.set_gemm_precision(prec)
     frames = list(synth_video(0, n_frames, seed=0, h=fh, w=fw))
     hp = _hyper(cfg)
-    bb = lambda im: O.resnet(sd, "detr.backbone.0.backbone", im, 50)
+    bb = _backbone_fn(cfg, sd)
     ref = {"frames": frames, "sd": sd, "cfg": cfg, "hp": hp}
     with torch.no_grad():
         x, sizes = O.pad_frames(O.preprocess(hp, frames), 32)
@@ -232,39 +238,16 @@ def test_msda_640p_level_table_properties():
         assert maxdiff(o1[1:2, q0:q0 + 200].cpu(), ref) < 2e-5
 
 
-def test_swinl_ovis_480p_backbone_and_encoder(gemm_precision):
-    """swinl_ovis.yaml at its own size: 2 frames of 480x853 -> 480x864, Swin-L (window 12/6, 195 M parameters) stage3/4/5 maps
-    and the 6-layer encoder (C=192, head dim 24, N=8617) against the oracle."""
-    from mdqe_cvpr2023_amd.config import SWINL_OVIS
-    ref = _swin_reference()
-    from mdqe_cvpr2023_amd.meta_arch import MDQE
-    model = MDQE(SWINL_OVIS, state_dict=ref["sd"]).eval()
-    eng = model.engine
-    geo = eng.geometry(480, 853)
+def test_swinl_ovis_480p_full_size(gemm_precision):
+    """swinl_ovis.yaml at its own size: 3 frames of 480x853 -> 480x864, Swin-L (window 12/6, 195 M parameters), hidden 192 (head
+    dim 24, mask dim 24, N = 8617), 2-frame clips: the same chained + direct comparison as the R50 configurations -- stage3/4/5
+    maps through the encoder and mask head, decoder, inference_clip, tracker, final masks."""
+    ref = _workload("swinl_ovis", 480, 853, 3, 20, 40)
+    model = _model(ref)
+    geo = model.engine.geometry(480, 853)
     assert (geo.Hp, geo.Wp, geo.N) == (480, 864, 8617) and geo.shapes == [(60, 108), (30, 54), (15, 27), (8, 14)]
-    with torch.no_grad():
-        feats = eng.backbone(torch.stack(ref["frames"]).cuda(), geo)
-        enc = eng.encode(feats, geo)
-    for o, r in zip(feats, ref["feats"]):
-        assert maxdiff(o.permute(0, 3, 1, 2).cpu(), r) < 1e-3 * max(1.0, float(r.abs().max()))
-    assert maxdiff(enc.cpu(), ref["enc"]) < 1e-3 * max(1.0, float(ref["enc"].abs().max()))
-
-
-@functools.lru_cache(maxsize=None)
-def _swin_reference():
-    from bench import synth_video
-    from mdqe_cvpr2023_amd.config import SWINL_OVIS
-    from mdqe_cvpr2023_amd.params import random_state
-    sd = random_state(SWINL_OVIS, seed=1)
-    frames = list(synth_video(0, 2, seed=2, h=480, w=853))
-    hp = O.Hyper(hidden_dim=192, n_frames=2, n_frames_test=2, n_frames_window_test=20)
-    with torch.no_grad():
-        x, sizes = O.pad_frames(O.preprocess(hp, frames), 32)
-        feats = O.swinv2(sd, "detr.backbone.0.backbone", x, O.SwinHyper())
-        masks = O.padding_masks(2, [tuple(f.shape[-2:]) for f in feats], (8, 16, 32), sizes)
-        xr, mr, pr, shapes = O.input_proj_and_flatten(sd, hp, feats, masks)
-        enc = O.encoder(sd, hp, xr, mr, pr, shapes)
-    return {"sd": sd, "frames": frames, "feats": feats, "enc": enc}
+    _chain(ref, model, 480, 853)
+    _direct(ref, model, 480, 853)
 
 
 def test_checkpoint_load_path_equals_constructor_path():
