@@ -277,7 +277,8 @@ def _conv_bn(sd, p, x, stride=1, padding=0, relu=True):
 
 
 def resnet(sd, p, x, depth=50):
-    """STRIDE_IN_1X1 False (configs/R50_coco.yaml:7-10): stride sits on the 3x3. Returns res3,res4,res5."""
+    """STRIDE_IN_1X1 False (configs/R50_coco.yaml:7-10): stride sits on the 3x3. Returns res3,res4,res5.
+    detectron2 is absent here; pinned against transformers.ResNetModel (same architecture) in tests/test_resnet_pin_cpu.py."""
     x = _conv_bn(sd, p + ".stem.conv1", x, 2, 3)
     x = F.max_pool2d(x, 3, 2, 1)
     outs = []
