@@ -9,8 +9,9 @@ from mdqe_cvpr2023_amd.config import MDQEConfig
 from mdqe_cvpr2023_amd.engine import Engine
 
 n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-bad = bad_tie = checked = 0
-for it in range(n_batches):
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = bad_tie = bad_swap = checked = 0
+for it in range(first, n_batches):
     g = torch.Generator().manual_seed(1000 + it)
     B = int(torch.randint(1, 9, (1,), generator=g)); Q = [16, 36, 100, 196][it % 4]; K = [5, 25][it % 2]; C = [32, 64, 256][it % 3]
     M = [8, 24, 32][it % 3]; T = [1, 2, 4, 5][it % 4]; Hm, Wm = [(8, 12), (16, 24), (24, 40)][it % 3]
@@ -45,12 +46,27 @@ for it in range(n_batches):
         ok = r["pred_masks"].shape == ref["pred_masks"].shape and r["pred_classes"].tolist() == ref["pred_classes"].tolist()
         ok = ok and float((r["pred_masks"].cpu() - ref["pred_masks"]).abs().max() if ref["pred_masks"].numel() else 0.0) < 1e-4
         ok = ok and float((r["scores"].cpu() - ref["scores"]).abs().max() if ref["scores"].numel() else 0.0) < 1e-5
+        swap = False
+        if not ok and r["pred_masks"].shape == ref["pred_masks"].shape and ref["scores"].numel():
+            # the same SET of instances in another order?  (two final scores closer than the fp32 noise of the rescoring product)
+            gm, gs, gc = r["pred_masks"].cpu().flatten(1), r["scores"].cpu(), r["pred_classes"].cpu()
+            used, swap = set(), True
+            for k in range(ref["scores"].numel()):
+                d = (gm - ref["pred_masks"][k].flatten()[None]).abs().amax(1)
+                cand = [j for j in range(len(d)) if j not in used and float(d[j]) < 1e-4 and int(gc[j]) == int(ref["pred_classes"][k])
+                        and abs(float(gs[j]) - float(ref["scores"][k])) < 1e-5]
+                if not cand:
+                    swap = False
+                    break
+                used.add(cand[0])
         if not ok:
             bad += 1
             bad_tie += b in tied
+            bad_swap += swap and b not in tied
             print("MISMATCH%s batch %d clip %d (Q=%d K=%d C=%d M=%d T=%d thr=%.3f): got %d instances %s / oracle %d %s" % (
-                " (injected score tie)" if b in tied else "", it, b, Q, K, C, M, T, thr, r["scores"].numel(), [round(float(v), 4) for v in r["scores"].cpu()][:6],
+                " (injected score tie)" if b in tied else (" (same instances, order of near-equal scores)" if swap else ""), it, b, Q, K, C, M, T, thr, r["scores"].numel(), [round(float(v), 4) for v in r["scores"].cpu()][:6],
                 ref["scores"].numel(), [round(float(v), 4) for v in ref["scores"]][:6]), flush=True)
-print("fuzz: %d clips checked, %d mismatches, %d of them in clips with an injected exact score tie (order left open by the reference's "
-      "unstable sort; torch.sort(stable=True) and the kernel both break ties by query index)" % (checked, bad, bad_tie))
-sys.exit(1 if bad != bad_tie else 0)
+print("fuzz: %d clips checked, %d mismatches: %d in clips with an injected exact score tie (order left open by the reference's unstable "
+      "sort; torch.sort(stable=True) and the kernel both break ties by query index), %d with the same instances in another order of "
+      "near-equal final scores, %d other" % (checked, bad, bad_tie, bad_swap, bad - bad_tie - bad_swap))
+sys.exit(1 if bad != bad_tie + bad_swap else 0)
