@@ -64,3 +64,14 @@ def test_native_core_first_clip_new_ids_and_duplicates():
     assert m.shape == (3, 3) + hw and c.shape == (3, K)
     assert bool((m[0, :, 0] > 0).all()) and bool((m[1, :, 1] > 0).all())      # ids kept their rows across the swap
     assert bool((m[2, 1:, 2] > 0).all()) and bool((m[2, 0] == 0).all())
+
+
+def test_native_core_equals_the_oracle_tracker_on_random_sequences():
+    """40 random clip sequences (persistent / appearing / vanishing / duplicated objects, random clip length and window): the native
+    core with a torch stand-in bank against the oracle's restatement of OverTracker (itself held to the reference's recorded sequence in
+    test_oracle_golden.py) -- instance counts after every clip, class scores and mean logits of every window."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_tracker
+    for seed in range(40):
+        assert fuzz_tracker.run(seed) is None, seed
