@@ -45,21 +45,36 @@ def sequence(seed):
     return T, win, E, K, hw, clips
 
 
-def run(seed):
+def run(seed, gpu=False, many=False):
+    """gpu: the product tracker (HIP bank kernels) instead of the torch stand-in; many: the clips between two flushes go through
+    update_many (one native call)."""
     T, win, E, K, hw, clips = sequence(seed)
     hp = O.Hyper(hidden_dim=E, num_classes=K, n_frames_test=T, n_frames_window_test=win, n_max_inst=24, apply_cls_thres=0.1)
     ref = O.Tracker(hp, hw)
-    trk = TorchBankTracker(24, T, win, 1, K, 4, E, hw, torch.device("cpu"), 0.1)
-    saved = 0
+    if gpu:
+        from mdqe_cvpr2023_amd.tracking import OverTracker
+        trk = OverTracker(24, T, win, 1, K, 4, E, hw, torch.device("cuda"), 0.1)
+    else:
+        trk = TorchBankTracker(24, T, win, 1, K, 4, E, hw, torch.device("cpu"), 0.1)
+    saved, run_ = 0, []
     for s, e, last, r in clips:
         c = dict(r); c["frame_idx"] = list(range(s, e))
         ref.update(c)
-        trk.update(Clips(range(s, e), r))
-        if trk.num_inst != ref.num_inst:
+        rr = dict(r, pred_masks=r["pred_masks"].cuda()) if gpu else r
+        flush = last or (s + 1 >= win * (saved + 1))
+        if gpu and many:
+            run_.append(Clips(range(s, e), rr))
+            if flush:
+                trk.update_many(run_)
+                run_ = []
+        else:
+            trk.update(Clips(range(s, e), rr))
+        if (flush or not (gpu and many)) and trk.num_inst != ref.num_inst:
             return "num_inst %d vs %d after clip %d" % (trk.num_inst, ref.num_inst, s)
-        if last or (s + 1 >= win * (saved + 1)):
+        if flush:
             c0, m0 = ref.get_result(last)
             c1, m1 = trk.get_result(last)
+            m1 = m1.cpu()
             if m0.shape != m1.shape or float((m0 - m1).abs().max() if m0.numel() else 0) > 1e-5 or float((c0 - c1).abs().max() if c0.numel() else 0) > 1e-6:
                 return "window %d differs" % saved
             saved += 1
@@ -68,10 +83,11 @@ def run(seed):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    gpu = "--gpu" in sys.argv
     bad = 0
     for seed in range(n):
         try:
-            r = run(seed)
+            r = run(seed, gpu=gpu, many=gpu and seed % 2 == 1)
         except Exception as ex:                                      # both sides raise on the same overflow conditions or neither
             r = "exception %r" % (ex,)
         if r:
