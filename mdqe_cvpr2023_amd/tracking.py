@@ -139,7 +139,7 @@ class OverTracker(TrackerCore):
         self._cap = 0
 
     def _scratch(self, n_in):
-        if n_in > self._cap:
+        if self._counts_dev is None or n_in > self._cap:         # (also for a first clip without instances)
             self._cap = max(64, 2 * n_in)
             self._counts_dev = torch.empty(self.max_inst * self._cap * 3, device=self.device)
             self._counts_host = torch.empty(self.max_inst * self._cap * 3, pin_memory=True)
