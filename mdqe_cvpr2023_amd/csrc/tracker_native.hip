@@ -486,10 +486,10 @@ extern "C" int mdqe_tracker_update_many(void* handle, float* bank_sum, float* ba
 // (its capacity must be max_inst*max(win, mem_len)*hw floats, or the caller sizes it from mdqe_tracker_state first).
 extern "C" int mdqe_tracker_get_result(void* handle, int is_last, float* bank_sum, float* bank_cnt, long hw, float* out_masks,
                                        float* carry, float* out_cls, int* n, int* ln, void* stream) {
-  MDQE_CHECK_PTR(handle); MDQE_CHECK_PTR(bank_sum); MDQE_CHECK_PTR(bank_cnt); MDQE_CHECK_PTR(out_masks); MDQE_CHECK_PTR(out_cls);
+  MDQE_CHECK_PTR(handle); MDQE_CHECK_PTR(bank_sum); MDQE_CHECK_PTR(bank_cnt); MDQE_CHECK_PTR(out_cls);
   MDQE_CHECK_PTR(n); MDQE_CHECK_PTR(ln);
   Tracker* t = static_cast<Tracker*>(handle);
-  if (!is_last) MDQE_CHECK_PTR(carry);
+  if (t->num_inst > 0) { MDQE_CHECK_PTR(out_masks); if (!is_last) MDQE_CHECK_PTR(carry); }   // (a window without any track: empty outputs)
   const int rc = t->result(is_last, out_cls, n, ln, nullptr);
   if (rc != MDQE_OK) return rc;
   int rc2 = mdqe_trk_window_mean_f32(bank_sum, bank_cnt, hw, t->mem_len, *n, *ln, 0, out_masks, stream);
