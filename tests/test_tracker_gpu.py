@@ -70,3 +70,14 @@ def test_hip_tracker_more_than_128_new_tracks_in_one_clip():
     assert trk.num_inst == n
     c, m = trk.get_result(True)
     assert m.shape == (n, 2) + hw and torch.equal(m, masks)
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_hip_tracker_equals_the_oracle_on_random_sequences(many):
+    """Random clip sequences (tools/fuzz_tracker.py) on the HIP bank, clip by clip and through update_many -- among them the two edge
+    cases the fuzz found in round 2: a first clip without any instance (seeds 284, 286) and a window flushed without any track (82, 99)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_tracker
+    for seed in (82, 99, 284, 286, 0, 1, 2, 3, 4, 5, 6, 7):
+        assert fuzz_tracker.run(seed, gpu=True, many=many) is None, seed
