@@ -3,8 +3,9 @@
 Call site: instances_to_coco_json_video (mdqe/data/ytvis_eval.py:288-324) -> pycocotools `encode`
 (mdqe/data/pycocotools/_mask.pyx:42,137-140 -> rleEncode, rleToString).  The C core (common/maskApi.c of cocoapi, third
 party) is NOT in the reference tree and pycocotools is not installed here, so this file restates the published algorithm
-and is **parity unpinned** (no reference-generated vectors; the tests check the device path against this file and through
-encode -> decode round trips):
+and is **parity unpinned** for the string packing (no reference-generated vectors; the tests check the device path against
+this file and through encode -> decode round trips).  The run lengths (rleEncode) ARE held to an independent implementation:
+`transformers`' SAM post-processing `_mask_to_rle` (tests/test_rle_cpu.py::test_run_lengths_pinned_against_an_independent_implementation):
 
   rleEncode:   the mask is read in COLUMN-major order; counts = lengths of alternating runs, the first run counts zeros
                (it is 0 when the mask starts with a one).

@@ -46,3 +46,26 @@ def test_result_writer_layout():
     rec = R.instances_to_coco_json_video([{"video_id": 11, "length": 2}], out)
     assert rec == [{"video_id": 11, "score": 0.9, "category_id": 3,
                     "segmentations": [{"size": [4, 4], "counts": "`0"}, {"size": [4, 4], "counts": "`0"}]}]
+
+
+def test_run_lengths_pinned_against_an_independent_implementation():
+    """The rleEncode half (column-major run lengths, zeros run first) held to an implementation that is neither the reference's nor
+    ours: `_mask_to_rle` of the `transformers` package in this image (its SAM post-processing, 'in the format expected by pycoco
+    tools').  The string packing of rleToString has no independent implementation here and stays parity-unpinned."""
+    import pytest
+    import torch
+    sam = pytest.importorskip("transformers.models.sam.image_processing_pil_sam")      # (the torchvision-free twin)
+    rng = np.random.RandomState(5)
+    masks = [np.zeros((6, 9), bool), np.ones((6, 9), bool)]
+    for _ in range(60):
+        h, w = rng.randint(1, 50), rng.randint(1, 50)
+        masks.append(rng.rand(h, w) < rng.rand())
+    blob = np.zeros((40, 64), bool); blob[5:30, 10:50] = 1; blob[0, 0] = 1
+    masks.append(blob)
+    for m in masks:
+        ref = sam._mask_to_rle(torch.from_numpy(m)[None])[0]
+        assert ref["size"] == list(m.shape)
+        assert RO.rle_counts(m) == [int(c) for c in ref["counts"]]
+        # ... and the product's packing decodes back to those run lengths
+        assert RO.rle_from_string(R.encode_dense(m)["counts"].encode()) == [int(c) for c in ref["counts"]]
+        assert (np.asarray(sam._rle_to_mask(ref)) == m).all()
