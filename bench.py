@@ -227,13 +227,19 @@ def main():
     # test hooks (1-GPU box): MDQE_BENCH_BACKEND=gloo + MDQE_BENCH_ONE_DEVICE=1 run all ranks on cuda:0 without RCCL
     one_dev = os.environ.get("MDQE_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("MDQE_BENCH_BACKEND", "nccl")
+    # MDQE_BENCH_FORCE_SHARDED=1: take the N > 1 path (chunks, per-round gather, replay thread) with whatever world size there is --
+    # on a 1-GPU box that runs the sharded schedule through a ONE-rank RCCL communicator (the only RCCL execution a single GPU allows)
+    sharded = world > 1 or os.environ.get("MDQE_BENCH_FORCE_SHARDED") == "1"
     if one_dev:
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -259,7 +265,7 @@ def main():
     # 228-263); the host->device copy of a1 (mdqe/mdqe.py:480) is part of every timed step.
     L = args.frames * world
     T = cfg.n_frames_test
-    if world == 1:
+    if not sharded:
         video = synth_video(0, L, seed=0, h=fh, w=fw).pin_memory()
         host_frames = list(video)                          # L views [3,h,w] of the pinned block
         chunk_frames = plan = None
@@ -282,7 +288,7 @@ def main():
         reference's evaluator calls the model once per video, train_net.py:207).  stream=True: MDQE.forward_stream /
         sharding.run_round_robin_stream -- the next video's first pass (round) is queued under the current video's tracker tail."""
         o = None
-        if world == 1:
+        if not sharded:
             inp = [{"image": resident if resident is not None else host_frames, "height": fh, "width": fw}]
             if not stream:
                 for _ in range(k):
@@ -326,7 +332,7 @@ def main():
     # the chip with the clip-stream / tracker-stream kernels, which stretches its per-launch duration without being a
     # property of the kernel; both figures are reported.
     g_iso = None
-    if world == 1:
+    if not sharded:
         meter.rec = []
         model.overlap_streams = False
         with torch.no_grad():
@@ -344,7 +350,7 @@ def main():
         if args.precision == "f32":
             d, _ = timed("f16x3", False)
             extra["fast_mode"] = dict(rate(d), gemm="f16x3 split precision (fp32 in/out, 3 f16 MFMAs, ~1e-6 rel. to fp32; same parity tests)")
-        if world == 1:
+        if not sharded:
             res = torch.stack(host_frames).cuda()
             d, _ = timed(args.precision, False, resident=res)
             extra["frames_resident"] = dict(rate(d), what="the same steps with the video already in HBM (no host->device copy in the step)")
@@ -365,7 +371,7 @@ def main():
                 del m_ref, sd_ref
     ops.set_gemm_precision("f32")
 
-    if args.stages and rank == 0 and world == 1:
+    if args.stages and rank == 0 and not sharded:
         from mdqe_cvpr2023_amd import profiling
         with torch.no_grad():
             print(json.dumps({"stages_ms": profiling.stage_breakdown(model, torch.stack(host_frames).cuda())}), file=sys.stderr)
@@ -388,14 +394,14 @@ def main():
                        "instances_out": len(out["pred_scores"]),
                        "tracked_instances": len(set(m.data_ptr() for m in out["pred_masks"])) if "pred_masks" in out else None,
                        "output": "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
-                       "merge_on_cpu": bool(cfg.merge_on_cpu) if world == 1 else True,     # (sharded videos stream their windows out: sharding._Job)
+                       "merge_on_cpu": bool(cfg.merge_on_cpu) if not sharded else True,     # (sharded videos stream their windows out: sharding._Job)
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
                        "parallelism": ("1 process/GPU; %d-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
                                        "clip results to rank 0, whose native tracker replay runs on a worker thread under the next round"
                                        % (cfg.n_frames_window_test * args.chunk_windows,
                                           "halo exchange (T-1 frames of encoder tokens + mask features by send/recv)" if args.halo_exchange
-                                          else "a chunk's T-1 frame halo is computed by its owner again")) if world > 1 else "single GPU"},
+                                          else "a chunk's T-1 frame halo is computed by its owner again")) if sharded else "single GPU"},
         }
         if g:
             pk = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3
@@ -415,7 +421,7 @@ def main():
                                              "avg_launch_us": g_iso["avg_us"],
                                              "note": "same launches, one extra untimed step with all stages on one stream"}
         line.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
         print(json.dumps(line))
     if dist is not None:

@@ -68,6 +68,15 @@ def worker(rank, world, port, outdir):
                                            root_only=os.environ.get("MDQE_TEST_SHARDING") == "root_only", halo_exchange=halo)
             if os.environ.get("MDQE_TEST_SHARDING") == "root_only":
                 assert (out is None) == (rank != 0)
+    if os.environ.get("MDQE_TEST_P2P_SELF") == "1":
+        # sharding._Halo's grouped send/recv through the real backend, addressed to this rank itself (the only peer a 1-GPU box has)
+        h = sharding._Halo(dist, rank, rank, (2, 7, 16, 4, 6, 8), torch.device("cuda", dev))
+        g = torch.Generator().manual_seed(1)
+        enc, mf = torch.randn(2, 7, 16, generator=g).cuda(), torch.randn(2, 4, 6, 8, generator=g).cuda()
+        h.on_tail(enc, mf)
+        e2, m2 = h.head()
+        torch.cuda.synchronize()
+        assert torch.equal(e2, enc) and torch.equal(m2, mf)
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
@@ -114,6 +123,37 @@ def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
         ref = model([{"image": _video(), "height": 64, "width": 96}])
     for r in range(1 if mode == "root_only" else 2):
         out = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
+        assert out["pred_labels"] == ref["pred_labels"]
+        assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
+        assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
+
+
+@pytest.mark.parametrize("mode", ["round_robin", "root_only", "stream_root_only"])
+def test_one_rank_rccl_communicator(tmp_path, mode):
+    """The sharded schedule over the REAL backend of bench.py --gpus N (`nccl` = RCCL) with a one-rank communicator: all a 1-GPU box can
+    offer, but it puts every collective call of the path (all_gather of sizes, gather / all_gather of int64 + fp32 payloads, the
+    grouped isend/irecv of the halo exchange addressed to self, barrier-free teardown) through RCCL's argument checks, stream
+    handling and kernels beside the replay thread."""
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    os.environ["MDQE_TEST_SHARDING"] = mode
+    os.environ["MDQE_TEST_BACKEND"] = "nccl"
+    os.environ["MDQE_TEST_P2P_SELF"] = "1"
+    try:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        p = ctx.Process(target=worker, args=(0, 1, port, str(tmp_path)))
+        p.start()
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    finally:
+        del os.environ["MDQE_TEST_BACKEND"], os.environ["MDQE_TEST_P2P_SELF"]
+    model = MDQE(_cfg(), seed=5).eval()
+    with torch.no_grad():
+        vids = STREAM if mode.startswith("stream") else ((11, 2),)
+        refs = [model([{"image": _video(Lv, seed), "height": 64, "width": 96}]) for Lv, seed in vids]
+    outs = torch.load(os.path.join(str(tmp_path), "rank0.pt"), weights_only=False)
+    outs = outs if mode.startswith("stream") else [outs]
+    for out, ref in zip(outs, refs):
         assert out["pred_labels"] == ref["pred_labels"]
         assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
         assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
