@@ -675,7 +675,7 @@ class Engine:
             h = hs[r0:r0 + k]
             d = small[r0:r0 + k]
             results.append({"scores": d[:, 0], "pred_classes": labels[r0:r0 + k], "cls_probs": d[:, 2:2 + K], "pred_masks": pm[o:o + k],
-                            "query_embeds": d[:, 2 + K:],
+                            "query_embeds": d[:, 2 + K:], "rows": d,
                             "host": {"scores": h[:, 0], "cls_probs": h[:, 2:2 + K], "query_embeds": h[:, 2 + K:]}})
             o += k
         return results

@@ -184,6 +184,12 @@ class MDQE(nn.Module):
             bounds = [h] + list(range(h + fbatch, n_frames, fbatch)) + [n_frames]
             if len(bounds) >= 2 and bounds[-1] - bounds[-2] > t and n_frames - t - bounds[-2] >= 4:
                 bounds.insert(-1, n_frames - t)
+            if len(bounds) >= 3 and bounds[-1] - bounds[-2] < max(min(t, h) // 2, 1):
+                # a last pass of a handful of frames (a 60-frame chunk + its 3-frame halo: 20 / 40 / 3) runs every GEMM of the
+                # per-frame stages on a sliver: split what lies behind the first pass evenly instead (20 / 22 / 21)
+                r = n_frames - h
+                k = -(-r // fbatch)
+                bounds = [h] + [h + (r * (i + 1)) // k for i in range(k)]
         return bounds
 
     @staticmethod
@@ -363,7 +369,11 @@ class MDQE(nn.Module):
 
         plan_next()
         if primed:
-            yield None                            # per-frame work of the first chunk is queued; the caller resumes later
+            # a primed generator (sharded videos) is resumed only after the caller has gathered the previous round -- host syncs,
+            # collectives: the frame stream gets its whole look-ahead now so that it does not run dry meanwhile
+            while len(states) < NR and plan_next():
+                pass
+            yield None                            # per-frame work of the first passes is queued; the caller resumes later
         while states:
             # `lookahead` passes are queued BEFORE this group's clip work: with one, the frame stream ran dry at every group
             # boundary -- the clip kernels share the chip with the pass queued behind them and finish together with it, and

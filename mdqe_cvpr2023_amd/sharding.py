@@ -31,87 +31,89 @@ def owned_clips(clips, L, world, rank):
     return [c for c in clips if a <= c[0] < b]
 
 
-def pack(results, T, device):
-    """list of (start,end,last,res) -> dict of padded tensors [n_clips, n_max, ...] + meta [n_clips,4]."""
+def pack(results, T, device, proto_shapes):
+    """list of (start,end,last,res) -> (meta [n_clips,4] int64, vec [n_inst, 2+K+C] fp32, masks [n_inst, T, h, w] fp32): the
+    instances of all clips back to back (no padding per clip).  vec columns = score | class | cls_probs | query_embeds -- the layout
+    the engine already holds them in (`res["rows"]`, engine.inference_clips), so a round is packed by two concatenations."""
     n = len(results)
-    nmax = max([len(r[3]["scores"]) for r in results], default=0)
+    K, C = proto_shapes["cls_probs"][0][0], proto_shapes["query_embeds"][0][0]
+    hw = tuple(proto_shapes["pred_masks"][0][1:])
     meta = torch.tensor([[s, e, int(l), len(r["scores"])] for s, e, l, r in results], dtype=torch.int64, device=device).view(n, 4)
-    out = {"meta": meta}
-    for f in FIELDS:
-        if n == 0:
-            out[f] = None
+    rows, masks = [], []
+    for s, e, _, r in results:
+        k = len(r["scores"])
+        if k == 0:
             continue
-        proto = results[0][3][f]
-        shape = list(proto.shape[1:])
-        if f == "pred_masks":
-            shape[0] = T                                   # the short last clip is padded in time
-        buf = torch.zeros([n, nmax] + shape, dtype=proto.dtype, device=device)
-        for i, (_, _, _, r) in enumerate(results):
-            t = r[f]
-            if f == "pred_masks":
-                buf[i, :t.shape[0], :t.shape[1]] = t
-            else:
-                buf[i, :t.shape[0]] = t
-        out[f] = buf
-    return out, nmax
+        v = r.get("rows")
+        if v is None:
+            v = torch.cat([r["scores"].reshape(k, 1).float(), r["pred_classes"].reshape(k, 1).float(), r["cls_probs"].reshape(k, K).float(),
+                           r["query_embeds"].reshape(k, C).float()], 1)
+        rows.append(v)
+        m = r["pred_masks"]
+        if m.shape[1] != T:                                # the short last clip is padded in time
+            m = torch.cat([m, m.new_zeros((k, T - m.shape[1]) + hw)], 1)
+        masks.append(m)
+    vec = torch.cat(rows).to(device) if rows else torch.zeros(0, 2 + K + C, device=device)
+    msk = torch.cat(masks).to(device) if masks else torch.zeros((0, T) + hw, device=device)
+    return meta, vec.contiguous(), msk.contiguous()
 
 
 def all_gather_clips(local, T, dist, world, device, proto_shapes, root=None, rank=0):
-    """Variable-length gather: sizes first (all-gather, 16 B per rank), then payloads padded to the global maxima.
+    """Variable-length gather: sizes first (all-gather, 16 B per rank), then three payloads -- clip table, per-instance vectors,
+    per-instance mask logits -- padded to the global maxima of clips and of INSTANCES per rank (not clips x max instances).
     root=None: all-gather, every rank gets the merged list.  root=r: payloads go to rank r only (`dist.gather`; the other
     ranks return None) -- 1/world of the all-gather's traffic into every non-root rank."""
-    packed, nmax = pack(local, T, device)
-    sizes = torch.tensor([len(local), nmax], dtype=torch.int64, device=device)
+    meta_l, vec_l, msk_l = pack(local, T, device, proto_shapes)
+    K = proto_shapes["cls_probs"][0][0]
+    sizes = torch.tensor([len(local), vec_l.shape[0]], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
-    cmax = max(1, int(max(int(s[0]) for s in all_sizes)))     # never hand RCCL a zero-size buffer
-    gmax = max(1, int(max(int(s[1]) for s in all_sizes)))
+    sizes_h = torch.stack(all_sizes).cpu().tolist()               # one sync
+    cmax = max(1, max(s_[0] for s_ in sizes_h))                   # never hand RCCL a zero-size buffer
+    imax = max(1, max(s_[1] for s_ in sizes_h))
     mine = root is None or rank == root
 
-    def exchange(buf):
-        outs = [torch.zeros_like(buf) for _ in range(world)] if mine else None
+    def exchange(part, rows):
+        buf = part
+        if part.shape[0] != rows:
+            buf = torch.zeros((rows,) + tuple(part.shape[1:]), dtype=part.dtype, device=device)
+            buf[:part.shape[0]] = part
+        outs = [torch.empty_like(buf) for _ in range(world)] if mine else None
         if root is None:
             dist.all_gather(outs, buf)
         else:
             dist.gather(buf, outs, dst=root)
         return outs
 
-    merged = []
-    gathered = {}
-    meta = torch.zeros(cmax, 4, dtype=torch.int64, device=device)
-    meta[:len(local)] = packed["meta"]
-    gathered["meta"] = exchange(meta)
-    for f in FIELDS:
-        shape, dtype = proto_shapes[f]
-        buf = torch.zeros([cmax, gmax] + list(shape), dtype=dtype, device=device)
-        if packed[f] is not None and packed[f].numel() > 0:
-            buf[:packed[f].shape[0], :packed[f].shape[1]] = packed[f]
-        gathered[f] = exchange(buf)
+    g_meta = exchange(meta_l, cmax)
+    g_vec = exchange(vec_l, imax)
+    g_msk = exchange(msk_l, imax)
     if not mine:
         return None
     ready = None
     if device.type == "cuda":
         ready = torch.cuda.Event()
         ready.record()                                 # the gathered payloads are complete once this event fires
-    sizes_h = [int(s_[0]) for s_ in all_sizes]
+    merged = []
     for r in range(world):
-        nclips = sizes_h[r]
+        nclips, ninst = sizes_h[r]
         if nclips == 0:
             continue
-        m = gathered["meta"][r].cpu().tolist()
-        host = {f: gathered[f][r].cpu().numpy() for f in ("scores", "cls_probs", "query_embeds")}   # one copy per rank buffer
-        dev = [gathered[f][r] for f in FIELDS]         # (root of N ranks walks N x clips here: keep the per-clip work small)
-        for i in range(nclips):
-            s, e, l, n = m[i]
-            res = {}
-            for f, g_ in zip(FIELDS, dev):
-                t = g_[i, :n]
-                if f == "pred_masks" and e - s != T:
-                    t = t[:, :e - s].contiguous()      # the short last clip was padded in time
-                res[f] = t
-            res["host"] = {f: v[i, :n] for f, v in host.items()}
-            res["ready"] = ready
-            merged.append((s, e, bool(l), res))
+        m = g_meta[r][:nclips].cpu().tolist()
+        vec = g_vec[r][:ninst]
+        host = vec.cpu().numpy()                       # one copy per rank (root of N ranks walks N x clips below: keep the per-clip work small)
+        classes = vec[:, 1].long()
+        msk = g_msk[r]
+        o = 0
+        for s, e, l, n in m:
+            pm = msk[o:o + n]
+            if e - s != T:
+                pm = pm[:, :e - s].contiguous()        # the short last clip was padded in time
+            h = host[o:o + n]
+            merged.append((s, e, bool(l), {"scores": vec[o:o + n, 0], "pred_classes": classes[o:o + n], "cls_probs": vec[o:o + n, 2:2 + K],
+                                           "query_embeds": vec[o:o + n, 2 + K:], "pred_masks": pm, "ready": ready,
+                                           "host": {"scores": h[:, 0], "cls_probs": h[:, 2:2 + K], "query_embeds": h[:, 2 + K:]}}))
+            o += n
     merged.sort(key=lambda c: c[0])
     return merged
 
@@ -328,8 +330,8 @@ class _Job:
         else:
             recv_from = world - 1 if q * world + world < len(self.plan) else None      # consumed in round q+1
             carry_src = self.halos.get(q - 1) if g > 0 else None
-        if world == 1:
-            send_to = recv_from = None
+        if world == 1 and self.dist is None:
+            send_to = recv_from = None                 # (with a backend, one rank sends to itself: the 1-GPU RCCL rehearsal)
         h = _Halo(self.dist, send_to, recv_from, (self.T - 1,) + self.halo_dims, self.device, carry_src=carry_src)
         self.halos[q] = h
         self.halos.pop(q - 2, None)

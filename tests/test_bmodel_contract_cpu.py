@@ -132,6 +132,8 @@ def test_pass_bounds_cover_the_chunk():
     assert MDQE.pass_bounds(120, 40, False) == [40, 80, 120]
     assert MDQE.pass_bounds(120, 40, True, tail=8) == [20, 60, 100, 112, 120]
     assert MDQE.pass_bounds(30, 40, True) == [30]
+    assert MDQE.pass_bounds(63, 40, True) == [20, 41, 63]                      # (not 20 / 40 / 3: no sliver of a last pass)
+    assert MDQE.pass_bounds(61, 40, True) == [20, 40, 61]
 
 
 def test_stacked_view_of_per_frame_tensors():

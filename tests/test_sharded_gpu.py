@@ -128,7 +128,7 @@ def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
         assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
 
 
-@pytest.mark.parametrize("mode", ["round_robin", "root_only", "stream_root_only"])
+@pytest.mark.parametrize("mode", ["round_robin", "root_only", "stream_root_only", "halo_exchange", "stream_halo_exchange"])
 def test_one_rank_rccl_communicator(tmp_path, mode):
     """The sharded schedule over the REAL backend of bench.py --gpus N (`nccl` = RCCL) with a one-rank communicator: all a 1-GPU box can
     offer, but it puts every collective call of the path (all_gather of sizes, gather / all_gather of int64 + fp32 payloads, the
