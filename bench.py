@@ -210,6 +210,10 @@ def main():
     ap.add_argument("--chunk-windows", type=int, default=2,
                     help="N > 1: frames per chunk, in tracker windows (a chunk carries a T-1 frame halo that is computed twice: "
                          "10 %% of a 30-frame chunk, 5 %% of a 60-frame one; the stream hides the longer replay tail)")
+    ap.add_argument("--chunk-rounds", choices=["decreasing", "uniform"], default="decreasing",
+                    help="N > 1: decreasing (default) = each rank's frames go in rounds of shrinking chunks (sharding.round_sizes: 69 / 34 / 17 "
+                         "of 120) -- the tracker replay of a round hides under the next round's compute and only the LAST round's is exposed "
+                         "at the end of a video, so that one is kept short; uniform = --chunk-windows sized chunks throughout")
     ap.add_argument("--halo-exchange", action="store_true",
                     help="N > 1: no frame is computed twice -- a chunk's first clips read the left neighbour's last T-1 frames from shipped "
                          "encoder tokens + mask features (one grouped send/recv per rank and round) instead of recomputing them "
@@ -268,10 +272,11 @@ def main():
     if not sharded:
         video = synth_video(0, L, seed=0, h=fh, w=fw).pin_memory()
         host_frames = list(video)                          # L views [3,h,w] of the pinned block
-        chunk_frames = plan = None
+        chunk_frames = plan = chunk = None
     else:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
-        plan = sharding.chunk_plan(L, T, cfg.clip_stride, cfg.n_frames_window_test * args.chunk_windows, halo_exchange=args.halo_exchange)
+        chunk = sharding.round_sizes(args.frames, T) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
+        plan = sharding.chunk_plan(L, T, cfg.clip_stride, chunk, halo_exchange=args.halo_exchange, world=world)
         chunk_frames = {g: synth_video(plan[g][1], plan[g][2], seed=0, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(plan, world, rank)}
     like = torch.zeros(0, 3, fh, fw, device="cuda")
     torch.cuda.synchronize()
@@ -397,9 +402,9 @@ def main():
                        "merge_on_cpu": bool(cfg.merge_on_cpu) if not sharded else True,     # (sharded videos stream their windows out: sharding._Job)
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
-                       "parallelism": ("1 process/GPU; %d-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
+                       "parallelism": ("1 process/GPU; %s-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
                                        "clip results to rank 0, whose native tracker replay runs on a worker thread under the next round"
-                                       % (cfg.n_frames_window_test * args.chunk_windows,
+                                       % ("/".join(str(c) for c in chunk) + " (one size per round)" if isinstance(chunk, list) else str(chunk),
                                           "halo exchange (T-1 frames of encoder tokens + mask features by send/recv)" if args.halo_exchange
                                           else "a chunk's T-1 frame halo is computed by its owner again")) if sharded else "single GPU"},
         }

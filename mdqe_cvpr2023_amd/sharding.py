@@ -180,27 +180,48 @@ class ReplayThread:
 # ------------------------------------------------------------------------------------------------
 # Round-robin chunks: overlap the (inherently sequential) tracker replay with compute
 # ------------------------------------------------------------------------------------------------
-def chunk_plan(L, T, stride, chunk, halo_exchange=False):
-    """Global chunks in clip order: [(clips, f0, f1)] with clips = those that START in frames [g*chunk, (g+1)*chunk) and
-    [f0, f1) the frames they need (chunk + (T-1)-frame halo, which the owner computes again).
-    halo_exchange=True: no frame is computed twice.  Chunk g holds exactly the frames [g*chunk, (g+1)*chunk) and owns the clips
-    whose LAST frame falls there; its first clips start up to T-1 frames earlier, in the left neighbour's chunk, whose
-    encoder tokens + mask features of those frames arrive by send/recv (_Halo).  A last chunk shorter than T frames is merged
-    into its neighbour (every chunk needs a whole clip of its own)."""
+def round_sizes(frames_per_rank, T, ratio=0.5, smallest=None, max_rounds=3):
+    """Chunk sizes (frames) of the rounds of one video, DECREASING: the tracker replay of round q (world x the clips of a chunk, on
+    rank 0, sequential) runs under the compute of round q+1, so the only replay nobody hides is the LAST round's -- which should
+    therefore be short -- while a replay stays hidden as long as the next round is not much shorter than it (ratio ~ replay time /
+    compute time per frame x world, about 0.4 at N = 8).  120 frames per rank -> 69 / 34 / 17."""
+    smallest = max(3 * T, 12) if smallest is None else smallest
+    per = int(frames_per_rank)
+    for k in range(max_rounds, 1, -1):
+        s0 = per * (1 - ratio) / (1 - ratio ** k)
+        if s0 * ratio ** (k - 1) >= smallest:
+            sizes = [max(int(round(s0 * ratio ** i)), 1) for i in range(k)]
+            sizes[0] += per - sum(sizes)
+            return sizes
+    return [per]
+
+
+def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
+    """Global chunks in clip order: [(clips, f0, f1)] with clips = those that START in the chunk's frames and [f0, f1) the frames
+    they need (chunk + (T-1)-frame halo, which the owner computes again).  `chunk`: frames per chunk, or a list of per-ROUND chunk
+    sizes (round q = the `world` chunks q*world .. q*world+world-1; the last entry repeats) -- see round_sizes.
+    halo_exchange=True: no frame is computed twice.  A chunk holds exactly its own frames and owns the clips whose LAST frame falls
+    there; its first clips start up to T-1 frames earlier, in the left neighbour's chunk, whose encoder tokens + mask features of
+    those frames arrive by send/recv (_Halo).  A last chunk shorter than T frames is merged into its neighbour (every chunk needs
+    a whole clip of its own)."""
     from .meta_arch import MDQE
     clips = MDQE.clip_schedule(L, T, stride)
+    sizes = [int(chunk)] if isinstance(chunk, int) else [int(c) for c in chunk]
+    if min(sizes) < 1:
+        raise ValueError("chunk_plan: chunk sizes must be positive")
+    edges, g = [0], 0
+    while edges[-1] < L:
+        edges.append(min(L, edges[-1] + sizes[min(g // max(world, 1), len(sizes) - 1)]))
+        g += 1
     if halo_exchange:
-        edges = list(range(0, L, chunk)) + [L]
         if len(edges) > 2 and edges[-1] - edges[-2] < T:
             del edges[-2]
         return [([c for c in clips if a <= c[1] - 1 < b], a, b) for a, b in zip(edges[:-1], edges[1:])]
     plan = []
-    g = 0
-    while g * chunk < L:
-        cl = [c for c in clips if g * chunk <= c[0] < (g + 1) * chunk]
+    for a, b in zip(edges[:-1], edges[1:]):
+        cl = [c for c in clips if a <= c[0] < b]
         if cl:
             plan.append((cl, cl[0][0], max(c[1] for c in cl)))
-        g += 1
     return plan
 
 

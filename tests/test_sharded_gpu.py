@@ -61,8 +61,9 @@ def worker(rank, world, port, outdir):
             f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
             out = sharding.run_sharded(model, video[f0:f1].cuda(), f0, L, rank, world, dist, (64, 96))
         else:
-            halo = os.environ.get("MDQE_TEST_SHARDING") == "halo_exchange"
-            plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, 4, halo_exchange=halo)   # 4-frame chunks -> 3 chunks, 2 rounds
+            halo = os.environ.get("MDQE_TEST_SHARDING") in ("halo_exchange", "decreasing_halo_exchange")
+            sizes = [4, 3] if os.environ.get("MDQE_TEST_SHARDING", "").startswith("decreasing") else 4     # decreasing rounds: 4 4 | 3
+            plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, sizes, halo_exchange=halo, world=world)   # 4-frame chunks -> 3 chunks, 2 rounds
             frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}
             out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96),
                                            root_only=os.environ.get("MDQE_TEST_SHARDING") == "root_only", halo_exchange=halo)
@@ -106,7 +107,7 @@ def test_two_rank_stream_of_videos_equals_single_gpu(tmp_path, mode):
             assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
 
 
-@pytest.mark.parametrize("mode", ["round_robin", "root_only", "contiguous", "halo_exchange"])
+@pytest.mark.parametrize("mode", ["round_robin", "root_only", "contiguous", "halo_exchange", "decreasing", "decreasing_halo_exchange"])
 def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     os.environ["MDQE_TEST_SHARDING"] = mode

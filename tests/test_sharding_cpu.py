@@ -129,6 +129,29 @@ def test_halo_exchange_plan_partitions_frames_and_clips():
             assert any(s >= f0 and e - s == min(T, L_) for s, e, _ in cl)
 
 
+def test_decreasing_rounds_plan():
+    """round_sizes: per-rank frames split into rounds of decreasing chunks (the last round's replay is the one nobody hides);
+    chunk_plan with per-round sizes: round q = chunks q*world .. q*world+world-1 of that size; all clips once, in order, both forms."""
+    assert sharding.round_sizes(120, 4) == [69, 34, 17]
+    assert sharding.round_sizes(30, 4) == [20, 10] or sum(sharding.round_sizes(30, 4)) == 30
+    for per in (5, 12, 24, 62, 120, 240, 1000):
+        sz = sharding.round_sizes(per, 4)
+        assert sum(sz) == per and sz == sorted(sz, reverse=True) and (len(sz) == 1 or sz[-1] >= 12)
+    for L_, T, world in ((960, 4, 8), (240, 4, 2), (500, 4, 8), (123, 3, 4)):
+        sz = sharding.round_sizes(-(-L_ // world), T)
+        for halo in (False, True):
+            plan = sharding.chunk_plan(L_, T, 1, sz, halo_exchange=halo, world=world)
+            assert [c for ch in plan for c in ch[0]] == clip_schedule(L_, T, 1)
+            if halo:
+                assert plan[0][1] == 0 and plan[-1][2] == L_ and all(a[2] == b[1] for a, b in zip(plan[:-1], plan[1:]))
+                lens = [b - a for _, a, b in plan]
+            else:
+                lens = [b - a - (T - 1) for _, a, b in plan]
+            for q in range(len(sz)):                                   # whole rounds of equal chunks (the video's end may cut the last ones)
+                assert all(x == sz[q] for x in lens[q * world:(q + 1) * world][:-1] if q * world + world < len(plan))
+    assert sharding.chunk_plan(13, 3, 1, 4) == sharding.chunk_plan(13, 3, 1, [4], world=2)
+
+
 def test_replay_thread_keeps_order_and_surfaces_errors():
     class Merger:
         def __init__(self):
