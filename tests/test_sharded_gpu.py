@@ -1,6 +1,8 @@
 """GPU: the sharded path end to end with 2 ranks must reproduce the single-process result.  With two or more GPUs visible
 the ranks take one GPU each and talk over RCCL (backend "nccl": the production path of bench.py --gpus N); on a 1-GPU box
-both ranks share cuda:0 and rendezvous over gloo (RCCL needs one GPU per rank).  MDQE_TEST_BACKEND=gloo|nccl overrides."""
+both ranks share cuda:0 and rendezvous over gloo (RCCL needs one GPU per rank).  MDQE_TEST_BACKEND=gloo|nccl overrides.
+A second group runs the same schedule over RCCL with a ONE-rank communicator -- the only RCCL execution a single GPU allows.
+Each group is one set of worker processes that walks all its modes (one spawn + one model build per rank, not one per mode)."""
 import os
 import socket
 
@@ -9,6 +11,10 @@ import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+
+VIDEO_MODES = ["round_robin", "root_only", "contiguous", "halo_exchange", "decreasing", "decreasing_halo_exchange"]
+STREAM_MODES = ["stream", "stream_root_only", "stream_two_window_chunks", "stream_halo_exchange"]
+ONE_RANK_MODES = ["round_robin", "root_only", "stream_root_only", "halo_exchange", "stream_halo_exchange"]
 
 
 def _cfg():
@@ -27,49 +33,61 @@ def _video(L=11, seed=2):
 STREAM = ((11, 2), (5, 3), (14, 4))        # (frames, seed) of the videos of the stream test: 3, 1 and 4 chunks of 4 frames
 
 
-def worker(rank, world, port, outdir):
+def _run_mode(mode, model, cfg, rank, world, dist, sharding):
+    video = _video()
+    L = video.shape[0]
+    if mode.startswith("stream"):
+        root_only = mode == "stream_root_only"
+        halo = mode == "stream_halo_exchange"
+        jobs = []
+        for Lv, seed in STREAM:
+            v = _video(Lv, seed)
+            chunk = 8 if mode == "stream_two_window_chunks" else 4     # tracker window = 4 frames
+            plan = sharding.chunk_plan(Lv, cfg.n_frames_test, cfg.clip_stride, chunk, halo_exchange=halo)
+            jobs.append(({g: v[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}, plan, v[:0].cuda()))
+        out = list(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (64, 96), root_only=root_only, halo_exchange=halo))
+        assert len(out) == len(STREAM) and (not root_only or all((o is None) == (rank != 0) for o in out))
+        return out
+    if mode == "contiguous":
+        f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
+        return sharding.run_sharded(model, video[f0:f1].cuda(), f0, L, rank, world, dist, (64, 96))
+    halo = mode in ("halo_exchange", "decreasing_halo_exchange")
+    sizes = [4, 3] if mode.startswith("decreasing") else 4     # decreasing rounds at 2 ranks: 4 4 | 3; else 4-frame chunks -> 3 chunks, 2 rounds
+    plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, sizes, halo_exchange=halo, world=world)
+    frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}
+    out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96), root_only=mode == "root_only", halo_exchange=halo)
+    if mode == "root_only":
+        assert (out is None) == (rank != 0)
+    return out
+
+
+def worker(rank, world, port, outdir, modes, backend, p2p_self):
+    import dataclasses
+    import traceback
     import torch.distributed as dist
     from mdqe_cvpr2023_amd import sharding
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    backend = os.environ.get("MDQE_TEST_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
-    dev = rank if backend == "nccl" else 0
+    backend = backend or os.environ.get("MDQE_TEST_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
+    dev = rank if (backend == "nccl" and world > 1) else 0
     torch.cuda.set_device(dev)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    import dataclasses
     cfg = dataclasses.replace(_cfg(), device="cuda:%d" % dev)
     model = MDQE(cfg, seed=5).eval()
-    video = _video()
-    L = video.shape[0]
-    with torch.no_grad():
-        if os.environ.get("MDQE_TEST_SHARDING", "").startswith("stream"):
-            root_only = os.environ["MDQE_TEST_SHARDING"] == "stream_root_only"
-            jobs = []
-            halo = os.environ["MDQE_TEST_SHARDING"] == "stream_halo_exchange"
-            for Lv, seed in STREAM:
-                v = _video(Lv, seed)
-                chunk = 8 if os.environ["MDQE_TEST_SHARDING"] == "stream_two_window_chunks" else 4     # tracker window = 4 frames
-                plan = sharding.chunk_plan(Lv, cfg.n_frames_test, cfg.clip_stride, chunk, halo_exchange=halo)
-                jobs.append(({g: v[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}, plan, v[:0].cuda()))
-            out = list(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (64, 96), root_only=root_only, halo_exchange=halo))
-            assert len(out) == len(STREAM) and (not root_only or all((o is None) == (rank != 0) for o in out))
-        elif os.environ.get("MDQE_TEST_SHARDING") == "contiguous":
-            f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
-            out = sharding.run_sharded(model, video[f0:f1].cuda(), f0, L, rank, world, dist, (64, 96))
-        else:
-            halo = os.environ.get("MDQE_TEST_SHARDING") in ("halo_exchange", "decreasing_halo_exchange")
-            sizes = [4, 3] if os.environ.get("MDQE_TEST_SHARDING", "").startswith("decreasing") else 4     # decreasing rounds: 4 4 | 3
-            plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, sizes, halo_exchange=halo, world=world)   # 4-frame chunks -> 3 chunks, 2 rounds
-            frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}
-            out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96),
-                                           root_only=os.environ.get("MDQE_TEST_SHARDING") == "root_only", halo_exchange=halo)
-            if os.environ.get("MDQE_TEST_SHARDING") == "root_only":
-                assert (out is None) == (rank != 0)
-    if os.environ.get("MDQE_TEST_P2P_SELF") == "1":
+    for mode in modes:                                     # every rank walks the modes in the same order (same sequence of collectives)
+        try:
+            with torch.no_grad():
+                out = _run_mode(mode, model, cfg, rank, world, dist, sharding)
+            torch.save(out, os.path.join(outdir, f"{mode}_rank{rank}.pt"))
+        except BaseException:
+            with open(os.path.join(outdir, f"{mode}_rank{rank}.err"), "w") as f:
+                f.write(traceback.format_exc())
+            raise                                          # the communicator's state is unknown after a failure: stop here
+    if p2p_self:
         # sharding._Halo's grouped send/recv through the real backend, addressed to this rank itself (the only peer a 1-GPU box has)
         h = sharding._Halo(dist, rank, rank, (2, 7, 16, 4, 6, 8), torch.device("cuda", dev))
         g = torch.Generator().manual_seed(1)
@@ -78,83 +96,99 @@ def worker(rank, world, port, outdir):
         e2, m2 = h.head()
         torch.cuda.synchronize()
         assert torch.equal(e2, enc) and torch.equal(m2, mf)
-    torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
+        open(os.path.join(outdir, "p2p_self.ok"), "w").close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["stream", "stream_root_only", "stream_two_window_chunks", "stream_halo_exchange"])
-def test_two_rank_stream_of_videos_equals_single_gpu(tmp_path, mode):
+def _spawn(world, outdir, modes, backend=None, p2p_self=False):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=worker, args=(r, world, port, outdir, modes, backend, p2p_self)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    for p in procs:                                        # a rank that outlived the limit (a peer died mid-collective) is ended by PID
+        if p.is_alive():
+            p.kill()
+            p.join()
+    return [p.exitcode for p in procs]
+
+
+@pytest.fixture(scope="module")
+def refs():
+    from mdqe_cvpr2023_amd.meta_arch import MDQE
+    model = MDQE(_cfg(), seed=5).eval()
+    with torch.no_grad():
+        return {"video": model([{"image": _video(), "height": 64, "width": 96}]),
+                "stream": [model([{"image": _video(Lv, seed), "height": 64, "width": 96}]) for Lv, seed in STREAM]}
+
+
+@pytest.fixture(scope="module")
+def two_ranks(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("two_ranks"))
+    return d, _spawn(2, d, VIDEO_MODES + STREAM_MODES)
+
+
+@pytest.fixture(scope="module")
+def one_rank_rccl(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("one_rank_rccl"))
+    return d, _spawn(1, d, ONE_RANK_MODES, backend="nccl", p2p_self=True)
+
+
+def _load(d, mode, rank):
+    err = os.path.join(d, f"{mode}_rank{rank}.err")
+    if os.path.exists(err):
+        pytest.fail("rank %d failed in mode %s:\n%s" % (rank, mode, open(err).read()))
+    path = os.path.join(d, f"{mode}_rank{rank}.pt")
+    assert os.path.exists(path), "no output of rank %d for mode %s (a worker stopped in an earlier mode)" % (rank, mode)
+    return torch.load(path, weights_only=False)
+
+
+def _same(out, ref):
+    assert out["pred_labels"] == ref["pred_labels"]
+    assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
+    assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
+
+
+@pytest.mark.parametrize("mode", STREAM_MODES)
+def test_two_rank_stream_of_videos_equals_single_gpu(two_ranks, refs, mode):
     """run_round_robin_stream over three videos of 3, 1 and 4 chunks (a rank sits out a last round, or a whole video): every video's
     result equals the single-process one, in order, on both ranks (all-ranks form) or on rank 0 (root-only form)."""
-    from mdqe_cvpr2023_amd.meta_arch import MDQE
-    os.environ["MDQE_TEST_SHARDING"] = mode
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=300)
-        assert p.exitcode == 0
-    model = MDQE(_cfg(), seed=5).eval()
-    with torch.no_grad():
-        refs = [model([{"image": _video(Lv, seed), "height": 64, "width": 96}]) for Lv, seed in STREAM]
+    d, _ = two_ranks
     for r in range(1 if mode == "stream_root_only" else 2):
-        outs = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
-        for out, ref in zip(outs, refs):
-            assert out["pred_labels"] == ref["pred_labels"]
-            assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
-            assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
+        outs = _load(d, mode, r)
+        assert len(outs) == len(refs["stream"])
+        for out, ref in zip(outs, refs["stream"]):
+            _same(out, ref)
 
 
-@pytest.mark.parametrize("mode", ["round_robin", "root_only", "contiguous", "halo_exchange", "decreasing", "decreasing_halo_exchange"])
-def test_two_rank_sharded_video_equals_single_gpu(tmp_path, mode):
-    from mdqe_cvpr2023_amd.meta_arch import MDQE
-    os.environ["MDQE_TEST_SHARDING"] = mode
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=300)
-        assert p.exitcode == 0
-    model = MDQE(_cfg(), seed=5).eval()
-    with torch.no_grad():
-        ref = model([{"image": _video(), "height": 64, "width": 96}])
+@pytest.mark.parametrize("mode", VIDEO_MODES)
+def test_two_rank_sharded_video_equals_single_gpu(two_ranks, refs, mode):
+    d, _ = two_ranks
     for r in range(1 if mode == "root_only" else 2):
-        out = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
-        assert out["pred_labels"] == ref["pred_labels"]
-        assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
-        assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
+        _same(_load(d, mode, r), refs["video"])
 
 
-@pytest.mark.parametrize("mode", ["round_robin", "root_only", "stream_root_only", "halo_exchange", "stream_halo_exchange"])
-def test_one_rank_rccl_communicator(tmp_path, mode):
+def test_two_rank_workers_exit_cleanly(two_ranks):
+    assert two_ranks[1] == [0, 0]
+
+
+@pytest.mark.parametrize("mode", ONE_RANK_MODES)
+def test_one_rank_rccl_communicator(one_rank_rccl, refs, mode):
     """The sharded schedule over the REAL backend of bench.py --gpus N (`nccl` = RCCL) with a one-rank communicator: all a 1-GPU box can
     offer, but it puts every collective call of the path (all_gather of sizes, gather / all_gather of int64 + fp32 payloads, the
-    grouped isend/irecv of the halo exchange addressed to self, barrier-free teardown) through RCCL's argument checks, stream
-    handling and kernels beside the replay thread."""
-    from mdqe_cvpr2023_amd.meta_arch import MDQE
-    os.environ["MDQE_TEST_SHARDING"] = mode
-    os.environ["MDQE_TEST_BACKEND"] = "nccl"
-    os.environ["MDQE_TEST_P2P_SELF"] = "1"
-    try:
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        ctx = mp.get_context("spawn")
-        p = ctx.Process(target=worker, args=(0, 1, port, str(tmp_path)))
-        p.start()
-        p.join(timeout=300)
-        assert p.exitcode == 0
-    finally:
-        del os.environ["MDQE_TEST_BACKEND"], os.environ["MDQE_TEST_P2P_SELF"]
-    model = MDQE(_cfg(), seed=5).eval()
-    with torch.no_grad():
-        vids = STREAM if mode.startswith("stream") else ((11, 2),)
-        refs = [model([{"image": _video(Lv, seed), "height": 64, "width": 96}]) for Lv, seed in vids]
-    outs = torch.load(os.path.join(str(tmp_path), "rank0.pt"), weights_only=False)
-    outs = outs if mode.startswith("stream") else [outs]
-    for out, ref in zip(outs, refs):
-        assert out["pred_labels"] == ref["pred_labels"]
-        assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
-        assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
+    grouped isend/irecv of the halo exchange addressed to self, teardown) through RCCL's argument checks, stream handling and
+    kernels beside the replay thread."""
+    d, _ = one_rank_rccl
+    outs = _load(d, mode, 0)
+    if mode.startswith("stream"):
+        for out, ref in zip(outs, refs["stream"]):
+            _same(out, ref)
+    else:
+        _same(outs, refs["video"])
+
+
+def test_one_rank_rccl_p2p_to_self(one_rank_rccl):
+    d, codes = one_rank_rccl
+    assert codes == [0] and os.path.exists(os.path.join(d, "p2p_self.ok"))
