@@ -34,6 +34,8 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
+  unsigned long long t_start = 0, t_pro = 0, t_loop = 0;   // tools/gemm_stamps.py only (100 MHz wall clock)
+  if (p.stamps) t_start = wall_clock64();
 
   // XCD-aware tile order: blocks that share an A row-panel run on the same XCD (same L2).
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -127,6 +129,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) issue(kt0 + s, s);
+  if (p.stamps) t_pro = wall_clock64();
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's LDS-DMA for step kt has landed: at most the loads of the stages issued after it may still be in flight
     if constexpr (NS == 2) {
@@ -164,6 +167,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][s], b1[j][s], acc[i][j], 0, 0, 0);
   }
 
+  if (p.stamps) t_loop = wall_clock64();
   if constexpr (LN) {
     // ---- LayerNorm epilogue (BN == N: the block owns whole rows): y = LN(acc + bias + residual) * gamma + beta.
     // Sub-tiles are restaged as below (a lane gets 4 consecutive columns of 4 rows per sub-tile) but stay in registers;
@@ -319,6 +323,11 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   if constexpr (NT > 1) sub(I0{}, I1{});
   if constexpr (MT > 1) sub(I1{}, I0{});
   if constexpr (MT > 1 && NT > 1) sub(I1{}, I1{});
+  if (p.stamps && tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = p.stamps + (long)blockIdx.x * 4;
+    o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = wall_clock64();
+  }
 }
 
 static int g_k16_stages = 0;       // tools/ A/B: 0 = by grid size, 2 / 4 = forced
