@@ -250,6 +250,153 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
   }
 }
 
+
+// ---- v3 (encoder: mode 0, one group, the queries are the level tokens): the COARSE levels live in LDS -------------------
+// A head's slice of a level is H*W rows of D floats: at 360p the two coarsest levels (12x20 + 6x10 tokens) are 38 KB per
+// (frame, head), at 640p 115 KB -- they fit the 160-KB LDS, and half of every query's 16 samples fall on them.  A block of
+// 1024 threads owns one (frame, head) and a run of queries: it stages the levels [LS, L) of its head once (coalesced 128-B
+// rows), then walks its queries 128 at a time with exactly v2's lane mapping and arithmetic (8 lanes per (query, head), 4
+// channels each, samples in order, corners in order -- bit-identical results); samples on a staged level read their four
+// corners with ds_read_b128 instead of going through the texture path, which is what bounds v2 (TA busy 0.62-0.71, L1 hit 65 %).
+// A corner outside the map points at a zero row behind the staged levels (v2: an out-of-range buffer offset that reads as 0).
+// The sample descriptors take half of v2's LDS: the 16 samples go in two halves of 8 (same order).
+template <int L, int P, int DD, int NT>
+__global__ void __launch_bounds__(NT)
+msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows,
+                     const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
+                     const float* __restrict__ ref, long ref_bstride, int ref_dim, MsdaLevels lv,
+                     int B, int M, int Q, int LS, int stage_px, int chunk, int nchunk, float scale,
+                     float* __restrict__ out, long ldout, int xcd_order) {
+  constexpr int LP = L * P;                    // 16
+  constexpr int D = DD, HS = LP / 2;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // [stage_px + 1 rows of D floats | per wave: 8 groups x (HS + 1) samples x 4 corner offsets | the same of weights]
+  float* stage = smem;
+  const int wave = threadIdx.x >> 6;
+  unsigned* soff = reinterpret_cast<unsigned*>(smem + (long)(stage_px + 1) * D) + wave * (8 * (HS + 1) * 4 * 2);
+  float* swgt = reinterpret_cast<float*>(soff + 8 * (HS + 1) * 4);
+  __shared__ int sH[16], sW[16], sS[16];
+  if (threadIdx.x < 16) { sH[threadIdx.x] = lv.H[threadIdx.x]; sW[threadIdx.x] = lv.W[threadIdx.x]; sS[threadIdx.x] = lv.start[threadIdx.x]; }
+  // block -> (frame, head, run of queries); frames dealt one per XCD as in v2
+  const int nbq = M * nchunk;
+  const int full = (xcd_order && B >= 16) ? (B / 8) * 8 : 0;
+  int b, blk;
+  if ((int)blockIdx.x < full * nbq) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int fi = slot / nbq;
+    b = xcd + 8 * fi; blk = slot - fi * nbq;
+  } else {
+    const int r = (int)blockIdx.x - full * nbq;
+    b = full + r / nbq; blk = r - (r / nbq) * nbq;
+  }
+  if (b >= B) return;
+  const int m = blk % M, ck = blk / M;
+  const long brow = (long)b * v_brows;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
+  __syncthreads();
+  {                                             // stage the head's slice of the levels [LS, L): tokens sS[LS] .. sS[LS] + stage_px
+    const int s0 = sS[LS];
+    for (int idx = threadIdx.x; idx < (stage_px + 1) * 8; idx += NT) {
+      const int px = idx >> 3, c = idx & 7;
+      if (c * 4 >= D) continue;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (px < stage_px) v = *reinterpret_cast<const f32x4*>(value + (brow + s0 + px) * ldv + m * D + c * 4);
+      *reinterpret_cast<f32x4*>(stage + (long)px * D + c * 4) = v;       // row stage_px: zeros
+    }
+  }
+  __syncthreads();
+  const int grp = (threadIdx.x >> 3) & 7, j = threadIdx.x & 7;             // group within the wave
+  const bool chan = j * 4 < D;
+  const unsigned lane_off = chan ? (unsigned)((m * D + j * 4) * 4) : MSDA_OOB;
+  const unsigned lane_lds = chan ? (unsigned)(j * 16) : 0u;
+  const unsigned zero_row = (unsigned)(stage_px * D * 4);
+  const int q_end = min(Q, (ck + 1) * chunk);
+  for (int q0 = ck * chunk; q0 < q_end; q0 += NT / 8) {
+    const int q = q0 + (threadIdx.x >> 3);
+    const bool live = q < q_end;
+    const int qq = live ? q : q_end - 1;         // idle groups shadow the run's last query and do not store
+    const long t = (long)b * Q + qq;
+    const f32x4 o4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(offs + t * ldo + m * (2 * LP) + 4 * j));
+    const f32x2 l2 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(logits + t * ldl + m * LP + 2 * j));
+    float mx = fmaxf(l2[0], l2[1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    const float e0 = expf(l2[0] - mx), e1 = expf(l2[1] - mx);
+    float sm = e0 + e1;
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+    const float inv = 1.0f / sm;
+    const float* rp = ref + (long)b * ref_bstride + (long)qq * ref_dim;
+    const float rx = rp[0], ry = rp[1];
+    u32x4 offv[2];
+    f32x4 wv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = 2 * j + k;
+      const int l = i / P;
+      const float ox = o4[2 * k], oy = o4[2 * k + 1];
+      const float lx = rx + ox / 8.f, ly = ry + oy / 8.f;
+      const float aw = (k == 0 ? e0 : e1) * inv;
+      const int H = sH[l], W = sW[l];
+      const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+      const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const float lh = h_im - h_low, lw = w_im - w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const bool h0 = in && h_low >= 0, h1 = in && h_low + 1 <= H - 1;
+      const bool w0 = w_low >= 0, w1 = w_low + 1 <= W - 1;
+      unsigned base, dW, d1, oob;
+      if (l >= LS) {                             // staged level: byte offsets into `stage`
+        base = (unsigned)((sS[l] - sS[LS] + h_low * W + w_low) * (D * 4));
+        dW = (unsigned)(W * D * 4); d1 = (unsigned)(D * 4); oob = zero_row;
+      } else {
+        const long prow = brow + sS[l] + (long)h_low * W + w_low;
+        base = (unsigned)(prow * ldv * 4);
+        dW = (unsigned)((long)W * ldv * 4); d1 = (unsigned)(ldv * 4); oob = MSDA_OOB;
+      }
+      offv[k][0] = (h0 && w0) ? base : oob;
+      offv[k][1] = (h0 && w1) ? base + d1 : oob;
+      offv[k][2] = (h1 && w0) ? base + dW : oob;
+      offv[k][3] = (h1 && w1) ? base + dW + d1 : oob;
+      wv[k][0] = hh * hw * aw; wv[k][1] = hh * lw * aw; wv[k][2] = lh * hw * aw; wv[k][3] = lh * lw * aw;
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((j >> 2) == half) {                    // lanes 0-3 hold samples 0-7, lanes 4-7 samples 8-15
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int slot = 2 * (j & 3) + k;
+          *reinterpret_cast<u32x4*>(soff + (grp * (HS + 1) + slot) * 4) = offv[k];
+          *reinterpret_cast<f32x4*>(swgt + (grp * (HS + 1) + slot) * 4) = wv[k];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+        const int l = (half * HS + s) / P;        // compile-time
+        const u32x4 o = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + s) * 4);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + s) * 4);
+        if (l >= LS) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[c] + lane_lds);
+            acc += v * w[c];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
+            acc += v * w[c];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (chan && live) __builtin_nontemporal_store(acc * scale, reinterpret_cast<f32x4*>(out + t * ldout + m * D + j * 4));
+  }
+}
+
 static int g_msda_xcd_order = 1;   // tools/ A/B: 0 = plain block order in the fused kernel
 extern "C" int mdqe_debug_msda_xcd_order(int v) { g_msda_xcd_order = v; return MDQE_OK; }
 static int g_msda_variant = -1;    // tools/ A/B: block-to-query map (0, 1, 2) + 4 * (waves-per-SIMD hint 8 instead of none); -1 = by shape
@@ -285,7 +432,38 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
     for (int l = 0; l < L; ++l) ntok += (long)lv.H[l] * lv.W[l];
     // default: the encoder (mode 0: the queries are the level tokens in raster order) takes map 1 -- 608 vs 635 us on the
     // 40-frame launch with unstructured offsets (tools/pmc_msda.py variants), no difference end to end; the decoder keeps map 0
-    int var = g_msda_variant >= 0 ? g_msda_variant : (mode == 0 ? 1 : MSDA_DEFAULT_VARIANT);
+    int var = g_msda_variant >= 0 ? g_msda_variant : (mode == 0 ? (1 | 8) : MSDA_DEFAULT_VARIANT);
+    if ((var & 8) && mode == 0 && G == 1 && ntok == Q && vidx == nullptr && L == 4 && P == 4 && ref_dim == 2) {
+      // v3: the coarsest levels that fit beside the descriptors (2.3 KB per wave) in the 160-KB LDS are staged per (frame, head)
+      const int nt = (g_msda_variant >= 0 && (g_msda_variant & 128)) ? 512 : 1024;
+      const long desc = (nt / 64) * 8L * (8 + 1) * 4 * 2 * 4;
+      int LS = L;
+      long px = 0;
+      while (LS > 1 && ((px + (long)lv.H[LS - 1] * lv.W[LS - 1] + 1) * D * 4 + desc) <= 150L * 1024) { --LS; px += (long)lv.H[LS] * lv.W[LS]; }
+      if (LS < L) {
+        const size_t smem = (size_t)((px + 1) * D * 4 + desc);
+        // queries per block, by what a block stages (tools/pmc_msda.py variants, us per launch): 38 KB (360p, 40 frames) 128: 380,
+        // 256: 420, 640: 436, 2048: 513; 50 KB (Swin-L 480p, D = 24) 128: 240, 256: 227, 512: 255; 115 KB (640p, one block per CU)
+        // 256: 798, 512: 740, 1024: 755
+        const long staged = (px + 1) * D * 4;
+        int chunk = staged < 45 * 1024 ? 128 : staged < 80 * 1024 ? 256 : 512;
+        if (g_msda_variant >= 0 && ((g_msda_variant >> 4) & 7)) chunk = 32 << (((g_msda_variant >> 4) & 7) - 1);       // tools/ sweep: 32 .. 2048
+        const int nchunk = (Q + chunk - 1) / chunk;
+        const long nb3 = (long)B * M * nchunk;
+        auto launch3 = [&](auto kern) {
+          static bool attr_set = false;                                       // (one static per instantiation of this lambda body)
+          if (!attr_set) {
+            attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256) == hipSuccess;   // (a failure shows as a launch error below)
+          }
+          hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, (unsigned)vbytes, ldv, v_brows, offs, ldo, logits, ldl,
+                             ref, ref_bstride, ref_dim, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
+        };
+        if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
+        else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
+        return mdqe_launch_status();
+      }
+    }
     int map = var & 3;
     if (map == 2 && !(mode == 0 && G == 1 && ntok == Q)) map = (mode == 0) ? 1 : 0;
     long nbq;

@@ -7,21 +7,28 @@ from mdqe_cvpr2023_amd import ops
 g = torch.Generator().manual_seed(0)
 Bf, Mh, D, L, P = 40, 8, 32, 4, 4
 shapes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+GEO = os.environ.get("MSDA_GEO", "360p")          # 360p (default) | 640p (R50_ovis_720, 20-frame passes) | swinl (480x864, D = 24)
+if GEO == "640p":
+    Bf, shapes = 20, [(80, 144), (40, 72), (20, 36), (10, 18)]
+elif GEO == "swinl":
+    Bf, D, shapes = 10, 24, [(60, 108), (30, 54), (15, 27), (8, 14)]
+C = Mh * D
 Nq = sum(a * c for a, c in shapes)
 starts = [0]
 for a, c in shapes[:-1]:
     starts.append(starts[-1] + a * c)
 levels = ([s[0] for s in shapes], [s[1] for s in shapes], starts)
-proj = torch.randn(Bf * Nq, 256 + 3 * Mh * L * P, generator=g).cuda()
+proj = torch.randn(Bf * Nq, C + 3 * Mh * L * P, generator=g).cuda()
 ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(a) + 0.5) / a, (torch.arange(c) + 0.5) / c, indexing="ij"), -1).reshape(-1, 2).flip(-1)
                  for a, c in shapes]).float().cuda().contiguous()
-out = torch.empty(Bf * Nq, 256, device="cuda")
+out = torch.empty(Bf * Nq, C, device="cuda")
 nq = 2 * Mh * L * P
-run = lambda: ops.msda_fused(proj[:, :256], proj[:, 256:256 + nq], proj[:, 256 + nq:], ref, levels, Bf, Nq, Mh, D, L, P, mode=0, v_brows=Nq, out=out)
+COMP = Nq * (2 * C + 3 * Mh * L * P) * 4.0         # compulsory bytes per frame: value + offsets + logits + output (18.3 MB at 360p)
+run = lambda: ops.msda_fused(proj[:, :C], proj[:, C:C + nq], proj[:, C + nq:], ref, levels, Bf, Nq, Mh, D, L, P, mode=0, v_brows=Nq, out=out)
 if len(sys.argv) > 1 and sys.argv[1] == "variants":        # block-to-query maps x waves-per-SIMD hint, same box, output checked against variant 0
     from mdqe_cvpr2023_amd._lib import lib
     ref_out = None
-    for v in (0, 1, 2, 4, 5, 6):
+    for v in [int(a) for a in sys.argv[2:]] or (0, 1, 2, 4, 5, 6, 9):
         lib.mdqe_debug_msda_variant(v)
         run(); torch.cuda.synchronize()
         if ref_out is None:
@@ -35,7 +42,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "variants":        # block-to-query maps
             run()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print("variant %d (map %d, waves hint %s): %.1f us = %.2f TB/s compulsory, identical to variant 0: %s" % (v, v & 3, "8" if v & 4 else "-", us, 18.3e6 * Bf / us / 1e6, same), flush=True)
+        print("variant %d (map %d, waves hint %s%s): %.1f us = %.2f TB/s compulsory, identical to variant 0: %s" % (v, v & 3, "8" if v & 4 else "-", ", coarse levels in LDS" if v & 8 else "", us, COMP * Bf / us / 1e6, same), flush=True)
     lib.mdqe_debug_msda_variant(-1)
 elif len(sys.argv) > 1 and sys.argv[1] == "time":
     for _ in range(3):
@@ -46,7 +53,7 @@ elif len(sys.argv) > 1 and sys.argv[1] == "time":
         run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    comp = 18.3e6 * Bf
+    comp = COMP * Bf
     print("msda_fused enc 40 frames: %.1f us per launch = %.2f TB/s of the %.0f MB compulsory bytes" % (us, comp / us / 1e6, comp / 1e6))
 else:
     for _ in range(5):
