@@ -436,3 +436,44 @@ def test_linear_layernorm_fused():
         assert float((out - two).abs().max()) < 1e-5
         out2 = ops.linear_ln(x.cuda(), w.cuda(), b.cuda(), rc, ga.cuda(), be.cuda(), out=rc)      # in place over the residual
         assert out2.data_ptr() == rc.data_ptr() and torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("shapes,B,M,D", [
+    ([(12, 20), (6, 10), (3, 5), (2, 3)], 3, 8, 32),          # 96x160 frames
+    ([(8, 12), (4, 6), (2, 3), (1, 2)], 17, 8, 32),           # the tests' 64x96 frames; 17 >= 16 frames: XCD-aware block order
+    ([(48, 80), (24, 40), (12, 20), (6, 10)], 2, 8, 32),      # R50_ovis_360 (two coarse levels staged, 38 KB)
+    ([(15, 27), (8, 14), (4, 7), (2, 4)], 2, 8, 24),          # Swin-L's head width
+    ([(80, 144), (40, 72), (20, 36), (10, 18)], 1, 8, 32),    # R50_ovis_720 (115 KB staged, 512 queries per block)
+])
+def test_encoder_msda_with_coarse_levels_in_lds_equals_the_gather_form(shapes, B, M, D):
+    """msda_fused_v3_kernel (coarse levels staged in LDS per (frame, head)) against msda_fused_v2_kernel (every corner through the
+    texture path), which the reference goldens hold to the reference: same lane mapping and order of operations -> equal bits;
+    locations from inside the maps to far outside them, and onto pixel borders."""
+    from mdqe_cvpr2023_amd import ops
+    from mdqe_cvpr2023_amd._lib import lib
+    g = torch.Generator().manual_seed(B * 7 + D)
+    L, P = 4, 4
+    C = M * D
+    Nq = sum(h * w for h, w in shapes)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+    levels = ([s[0] for s in shapes], [s[1] for s in shapes], starts)
+    nq = 2 * M * L * P
+    proj = torch.randn(B * Nq, C + 3 * M * L * P, generator=g)
+    proj[:, C:C + nq] *= 3.0                                                  # offsets up to ~ +-1.5 maps
+    proj[::7, C:C + nq] = torch.round(proj[::7, C:C + nq])                    # exact eighths -> pixel borders on the /8 levels
+    proj = proj.cuda()
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(a) + 0.5) / a, (torch.arange(c) + 0.5) / c, indexing="ij"), -1).reshape(-1, 2).flip(-1)
+                     for a, c in shapes]).float().cuda().contiguous()
+    outs = []
+    try:
+        for var in (1, 9):
+            lib.mdqe_debug_msda_variant(var)
+            out = torch.full((B * Nq, C), float("nan"), device="cuda")
+            ops.msda_fused(proj[:, :C], proj[:, C:C + nq], proj[:, C + nq:], ref, levels, B, Nq, M, D, L, P, mode=0, v_brows=Nq, out=out)
+            outs.append(out)
+    finally:
+        lib.mdqe_debug_msda_variant(-1)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
