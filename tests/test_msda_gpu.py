@@ -89,6 +89,41 @@ def test_full_size_properties():
     assert maxdiff(o1[:1, :600].cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("shapes,B,Q", [
+    ([(48, 80), (24, 40), (12, 20), (6, 10)], 2, 5100),       # R50_ovis_360 encoder: the two coarse levels fit the S/16 budget
+    ([(48, 80), (24, 40), (12, 20), (6, 10)], 17, 196),       # decoder-like: few queries per element; 17 elements: XCD-aware order
+    ([(8, 12), (4, 6), (2, 3), (1, 2)], 3, 128),              # tiny maps: three levels staged
+    ([(10, 10), (10, 10), (10, 10), (10, 10)], 2, 400),       # not a pyramid: only the last level fits
+    ([(6, 10), (12, 20), (24, 40), (48, 80)], 2, 300),        # fine level LAST: nothing fits, every corner through the texture path
+])
+def test_op_with_coarse_levels_in_lds_equals_the_gather_form(shapes, B, Q):
+    """msda_fwd_v3_kernel (the native op with the coarse levels of a (batch element, head) staged in LDS; the level table is device
+    memory, so every block sizes the staging area itself) against msda_fwd_v2_kernel: equal bits, whatever suffix of levels fits."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    from mdqe_cvpr2023_amd._lib import lib
+    g = torch.Generator().manual_seed(Q)
+    M, D, L, P = 8, 32, 4, 4
+    S = sum(h * w for h, w in shapes)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+    sh, st = torch.tensor(shapes, dtype=torch.int64).cuda(), torch.tensor(starts, dtype=torch.int64).cuda()
+    v = torch.randn(B, S, M, D, generator=g).cuda()
+    loc = (0.5 + 1.6 * (torch.rand(B, Q, M, L, P, 2, generator=g) - 0.5))
+    loc[:, ::5] = torch.round(loc[:, ::5] * 8) / 8                             # pixel borders
+    at = torch.softmax(torch.randn(B, Q, M, L * P, generator=g), -1).view(B, Q, M, L, P)
+    outs = []
+    try:
+        for staged in (0, 1):
+            lib.mdqe_debug_msda_op_staged(staged)
+            outs.append(MSDA.ms_deform_attn_forward(v, sh, st, loc.cuda(), at.cuda(), 64))
+    finally:
+        lib.mdqe_debug_msda_op_staged(1)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    ref = O.msda_forward(v[:1].cpu(), shapes, starts, loc[:1, :64], at[:1, :64])
+    assert maxdiff(outs[1][:1, :64].cpu(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("case", ["enc", "dec", "swin_d24", "tiny_d8"])
 def test_backward_vs_reference_core_gradients(case):
     """ms_deform_attn_backward (HIP, fp32, float atomics) vs float64 autograd through the reference's own PyTorch core --
