@@ -262,9 +262,9 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
 // The sample descriptors take half of v2's LDS: the 16 samples go in two halves of 8 (same order).
 template <int L, int P, int DD, int NT>
 __global__ void __launch_bounds__(NT)
-msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows,
+msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
-                     const float* __restrict__ ref, long ref_bstride, int ref_dim, MsdaLevels lv,
+                     const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode, const float* __restrict__ grid, MsdaLevels lv,
                      int B, int M, int Q, int LS, int stage_px, int chunk, int nchunk, float scale,
                      float* __restrict__ out, long ldout, int xcd_order) {
   constexpr int LP = L * P;                    // 16
@@ -292,7 +292,7 @@ msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long
   }
   if (b >= B) return;
   const int m = blk % M, ck = blk / M;
-  const long brow = (long)b * v_brows;
+  const long brow = vidx != nullptr ? (long)vidx[b] * v_brows : (long)b * v_brows;
   const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
   __syncthreads();
   {                                             // stage the head's slice of the levels [LS, L): tokens sS[LS] .. sS[LS] + stage_px
@@ -327,13 +327,22 @@ msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long
     const float inv = 1.0f / sm;
     const float* rp = ref + (long)b * ref_bstride + (long)qq * ref_dim;
     const float rx = rp[0], ry = rp[1];
+    float bw = 0.f, bh = 0.f;
+    if (mode == 1) { bw = rp[2]; bh = rp[3]; }
     u32x4 offv[2];
     f32x4 wv[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = 2 * j + k;
       const int l = i / P;
-      const float ox = o4[2 * k], oy = o4[2 * k + 1];
+      float ox = o4[2 * k], oy = o4[2 * k + 1];
+      if (mode == 1) {                           // decoder: grid pattern scaled by the box + clamped delta (as v2)
+        const float gx = grid[(m * LP + i) * 2], gy = grid[(m * LP + i) * 2 + 1];
+        ox = fminf(fmaxf(ox, -bw * 8.f), bw * 8.f);
+        oy = fminf(fmaxf(oy, -bh * 8.f), bh * 8.f);
+        ox = gx * 0.5f * bw + ox;
+        oy = gy * 0.5f * bh + oy;
+      }
       const float lx = rx + ox / 8.f, ly = ry + oy / 8.f;
       const float aw = (k == 0 ? e0 : e1) * inv;
       const int H = sH[l], W = sW[l];
@@ -432,10 +441,18 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
     for (int l = 0; l < L; ++l) ntok += (long)lv.H[l] * lv.W[l];
     // default: the encoder (mode 0: the queries are the level tokens in raster order) takes map 1 -- 608 vs 635 us on the
     // 40-frame launch with unstructured offsets (tools/pmc_msda.py variants), no difference end to end; the decoder keeps map 0
-    int var = g_msda_variant >= 0 ? g_msda_variant : (mode == 0 ? (1 | 8) : MSDA_DEFAULT_VARIANT);
-    if ((var & 8) && mode == 0 && G == 1 && ntok == Q && vidx == nullptr && L == 4 && P == 4 && ref_dim == 2) {
+    int var = g_msda_variant >= 0 ? g_msda_variant : (mode == 0 ? (1 | 8) : (MSDA_DEFAULT_VARIANT | 8));
+    const bool enc_form = mode == 0 && ntok == Q && vidx == nullptr && ref_dim == 2;      // the queries are the level tokens
+    const bool dec_form = mode == 1 && ref_dim == 4;                                      // box-level decoder launch: Q queries per (clip, frame)
+    if ((var & 8) && G == 1 && L == 4 && P == 4 && (enc_form || dec_form)) {
       // v3: the coarsest levels that fit beside the descriptors (2.3 KB per wave) in the 160-KB LDS are staged per (frame, head)
-      const int nt = (g_msda_variant >= 0 && (g_msda_variant & 128)) ? 512 : 1024;
+      int nt = (g_msda_variant >= 0 && (g_msda_variant & 128)) ? 512 : 1024;
+      int chunk = 0;
+      if (dec_form) {                            // few queries per (element, head): even runs of at most 128, threads to match (196 -> 2 x 98 on 13 waves)
+        const int runs = (Q + 127) / 128;
+        chunk = (Q + runs - 1) / runs;
+        nt = chunk <= 64 ? 512 : chunk <= 104 ? 832 : 1024;
+      }
       const long desc = (nt / 64) * 8L * (8 + 1) * 4 * 2 * 4;
       int LS = L;
       long px = 0;
@@ -446,7 +463,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         // 256: 420, 640: 436, 2048: 513; 50 KB (Swin-L 480p, D = 24) 128: 240, 256: 227, 512: 255; 115 KB (640p, one block per CU)
         // 256: 798, 512: 740, 1024: 755
         const long staged = (px + 1) * D * 4;
-        int chunk = staged < 45 * 1024 ? 128 : staged < 80 * 1024 ? 256 : 512;
+        if (chunk == 0) chunk = staged < 45 * 1024 ? 128 : staged < 80 * 1024 ? 256 : 512;
         if (g_msda_variant >= 0 && ((g_msda_variant >> 4) & 7)) chunk = 32 << (((g_msda_variant >> 4) & 7) - 1);       // tools/ sweep: 32 .. 2048
         const int nchunk = (Q + chunk - 1) / chunk;
         const long nb3 = (long)B * M * nchunk;
@@ -456,10 +473,11 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
             attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 256) == hipSuccess;   // (a failure shows as a launch error below)
           }
-          hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, (unsigned)vbytes, ldv, v_brows, offs, ldo, logits, ldl,
-                             ref, ref_bstride, ref_dim, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
+          hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, (unsigned)vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
+                             ref, ref_bstride, ref_dim, mode, grid, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
         };
         if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
+        else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
         else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
         return mdqe_launch_status();
       }

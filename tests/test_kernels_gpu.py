@@ -477,3 +477,35 @@ def test_encoder_msda_with_coarse_levels_in_lds_equals_the_gather_form(shapes, B
         lib.mdqe_debug_msda_variant(-1)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("Q,BT", [(196, 9), (64, 20), (300, 3)])
+def test_decoder_box_level_msda_with_coarse_levels_in_lds_equals_the_gather_form(Q, BT):
+    """The decoder's box-level launch (mode 1: grid pattern scaled by the query's box + clamped delta, value block picked per batch
+    element) on msda_fused_v3_kernel against msda_fused_v2_kernel: equal bits; Q = 196 runs as two runs of 98 queries on 13 waves."""
+    from mdqe_cvpr2023_amd import ops
+    from mdqe_cvpr2023_amd._lib import lib
+    g = torch.Generator().manual_seed(Q)
+    M, D, L, P, F = 8, 32, 4, 4, 6
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    N = sum(h * w for h, w in shapes)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+    levels = ([s[0] for s in shapes], [s[1] for s in shapes], starts)
+    wide = torch.randn(F * N, 3 * 256, generator=g).cuda()
+    nq = 2 * M * L * P
+    pr = (2.0 * torch.randn(BT * Q, 3 * M * L * P, generator=g)).cuda()
+    boxes = (torch.rand(BT, Q, 4, generator=g) * torch.tensor([1, 1, 0.5, 0.5])).cuda()
+    grid = torch.randn(M * L * P * 2, generator=g).cuda()
+    vidx = torch.randint(0, F, (BT,), generator=g, dtype=torch.int32).cuda()
+    outs = []
+    try:
+        for var in (0, 8):
+            lib.mdqe_debug_msda_variant(var)
+            out = torch.full((BT * Q, 256), float("nan"), device="cuda")
+            ops.msda_fused(wide[:, 256:512], pr[:, :nq], pr[:, nq:], boxes, levels, BT, Q, M, D, L, P, mode=1, grid=grid, v_brows=N, vidx=vidx, out=out)
+            outs.append(out)
+    finally:
+        lib.mdqe_debug_msda_variant(-1)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

@@ -24,3 +24,14 @@ out = torch.empty(BT * Q, 256, device="cuda")
 for name, v in (("slice of [rows,3072]", wide[:, 512:768]), ("contiguous [rows,256]", narrow)):
     ms = time_ms(lambda: ops.msda_fused(v, pr[:, :nq], pr[:, nq:], boxes, levels, BT, Q, M, D, L, P, mode=1, grid=grid, v_brows=N, vidx=vidx, out=out), iters=30, warm=5)
     print("%-24s %.1f us" % (name, 1e3 * ms))
+# round 2: the same launch with the two coarse levels of every (clip frame, head) staged in LDS (msda_fused_v3_kernel, mode 1) against v2
+from mdqe_cvpr2023_amd._lib import lib
+v = wide[:, 512:768]
+outs = []
+for var, name in ((0, "gather form (v2)"), (8, "coarse levels in LDS (v3)")):
+    lib.mdqe_debug_msda_variant(var)
+    ms = time_ms(lambda: ops.msda_fused(v, pr[:, :nq], pr[:, nq:], boxes, levels, BT, Q, M, D, L, P, mode=1, grid=grid, v_brows=N, vidx=vidx, out=out), iters=30, warm=5)
+    outs.append(out.clone())
+    print("%-28s %.1f us" % (name, 1e3 * ms))
+lib.mdqe_debug_msda_variant(-1)
+print("equal bits:", bool(torch.equal(outs[0], outs[1])))
