@@ -59,6 +59,7 @@ SIGNATURES = {
     "mdqe_debug_window_attn_variant": [i],
     "mdqe_debug_mha_variant": [i],
     "mdqe_debug_msda_xcd_order": [i],
+    "mdqe_debug_msda_dec_staged": [i],
     "mdqe_debug_msda_op_staged": [i],
     "mdqe_debug_msda_variant": [i],
     "mdqe_mask_row_stats_f32": [p, i, i, i, i, i, p, p, p, p],

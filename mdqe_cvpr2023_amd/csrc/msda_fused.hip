@@ -410,6 +410,8 @@ static int g_msda_xcd_order = 1;   // tools/ A/B: 0 = plain block order in the f
 extern "C" int mdqe_debug_msda_xcd_order(int v) { g_msda_xcd_order = v; return MDQE_OK; }
 static int g_msda_variant = -1;    // tools/ A/B: block-to-query map (0, 1, 2) + 4 * (waves-per-SIMD hint 8 instead of none); -1 = by shape
 extern "C" int mdqe_debug_msda_variant(int v) { g_msda_variant = v; return MDQE_OK; }
+static int g_msda_dec_staged = 1;  // tools/ A/B: 0 = the decoder's box-level launch stays on v2 (the encoder keeps its default)
+extern "C" int mdqe_debug_msda_dec_staged(int v) { g_msda_dec_staged = v; return MDQE_OK; }
 
 extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, const int* vidx, const float* offs, long ldo,
                                    const float* logits, long ldl, const float* ref, long ref_bstride, int ref_dim,
@@ -443,7 +445,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
     // 40-frame launch with unstructured offsets (tools/pmc_msda.py variants), no difference end to end; the decoder keeps map 0
     int var = g_msda_variant >= 0 ? g_msda_variant : (mode == 0 ? (1 | 8) : (MSDA_DEFAULT_VARIANT | 8));
     const bool enc_form = mode == 0 && ntok == Q && vidx == nullptr && ref_dim == 2;      // the queries are the level tokens
-    const bool dec_form = mode == 1 && ref_dim == 4;                                      // box-level decoder launch: Q queries per (clip, frame)
+    const bool dec_form = mode == 1 && ref_dim == 4 && g_msda_dec_staged;                                      // box-level decoder launch: Q queries per (clip, frame)
     if ((var & 8) && G == 1 && L == 4 && P == 4 && (enc_form || dec_form)) {
       // v3: the coarsest levels that fit beside the descriptors (2.3 KB per wave) in the 160-KB LDS are staged per (frame, head)
       int nt = (g_msda_variant >= 0 && (g_msda_variant & 128)) ? 512 : 1024;

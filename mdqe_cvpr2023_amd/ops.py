@@ -14,6 +14,9 @@ ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "tanh": 4}
 if os.environ.get("MDQE_MSDA_VARIANT"):                 # tools/ A/B of the fused MSDA's block-to-query map (csrc/msda_fused.hip)
     check(lib.mdqe_debug_msda_variant(int(os.environ["MDQE_MSDA_VARIANT"])), "msda_variant")
 
+if os.environ.get("MDQE_MSDA_DEC_STAGED"):              # tools/ A/B: decoder box-level MSDA on the LDS-staged kernel (1, default) or v2 (0)
+    check(lib.mdqe_debug_msda_dec_staged(int(os.environ["MDQE_MSDA_DEC_STAGED"])), "msda_dec_staged")
+
 _ws = {}
 
 
