@@ -352,9 +352,9 @@ extern "C" int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* 
       (((uintptr_t)loc | (uintptr_t)attn) & 15) == 0) {
     if (g_msda_op_staged && G == 1 && L == 4 && S >= 64) {
       // v3: coarse levels in LDS.  Budget from S alone (the level table is device memory): the two coarsest levels of a /2 pyramid
-      // are 5/85 of the tokens; 1100 rows = 138 KB at most beside the descriptors (36 KB)
+      // are 5/85 of the tokens; at most 960 rows = 120 KB beside the descriptors (36 KB) in the 160-KB LDS
       long budget = S / 16 + 8;
-      if (budget > 1100) budget = 1100;
+      if (budget > 960) budget = 960;
       const long desc = 16L * 8 * (8 + 1) * 4 * 2 * 4;
       const long staged = (budget + 1) * 32 * 4;
       const int chunk = staged < 45 * 1024 ? 128 : staged < 80 * 1024 ? 256 : 512;      // as msda_fused_v3 (measured there)

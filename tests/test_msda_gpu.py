@@ -95,6 +95,7 @@ def test_full_size_properties():
     ([(8, 12), (4, 6), (2, 3), (1, 2)], 3, 128),              # tiny maps: three levels staged
     ([(10, 10), (10, 10), (10, 10), (10, 10)], 2, 400),       # not a pyramid: only the last level fits
     ([(6, 10), (12, 20), (24, 40), (48, 80)], 2, 300),        # fine level LAST: nothing fits, every corner through the texture path
+    ([(100, 160), (50, 80), (25, 40), (13, 20)], 1, 300),     # 21260 tokens: the budget is capped (960 rows), only the coarsest level fits
 ])
 def test_op_with_coarse_levels_in_lds_equals_the_gather_form(shapes, B, Q):
     """msda_fwd_v3_kernel (the native op with the coarse levels of a (batch element, head) staged in LDS; the level table is device
