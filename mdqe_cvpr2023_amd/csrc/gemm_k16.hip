@@ -36,6 +36,16 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   const int lr = lane & 31, lh = lane >> 5;
   unsigned long long t_start = 0, t_pro = 0, t_loop = 0;   // tools/gemm_stamps.py only (100 MHz wall clock)
   if (p.stamps) t_start = wall_clock64();
+  if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 1024 && blockIdx.y == 0) {
+    // The blocks that share a CU start together and, tiles being equal, stay in lockstep for the whole launch: all of them are in
+    // their epilogue at the same time and the matrix pipe idles.  The k-th block of a CU's first round (dispatch fills the 256 CUs
+    // once per 256 blocks) therefore waits k x stagger; blocks start when a predecessor retires, so the offset carries on.
+    // Measured (tools/gemm_stagger_ab.py, r02): +9 % on FFN1 + GELU when the same GEMM is launched back to back (100 -> 109 TF),
+    // nothing inside the pipeline (107 TF either way, tools/frame_gemm_table.py; bench 700 vs 699 frames/s): there the blocks
+    // of a launch start as the previous, different kernel's blocks retire and are staggered already.  Off by default.
+    const unsigned long long until = wall_clock64() + (unsigned long long)((blockIdx.x >> 8) * p.stagger);
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+  }
 
   // XCD-aware tile order: blocks that share an A row-panel run on the same XCD (same L2).
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -330,11 +340,15 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   }
 }
 
+static int g_k16_stagger = 0;      // tools/ A/B: first-round start offset between the blocks of a CU, in 10-ns ticks
+extern "C" int mdqe_debug_gemm_stagger(int v) { g_k16_stagger = v; return MDQE_OK; }
 static int g_k16_stages = 0;       // tools/ A/B: 0 = by grid size, 2 / 4 = forced
 extern "C" int mdqe_debug_gemm_stages(int v) { g_k16_stages = v; return MDQE_OK; }
 
 template <int BM, int BN, int WM, int WN, bool CONV, bool LN, int NS>
-static int launch_k16_ns_(const GemmParams& p, hipStream_t st) {
+static int launch_k16_ns_(const GemmParams& p_in, hipStream_t st) {
+  GemmParams p = p_in;
+  p.stagger = g_k16_stagger;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   size_t smem = (size_t)NS * (BM + BN) * 16 * sizeof(float);
   if (smem < (size_t)WM * WN * 4096) smem = (size_t)WM * WN * 4096;        // per-wave epilogue slices

@@ -21,6 +21,7 @@ struct GemmParams {
   unsigned long long* stamps;   // debug: per-block s_memtime stamps (mdqe_debug_gemm_stamps), null in production
   const void* Wh; const void* Wl;   // pre-split f16 planes of W ([N][K] each; gemm_f16x3w.hip) or null
   const float* ln_g; const float* ln_b; float ln_eps;   // tile 6: LayerNorm over the 256 columns in the epilogue
+  int stagger;              // K-step-16 kernel: the first resident round of blocks starts (slot on the CU) x stagger 10-ns ticks late (0: off)
 };
 
 #define OOB_OFF 0xFFFFFFF0u
