@@ -121,7 +121,7 @@ msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows, const
 // 6 and 7 carry out-of-range offsets in the gather -- they read zeros -- and do not store).
 template <int L, int P, int MAP, int WPE, int DD = 32>
 __global__ void __launch_bounds__(256, WPE)
-msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
+msda_fused_v2_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode,
                      const float* __restrict__ grid, MsdaLevels lv,
@@ -137,7 +137,6 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
   __shared__ int sH[16], sW[16], sS[16];                                 // level table (indexed with a runtime level)
   if (threadIdx.x < 16) { sH[threadIdx.x] = lv.H[threadIdx.x]; sW[threadIdx.x] = lv.W[threadIdx.x]; sS[threadIdx.x] = lv.start[threadIdx.x]; }
   __syncthreads();
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
   const int grp = threadIdx.x >> 3, j = threadIdx.x & 7;
   // XCD-aware block order: blocks p and p+8 share an XCD (round-robin dispatch).  The first 8*floor(B/8) batch elements are
   // dealt one per XCD (element b entirely on XCD b mod 8: its value map, 5.2 MB at 360p, is fetched into ONE 4-MB L2 instead
@@ -192,7 +191,11 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
     const float rx = rp[0], ry = rp[1];
     float bw = 0.f, bh = 0.f;
     if (mode == 1) { bw = rp[2]; bh = rp[3]; }
-    const long brow = vidx != nullptr ? (long)vidx[b] * v_brows : (long)b * v_brows;
+    // The buffer resource starts at THIS element's value block (b is uniform over the block): the 32-bit offsets then span one
+    // element's levels -- one frame, or the frames of a clip in the temporal form -- not the whole cache (4.3 GB at 640p)
+    const long brow = __builtin_amdgcn_readfirstlane(vidx != nullptr ? vidx[b] : b) * v_brows;
+    const long left = value_bytes - brow * ldv * 4;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(value + brow * ldv), 0, (unsigned)(left < 0xF0000000L ? left : 0xF0000000L), 0x00020000);
     const bool chan = j * 4 < D;
     const unsigned lane_off = chan ? (unsigned)((m * D + j * 4) * 4) : MSDA_OOB;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -219,7 +222,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
         const float hh = 1.f - lh, hw = 1.f - lw;
         const bool h0 = in && h_low >= 0, h1 = in && h_low + 1 <= H - 1;
         const bool w0 = w_low >= 0, w1 = w_low + 1 <= W - 1;
-        const long prow = brow + sS[g * L + l] + (long)h_low * W + w_low;             // pixel row of the (low, low) corner
+        const long prow = sS[g * L + l] + (long)h_low * W + w_low;                    // pixel row of the (low, low) corner within the element
         const unsigned base = (unsigned)(prow * ldv * 4);
         const unsigned dW = (unsigned)((long)W * ldv * 4), d1 = (unsigned)(ldv * 4);
         u32x4 offv;
@@ -262,7 +265,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, unsigned value_bytes, long
 // The sample descriptors take half of v2's LDS: the 16 samples go in two halves of 8 (same order).
 template <int L, int P, int DD, int NT>
 __global__ void __launch_bounds__(NT)
-msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
+msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode, const float* __restrict__ grid, MsdaLevels lv,
                      int B, int M, int Q, int LS, int stage_px, int chunk, int nchunk, float scale,
@@ -292,8 +295,9 @@ msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long
   }
   if (b >= B) return;
   const int m = blk % M, ck = blk / M;
-  const long brow = vidx != nullptr ? (long)vidx[b] * v_brows : (long)b * v_brows;
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, value_bytes, 0x00020000);
+  const long brow = __builtin_amdgcn_readfirstlane(vidx != nullptr ? vidx[b] : b) * v_brows;
+  const long left = value_bytes - brow * ldv * 4;     // the resource starts at this element's value block (see v2)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(value + brow * ldv), 0, (unsigned)(left < 0xF0000000L ? left : 0xF0000000L), 0x00020000);
   __syncthreads();
   {                                             // stage the head's slice of the levels [LS, L): tokens sS[LS] .. sS[LS] + stage_px
     const int s0 = sS[LS];
@@ -358,7 +362,7 @@ msda_fused_v3_kernel(const float* __restrict__ value, unsigned value_bytes, long
         base = (unsigned)((sS[l] - sS[LS] + h_low * W + w_low) * (D * 4));
         dW = (unsigned)(W * D * 4); d1 = (unsigned)(D * 4); oob = zero_row;
       } else {
-        const long prow = brow + sS[l] + (long)h_low * W + w_low;
+        const long prow = sS[l] + (long)h_low * W + w_low;
         base = (unsigned)(prow * ldv * 4);
         dW = (unsigned)((long)W * ldv * 4); d1 = (unsigned)(ldv * 4); oob = MSDA_OOB;
       }
@@ -436,7 +440,11 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
   mdqe_clear_error();
   // v2 (cooperative sample set-up, buffer loads): D == 32, 16 samples, value buffer addressable with 32-bit offsets
   const long vbytes = value_rows > 0 ? ((value_rows - 1) * ldv + (long)M * D) * 4 : 0;
-  if ((D == 32 || D == 24) && L * P == 16 && vbytes > 0 && vbytes < 0xF0000000L) {
+  // what the 32-bit gather offsets must span: ONE element's levels (the kernels base their buffer resource at the element's block)
+  long span_rows = 0;
+  for (int i = 0; i < G * L; ++i) { const long e = (long)lv.start[i] + (long)lv.H[i] * lv.W[i]; if (e > span_rows) span_rows = e; }
+  const long span = (span_rows * ldv + (long)M * D) * 4;
+  if ((D == 32 || D == 24) && L * P == 16 && vbytes > 0 && span < 0xF0000000L) {
     // block-to-query map: the patch / row forms need the queries to be the level tokens in raster order (encoder: mode 0, G == 1,
     // Q == sum H*W); everything else keeps the plain order
     long ntok = 0;
@@ -475,7 +483,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
             attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 256) == hipSuccess;   // (a failure shows as a launch error below)
           }
-          hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, (unsigned)vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
+          hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
                              ref, ref_bstride, ref_dim, mode, grid, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
         };
         if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
@@ -492,7 +500,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
     else { nbq = 0; for (int l = 0; l < L; ++l) nbq += (long)((lv.W[l] + 7) / 8) * ((lv.H[l] + 3) / 4); nbq *= M; }
     const long nb2 = (long)B * nbq;                                            // exact grid: blocks per batch element x B
 #define LAUNCH2D(LL, PP, MP, WP, DDD) hipLaunchKernelGGL((msda_fused_v2_kernel<LL, PP, MP, WP, DDD>), dim3((unsigned)nb2), dim3(256), 0, st, value, \
-      (unsigned)vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total, \
+      vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, lv, B, M, G, Q, scale, out, ldout, total, \
       g_msda_xcd_order)
 #define LAUNCH2(LL, PP, MP, WP) do { if (D == 32) LAUNCH2D(LL, PP, MP, WP, 32); else LAUNCH2D(LL, PP, MP, WP, 24); } while (0)
 #define LAUNCH2M(LL, PP) do { const bool w8 = (var & 4) != 0; \

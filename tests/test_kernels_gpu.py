@@ -509,3 +509,50 @@ def test_decoder_box_level_msda_with_coarse_levels_in_lds_equals_the_gather_form
     finally:
         lib.mdqe_debug_msda_variant(-1)
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_fused_msda_on_a_value_cache_larger_than_4_gb():
+    """The decoder reads its value maps as 256-column slices of the [frames x tokens, 3072] cache, which passes 4 GB at 640p (or with
+    60-frame passes at 360p).  The gather kernels address with 32-bit buffer offsets: their resource is based at the ELEMENT's block, so
+    only one element's levels must fit the offset range.  Same launch on the big cache and on a compact copy of the frames it reads:
+    equal bits (box-level form on the staged kernel, temporal form -- 4 frames per element -- on v2)."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, D, L, P, Q = 8, 32, 4, 4, 196
+    shapes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    N = sum(h * w for h, w in shapes)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+    F = 72                                                         # 72 x 5100 rows x 3072 columns x 4 B = 4.5 GB
+    wide = torch.randn(F * N, 3072, device="cuda", generator=g)
+    assert wide.numel() * 4 > 2 ** 32
+    frames = [70, 3, 71, 68]                                       # blocks beyond the 4-GB mark and before it
+    compact = torch.cat([wide[f * N:(f + 1) * N] for f in frames + [69]]).contiguous()     # (+ frame 69: the temporal form reads 68..71)
+    nq = 2 * M * L * P
+    pr = 2.0 * torch.randn(len(frames) * Q, 3 * M * L * P, device="cuda", generator=g)
+    boxes = torch.rand(len(frames), Q, 4, device="cuda", generator=g) * torch.tensor([1, 1, 0.5, 0.5], device="cuda")
+    grid = torch.randn(M * L * P * 2, device="cuda", generator=g)
+    lv = ([s[0] for s in shapes], [s[1] for s in shapes], starts)
+    col = slice(1024, 1280)
+    outs = []
+    for buf, vidx in ((wide, frames), (compact, [0, 1, 2, 3])):
+        out = torch.empty(len(frames) * Q, 256, device="cuda")
+        ops.msda_fused(buf[:, col], pr[:, :nq], pr[:, nq:], boxes, lv, len(frames), Q, M, D, L, P, mode=1, grid=grid, v_brows=N,
+                       vidx=torch.tensor(vidx, dtype=torch.int32, device="cuda"), out=out)
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    # temporal form: one element = 4 consecutive frames (68..71 of the big cache = rows 3, 4, 2(71)... of the compact copy do not line up,
+    # so the compact copy is rebuilt in frame order)
+    compact_t = wide[68 * N:72 * N].contiguous()
+    Tc = 4
+    lv_tp = ([s[0] for s in shapes for _ in range(Tc)], [s[1] for s in shapes for _ in range(Tc)], [f * N + starts[gi] for gi in range(L) for f in range(Tc)])
+    pr_t = pr[:Q]
+    ib = boxes[:1]
+    outs = []
+    for buf, first in ((wide, 68), (compact_t, 0)):
+        out = torch.empty(Q, 256, device="cuda")
+        ops.msda_fused(buf[:, col], pr_t[:, :nq], pr_t[:, nq:], ib, lv_tp, 1, Q, M, D, Tc, P, mode=1, grid=grid, groups=L, scale=0.25, v_brows=N,
+                       vidx=torch.tensor([first], dtype=torch.int32, device="cuda"), out=out)
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
