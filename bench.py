@@ -417,7 +417,7 @@ def main():
                                 # HBM bytes need rocprofv3 --pmc passes, which cannot run inside this process: not a live figure -> null;
                                 # the per-launch counters of the dominant launch shape are in the file named below
                                 "traffic": None,
-                                "traffic_ref": "profiles/r01_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (M=153000 N=1024 K=256 +GELU, kernel unchanged since: 2 x FETCH_SIZE + WRITE_SIZE = 880 MB per launch vs 784 MB algorithmic)",
+                                "traffic_ref": "profiles/r02_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: 2 x FETCH_SIZE + WRITE_SIZE = 340 + 836 = 1175 MB per launch vs 1046 MB algorithmic = 1.12x)",
                                 "launches": g["launches"], "avg_launch_us": g["avg_us"],
                                 "note": "timed region: launches overlap with the clip-stream and tracker-stream kernels"}
             if g_iso:
