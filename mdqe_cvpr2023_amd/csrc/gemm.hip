@@ -288,6 +288,8 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
 static unsigned long long* g_gemm_stamps = nullptr;   // tools/ only: in-kernel phase stamps of the f16x3w kernel
 extern "C" int mdqe_debug_gemm_stamps(void* buf) { g_gemm_stamps = (unsigned long long*)buf; return MDQE_OK; }
 
+static int g_gemm_rows_dot = 1;       // tools/ A/B: 0 = N <= 8 products stay on the MFMA tiles
+extern "C" int mdqe_debug_gemm_rows_dot(int v) { g_gemm_rows_dot = v; return MDQE_OK; }
 static int g_gemm_variant = 2;         // fp32 kernel form: 0 = K-step 32 (gemm.hip), 1 = K-step 16 (gemm_k16.hip), 2 = by shape
 extern "C" int mdqe_debug_gemm_variant(int v) { g_gemm_variant = v; return MDQE_OK; }
 
@@ -371,6 +373,60 @@ extern "C" int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const 
   return mdqe_launch_gemm_k16(p, 6, (hipStream_t)stream);
 }
 
+
+// ---- N <= 8 output columns (the decoder's box head 256 -> 4 and time weights 256 -> 1, on 31 360 rows a pass): a 128x64 MFMA tile
+// computes 64 columns to keep 4, and the launch is bound by reading A anyway.  Here a wave takes 4 rows at a time, a lane 4
+// consecutive k of each (one coalesced 1-KB read per row and 256 k), the N weight rows come from L1, and the partial dot products
+// are summed across the wave with xor-shuffles.  fp32 FMA arithmetic; the summation order differs from the MFMA kernel's
+// (the same rows always take the same path: N and K decide, not M).
+template <int NN>
+__global__ void __launch_bounds__(256)
+rows_dot_kernel(const float* __restrict__ A, long lda, const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ C,
+                long ldc, int M, int K, int act, int act_cols) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long r0 = wave * 4; r0 < M; r0 += nwaves * 4) {
+    float acc[4][NN];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int n = 0; n < NN; ++n) acc[r][n] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 256) {
+      f32x4 a[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = r0 + r < M ? r0 + r : M - 1;
+        a[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A + row * lda + k0 + lane * 4));
+      }
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)n * K + k0 + lane * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[r][n] = fmaf(a[r][3], w[3], fmaf(a[r][2], w[2], fmaf(a[r][1], w[1], fmaf(a[r][0], w[0], acc[r][n]))));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        float v = acc[r][n];
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) v += __shfl_xor(v, sft, 64);
+        acc[r][n] = v;
+      }
+    if (lane < 4 && r0 + lane < M) {               // lane r writes row r0 + r
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        float v = lane == 0 ? acc[0][n] : lane == 1 ? acc[1][n] : lane == 2 ? acc[2][n] : acc[3][n];
+        if (bias != nullptr) v += bias[n];
+        if (act != MDQE_ACT_NONE && (act_cols <= 0 || n < act_cols)) v = mdqe_act(v, act);
+        C[(r0 + lane) * ldc + n] = v;
+      }
+    }
+  }
+}
+
 extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc,
                                 int M, int N, int K, int act, int act_cols, const float* residual, long ldr, int res_mod,
                                 int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
@@ -394,6 +450,19 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
     if (ks > 1) { p.ksplit = ks; p.kchunk = kc; p.ws = splitk_ws; }
   }
   mdqe_clear_error();
+  if (N <= 8 && K % 256 == 0 && tile == 0 && p.ksplit <= 1 && residual == nullptr && rowmask == nullptr && g_gemm_rows_dot) {
+    const long waves = ((long)M + 3) / 4;
+    long nb = (waves + 3) / 4;
+    if (nb > 256L * 8) nb = 256L * 8;
+    hipStream_t st = (hipStream_t)stream;
+#define ROWS_DOT(NN) hipLaunchKernelGGL((rows_dot_kernel<NN>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, W, bias, C, ldc, M, K, act, act_cols)
+    switch (N) {
+      case 1: ROWS_DOT(1); break; case 2: ROWS_DOT(2); break; case 3: ROWS_DOT(3); break; case 4: ROWS_DOT(4); break;
+      case 5: ROWS_DOT(5); break; case 6: ROWS_DOT(6); break; case 7: ROWS_DOT(7); break; default: ROWS_DOT(8); break;
+    }
+#undef ROWS_DOT
+    return mdqe_launch_status();
+  }
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }
 

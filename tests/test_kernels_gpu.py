@@ -556,3 +556,27 @@ def test_fused_msda_on_a_value_cache_larger_than_4_gb():
                        vidx=torch.tensor([first], dtype=torch.int32, device="cuda"), out=out)
         outs.append(out)
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K,act", [(31360, 4, 256, None), (31361, 1, 256, None), (2050, 8, 512, "sigmoid"), (7843, 3, 256, "relu")])
+def test_linear_with_a_few_output_columns(M, N, K, act):
+    """rows_dot_kernel (N <= 8: the decoder's box head and time weights) against fp64, and against the MFMA tiles it replaces."""
+    from mdqe_cvpr2023_amd import ops
+    from mdqe_cvpr2023_amd._lib import lib
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K + 64, generator=g).cuda()[:, :K]                     # a padded row pitch
+    w, b = (torch.randn(N, K, generator=g) / 16).cuda(), torch.randn(N, generator=g).cuda()
+    ref = x.double() @ w.double().t() + b.double()
+    if act == "sigmoid":
+        ref = torch.sigmoid(ref)
+    elif act == "relu":
+        ref = torch.relu(ref)
+    out = ops.linear(x, w, b, act=act)
+    try:
+        lib.mdqe_debug_gemm_rows_dot(0)
+        out_mfma = ops.linear(x, w, b, act=act)
+    finally:
+        lib.mdqe_debug_gemm_rows_dot(1)
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) < 2e-6 * max(scale, 1.0)
+    assert float((out - out_mfma).abs().max()) < 4e-6 * max(scale, 1.0)
