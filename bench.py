@@ -304,7 +304,7 @@ def main():
         elif not stream:
             for _ in range(k):
                 o = sharding.run_round_robin(mdl, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), root_only=True,
-                                             halo_exchange=args.halo_exchange)
+                                             halo_exchange=args.halo_exchange, like=like)
         else:
             for o in sharding.run_round_robin_stream(mdl, ((chunk_frames, plan, like) for _ in range(k)), rank, world, dist,
                                                      out_size=(fh, fw), root_only=True, halo_exchange=args.halo_exchange):

@@ -231,14 +231,15 @@ def owned_chunks(plan, world, rank):
     return [g for g in range(len(plan)) if g % world == rank]
 
 
-def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False):
+def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, like=None):
     """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
     Default: every rank all-gathers each round and replays the tracker (all ranks return the video result;
     emit_masks=False skips the mask production on ranks that only keep the tracker in step).
     root_only=True (bench.py): the rounds are gathered to rank 0 only, which replays the tracker on a worker thread while
-    its main thread goes on with the next round; the other ranks only compute and send, and return None."""
-    return next(run_round_robin_stream(model, [(chunk_frames, plan)], rank, world, dist, out_size, emit_masks=emit_masks,
-                                       root_only=root_only, halo_exchange=halo_exchange))
+    its main thread goes on with the next round; the other ranks only compute and send, and return None.
+    `like`: any [.., h, w] tensor on the frames' device -- needed by a rank that owns NO chunk of this video (more ranks than chunks)."""
+    return next(run_round_robin_stream(model, [(chunk_frames, plan, like) if like is not None else (chunk_frames, plan)], rank, world, dist, out_size,
+                                       emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange))
 
 
 class _Halo:

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 VIDEO_MODES = ["round_robin", "root_only", "contiguous", "halo_exchange", "decreasing", "decreasing_halo_exchange"]
 STREAM_MODES = ["stream", "stream_root_only", "stream_two_window_chunks", "stream_halo_exchange"]
 ONE_RANK_MODES = ["round_robin", "root_only", "stream_root_only", "halo_exchange", "stream_halo_exchange"]
+FOUR_RANK_MODES = ["round_robin", "root_only", "halo_exchange", "decreasing_halo_exchange", "stream_root_only", "stream_halo_exchange"]
 
 
 def _cfg():
@@ -55,7 +56,8 @@ def _run_mode(mode, model, cfg, rank, world, dist, sharding):
     sizes = [4, 3] if mode.startswith("decreasing") else 4     # decreasing rounds at 2 ranks: 4 4 | 3; else 4-frame chunks -> 3 chunks, 2 rounds
     plan = sharding.chunk_plan(L, cfg.n_frames_test, cfg.clip_stride, sizes, halo_exchange=halo, world=world)
     frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}
-    out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96), root_only=mode == "root_only", halo_exchange=halo)
+    out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96), root_only=mode == "root_only", halo_exchange=halo,
+                                   like=video[:0].cuda())
     if mode == "root_only":
         assert (out is None) == (rank != 0)
     return out
@@ -131,6 +133,12 @@ def two_ranks(tmp_path_factory):
 
 
 @pytest.fixture(scope="module")
+def four_ranks(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("four_ranks"))
+    return d, _spawn(4, d, FOUR_RANK_MODES)
+
+
+@pytest.fixture(scope="module")
 def one_rank_rccl(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("one_rank_rccl"))
     return d, _spawn(1, d, ONE_RANK_MODES, backend="nccl", p2p_self=True)
@@ -168,6 +176,23 @@ def test_two_rank_sharded_video_equals_single_gpu(two_ranks, refs, mode):
     d, _ = two_ranks
     for r in range(1 if mode == "root_only" else 2):
         _same(_load(d, mode, r), refs["video"])
+
+
+@pytest.mark.parametrize("mode", FOUR_RANK_MODES)
+def test_four_rank_sharded_equals_single_gpu(four_ranks, refs, mode):
+    """Four ranks (on a 1-GPU box: four processes on cuda:0 over gloo): the 11-frame video is 3 chunks, so rank 3 owns nothing and sits
+    the round out; the stream's videos of 3, 1 and 4 chunks leave ranks idle in turn; the halo ring runs over more than two ranks."""
+    d, codes = four_ranks
+    errs = sorted(f for f in os.listdir(d) if f.endswith(".err"))
+    assert codes == [0, 0, 0, 0] and not errs, "exit codes %s\n%s" % (codes, "\n".join("%s:\n%s" % (f, open(os.path.join(d, f)).read()) for f in errs))
+    root = mode in ("root_only", "stream_root_only")
+    for r in range(1 if root else 4):
+        outs = _load(d, mode, r)
+        if mode.startswith("stream"):
+            for out, ref in zip(outs, refs["stream"]):
+                _same(out, ref)
+        else:
+            _same(outs, refs["video"])
 
 
 def test_two_rank_workers_exit_cleanly(two_ranks):
