@@ -220,7 +220,7 @@ class _FakeMerger:
 STREAM_L = (13, 5, 22)            # 4, 1 and 6 chunks of 4 frames
 
 
-def stream_worker(rank, world, port, outdir, root_only):
+def stream_worker(rank, world, port, outdir, root_only, lengths=None):
     import torch.distributed as dist
     import mdqe_cvpr2023_amd.meta_arch as MA
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -230,7 +230,7 @@ def stream_worker(rank, world, port, outdir, root_only):
     log = []
     model = _FakeModel(log)
     jobs = []
-    for Lv in STREAM_L:
+    for Lv in (lengths or STREAM_L):
         plan = sharding.chunk_plan(Lv, CFG.n_frames_test, 1, 4)
         frames = {g: torch.zeros(plan[g][2] - plan[g][1], 3, HW[0] * 4, HW[1] * 4) for g in sharding.owned_chunks(plan, world, rank)}
         jobs.append((frames, plan, torch.zeros(0, 3, HW[0] * 4, HW[1] * 4)))
@@ -242,16 +242,16 @@ def stream_worker(rank, world, port, outdir, root_only):
     dist.destroy_process_group()
 
 
-def _run_stream(tmp_path, root_only):
+def _run_stream(tmp_path, root_only, world=2, lengths=None):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=stream_worker, args=(r, 2, port, str(tmp_path), root_only)) for r in range(2)]
+    procs = [ctx.Process(target=stream_worker, args=(r, world, port, str(tmp_path), root_only, lengths)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=180)
+        p.join(timeout=300)
         assert p.exitcode == 0
-    return [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(2)]
+    return [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(world)]
 
 
 def test_round_robin_stream_two_ranks_all_replay(tmp_path):
@@ -279,6 +279,22 @@ def test_round_robin_stream_two_ranks_root_only(tmp_path):
     for Lv, (clip_order, tracks) in zip(STREAM_L, outs0):
         assert clip_order == clip_schedule(Lv, CFG.n_frames_test, 1)
         ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clip_schedule(Lv, CFG.n_frames_test, 1)])
+        for (c, m), (cr, mr) in zip(tracks, ref):
+            assert torch.allclose(c, cr) and torch.equal(m, mr)
+
+
+def test_round_robin_stream_eight_ranks_root_only(tmp_path):
+    """The bench's N = 8 form with a stand-in model: videos of 4, 1 and 18 chunks on eight ranks (idle ranks in a round, a whole video
+    without work for most ranks, three rounds of the long one): rank 0 sees every clip once, in global order, and replays to the
+    single-process tracker result; the other ranks hand out None."""
+    lengths = (13, 5, 70)
+    got = _run_stream(tmp_path, True, world=8, lengths=lengths)
+    assert all(o is None for r in range(1, 8) for o in got[r][0]) and all(len(got[r][0]) == len(lengths) for r in range(8))
+    for Lv, (clip_order, tracks) in zip(lengths, got[0][0]):
+        clips = clip_schedule(Lv, CFG.n_frames_test, 1)
+        assert clip_order == clips
+        ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clips])
+        assert len(tracks) == len(ref)
         for (c, m), (cr, mr) in zip(tracks, ref):
             assert torch.allclose(c, cr) and torch.equal(m, mr)
 
