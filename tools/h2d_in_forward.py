@@ -17,12 +17,19 @@ ts = []
 def timed(imgs):
     t0 = time.perf_counter(); r = orig(imgs); ts.append(1e3 * (time.perf_counter() - t0)); return r
 model.upload_frames = timed
+import gc
 with torch.no_grad():
-    for name, img in (("host", frames), ("resident", res), ("host", frames), ("resident", res)):
+    for name, img in (("host", frames), ("resident", res), ("host gc.freeze", frames), ("host gc.disable", frames), ("host", frames)):
+        if "freeze" in name:
+            gc.collect(); gc.freeze()
+        if "disable" in name:
+            gc.disable()
+        elif name == "host":
+            gc.enable()
         inp = [{"image": img, "height": 360, "width": 640}]
         for _ in range(3):
             model(inp)
         torch.cuda.synchronize(); ts.clear(); per = []
         for _ in range(10):
             t0 = time.perf_counter(); model(inp); per.append(1e3 * (time.perf_counter() - t0))
-        print("%-8s per video %s ms (mean %.2f) | upload_frames host time %s ms" % (name, " ".join("%.1f" % v for v in per), sum(per) / len(per), " ".join("%.2f" % v for v in ts)), flush=True)
+        print("%-16s per video %s ms (mean %.2f) | upload_frames host time %s ms" % (name, " ".join("%.1f" % v for v in per), sum(per) / len(per), " ".join("%.2f" % v for v in ts)), flush=True)
