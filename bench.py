@@ -40,6 +40,7 @@ class GemmMeter:
         raw = _lib.load_library().mdqe_gemm_nt_f32
         raw_conv = _lib.load_library().mdqe_conv2d_nhwc_f32
         raw_ln = _lib.load_library().mdqe_gemm_ln_f32
+        raw_cat = _lib.load_library().mdqe_gemm_nt_cat2_f32
         meter = self
 
         class Wrapped:
@@ -67,6 +68,18 @@ class GemmMeter:
                 rc = raw_ln(*a)
                 e1.record()
                 meter.rec.append((e0, e1, 2.0 * M * N * K))
+                return rc
+
+            def mdqe_gemm_nt_cat2_f32(self_, *a):             # bottleneck conv3 + projection shortcut as one product (same kernel template)
+                K1, K2, NI, OH, OW, N = a[2], a[5], a[6], a[7], a[8], a[16]
+                M = NI * OH * OW
+                if not (meter.enabled and N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 192):
+                    return raw_cat(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = raw_cat(*a)
+                e1.record()
+                meter.rec.append((e0, e1, 2.0 * M * N * (K1 + K2)))
                 return rc
 
             def mdqe_conv2d_nhwc_f32(self_, *a):

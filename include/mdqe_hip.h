@@ -97,6 +97,15 @@ int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const float* bias
                      int res_first, const unsigned char* rowmask, int mask_cols, int tile, int ksplit,
                      float* splitk_ws, const void* w_split, void* stream);
 
+/* The last 1x1 conv of a ResNet bottleneck and its projection shortcut as ONE product (detectron2 BottleneckBlock.forward:
+ * out = relu(conv3(y) + shortcut(x)), both with folded FrozenBN; the reference reaches them through cuDNN):
+ * C = act([A1 | A2'] W^T + bias) with W = [W3 | Ws] along K and bias = b3 + bs, so the shortcut's output is never written and read
+ * back.  A1 [M = NI*OH*OW, K1] rows of pitch lda1; A2 the block's input, NHWC [NI, H2, W2, lda2 >= K2], read at pixel
+ * (oh*stride, ow*stride) for output row (img, oh, ow).  K1, K2 multiples of 16.  Exact fp32 MFMA. */
+int mdqe_gemm_nt_cat2_f32(const float* A1, long lda1, int K1, const float* A2, long lda2, int K2, int NI, int OH, int OW,
+                          int H2, int W2, int stride, const float* W, const float* bias, float* C, long ldc, int N, int act,
+                          void* stream);
+
 /* Linear + residual + LayerNorm in one kernel, for the encoder / decoder pattern  x = norm(x + dropout(linear(..)))
  * (transformer_enc.py:100-110, transformer_dec.py:352-358,404-409; nn.LayerNorm over d_model = 256):
  * C = LN(A W^T + bias + residual) * gamma + beta, N must be 256; C may alias the residual.  Exact fp32 MFMA. */

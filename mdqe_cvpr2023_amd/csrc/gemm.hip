@@ -466,6 +466,40 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
   return dispatch_gemm(p, tile, (hipStream_t)stream);
 }
 
+
+// C = act([A1 | A2'] W^T + bias): the last 1x1 conv of a ResNet bottleneck and its projection shortcut as ONE product -- W = [W3 | Ws]
+// along K, bias = b3 + bs -- so the shortcut's output (as wide as the block's output) is never written and read back.  A1: [M, K1]
+// rows (pitch lda1); A2: the block's input, NHWC [NI, H2, W2, lda2 >= K2], read at pixel (oh*stride, ow*stride) for output row
+// m = (img, oh, ow) (the shortcut's stride).  Exact fp32 MFMA only (the split-precision mode keeps the two-launch form).
+extern "C" int mdqe_gemm_nt_cat2_f32(const float* A1, long lda1, int K1, const float* A2, long lda2, int K2, int NI, int OH, int OW,
+                                     int H2, int W2, int stride, const float* W, const float* bias, float* C, long ldc, int N, int act,
+                                     void* stream) {
+  MDQE_REQUIRE(NI >= 0 && OH > 0 && OW > 0 && H2 > 0 && W2 > 0 && stride > 0 && N > 0 && K1 > 0 && K2 > 0);
+  MDQE_REQUIRE(K1 % 16 == 0 && K2 % 16 == 0 && lda1 % 4 == 0 && lda2 % 4 == 0 && lda1 >= K1 && lda2 >= K2 && ldc >= N);
+  MDQE_REQUIRE((long)(OH - 1) * stride < H2 && (long)(OW - 1) * stride < W2);
+  const long Ml = (long)NI * OH * OW;
+  MDQE_REQUIRE(Ml < 0x7FFFFFFFL);
+  if (Ml == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(A1); MDQE_CHECK_PTR(A2); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
+  MDQE_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)W) & 15) == 0);
+  const int M = (int)Ml, K = K1 + K2;
+  const long ab = ((long)(M - 1) * lda1 + K1) * 4, a2b = (((long)NI * H2 * W2 - 1) * lda2 + K2) * 4, wb = (long)N * K * 4;
+  MDQE_REQUIRE(ab < 0xFFFFFFF0L && a2b < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  GemmParams p = {};
+  p.A = A1; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda1; p.ldc = ldc; p.conv = 0;
+  p.A2 = A2; p.lda2 = lda2; p.K1 = K1; p.a2_bytes = (unsigned)a2b; p.OH = OH; p.OW = OW; p.H = H2; p.Wd = W2; p.stride = stride;
+  p.bias = bias; p.act = act; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.ksplit = 1; p.kchunk = K;
+  p.stamps = g_gemm_stamps;
+  p.vec_ok = ((((uintptr_t)C | (uintptr_t)bias) & 15) == 0) && (ldc % 4 == 0);
+  const long b128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  int tile = 3;                                          // the plain GEMM's rule (dispatch_gemm)
+  if (N <= 64) tile = (M >= 4096) ? 2 : 3;
+  else if (b128 >= 2000 && (N >= 1024 || K >= 1024)) tile = 1;
+  else if (b128 >= 2000 && (N > 256 || K > 256)) tile = 2;
+  mdqe_clear_error();
+  return mdqe_launch_gemm_k16(p, tile, (hipStream_t)stream);
+}
+
 extern "C" int mdqe_conv2d_nhwc_f32(const float* X, long x_img_stride, const float* Wt, const float* bias, float* Y, long ldy,
                                     int NI, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                     int act, const float* residual, long ldr, int res_first, int tile, const void* w_split,

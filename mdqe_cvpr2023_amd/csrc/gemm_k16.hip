@@ -17,9 +17,10 @@
 // [5292,256]x[256,256] product) and measured at no gain, so it stays behind mdqe_debug_gemm_stages(4).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false, int NS = 2>
+template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false, int NS = 2, bool CAT = false>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN > 4) ? 2 : 4)
 gemm_nt_f32_k16_kernel(const GemmParams p) {
+  static_assert(!CAT || (!CONV && !LN), "cat mode: plain tiles only");
   constexpr int NW = WM * WN;
   constexpr int BK = 16;
   constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
@@ -60,11 +61,12 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+  const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(CAT ? p.A2 : p.A), 0, CAT ? p.a2_bytes : p.a_bytes, 0x00020000);
 
   // instruction j of this wave covers image rows (wave*IPW + j)*16 .. +15; lane -> row += lane>>2, LDS chunk lane&3,
   // source chunk = (lane&3) ^ ((row>>2)&3).  voff[j] = byte offset of (row, k = 4*chunk); the K-step rides on the scalar
   // offset (plain rows, W rows) or on the filter-tap offset in the VGPR (conv A rows: a padded pixel's base may wrap).
-  unsigned voff[IPW];
+  unsigned voff[IPW], voff2[IPW];
   int ih0[IPW], iw0[IPW], kch[IPW];
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
@@ -79,8 +81,15 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
         voff[j] = (unsigned)(((long)img * p.img_stride + ((long)ih0[j] * p.Wd + iw0[j]) * p.Cin) * 4) + (unsigned)(kch[j] * 4);   // may wrap
       } else {
         voff[j] = (unsigned)((long)m * p.lda * 4) + (unsigned)(kch[j] * 4);
+        if constexpr (CAT) {                       // the second operand's row: pixel (oh*stride, ow*stride) of image img
+          const int ow = m % p.OW; const int t = m / p.OW; const int oh = t % p.OH; const int img = t / p.OH;
+          const long r2 = ((long)img * p.H + (long)oh * p.stride) * p.Wd + (long)ow * p.stride;
+          voff2[j] = (unsigned)(r2 * p.lda2 * 4) + (unsigned)(kch[j] * 4);
+        }
       }
+      if constexpr (!CAT) voff2[j] = 0;
     } else {
+      voff2[j] = 0;
       int n = n0 + irow - BM; if (n > p.N - 1) n = p.N - 1;
       voff[j] = (unsigned)((long)n * p.K * 4) + (unsigned)(kch[j] * 4);
     }
@@ -109,6 +118,10 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           const bool ok = (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.Wd);
           off = ok ? off + (unsigned)tap_off : OOB_OFF;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, 0, 0, 0);
+        } else if (CAT && k0 >= p.K1) {              // (wave-uniform: K1 is a multiple of the K-step)
+          off = voff2[j];
+          if (ktail && k0 + kch[j] >= p.K) off = OOB_OFF;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, (k0 - p.K1) * 4, 0, 0);
         } else {
           if (ktail && k0 + kch[j] >= p.K) off = OOB_OFF;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + irow0 * BK), 16, off, k0 * 4, 0, 0);
@@ -345,14 +358,14 @@ extern "C" int mdqe_debug_gemm_stagger(int v) { g_k16_stagger = v; return MDQE_O
 static int g_k16_stages = 0;       // tools/ A/B: 0 = by grid size, 2 / 4 = forced
 extern "C" int mdqe_debug_gemm_stages(int v) { g_k16_stages = v; return MDQE_OK; }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool LN, int NS>
+template <int BM, int BN, int WM, int WN, bool CONV, bool LN, int NS, bool CAT = false>
 static int launch_k16_ns_(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
   p.stagger = g_k16_stagger;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   size_t smem = (size_t)NS * (BM + BN) * 16 * sizeof(float);
   if (smem < (size_t)WM * WN * 4096) smem = (size_t)WM * WN * 4096;        // per-wave epilogue slices
-  auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV, LN, NS>;
+  auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV, LN, NS, CAT>;
   hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(64 * WM * WN), smem, st, p);
   return mdqe_launch_status();
 }
@@ -372,6 +385,15 @@ static int launch_k16_(const GemmParams& p, hipStream_t st) {
 
 // tile: 1 128x128, 2 128x64, 3 64x64 (as gemm.hip), 7 32x64, 8 32x128, 9 64x128; the split-K reduce pass is launched by the caller
 int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
+  if (p.A2 != nullptr) {                                // cat mode: two A operands side by side along K
+    if (p.conv || p.ksplit > 1) return MDQE_EINVAL;
+    switch (tile) {
+      case 1: return launch_k16_ns_<128, 128, 2, 2, false, false, 2, true>(p, st);
+      case 2: return launch_k16_ns_<128, 64, 2, 2, false, false, 2, true>(p, st);
+      case 3: return launch_k16_ns_<64, 64, 2, 2, false, false, 2, true>(p, st);
+      default: return MDQE_EINVAL;
+    }
+  }
   switch (tile) {
     case 1: return p.conv ? launch_k16_<128, 128, 2, 2, true>(p, st) : launch_k16_<128, 128, 2, 2, false>(p, st);
     case 2: return p.conv ? launch_k16_<128, 64, 2, 2, true>(p, st) : launch_k16_<128, 64, 2, 2, false>(p, st);

@@ -21,6 +21,9 @@ struct GemmParams {
   unsigned long long* stamps;   // debug: per-block s_memtime stamps (mdqe_debug_gemm_stamps), null in production
   const void* Wh; const void* Wl;   // pre-split f16 planes of W ([N][K] each; gemm_f16x3w.hip) or null
   const float* ln_g; const float* ln_b; float ln_eps;   // tile 6: LayerNorm over the 256 columns in the epilogue
+  // cat mode (A2 != null, K-step-16 kernel, plain tiles): k < K1 comes from A, k >= K1 from row (img, oh*stride, ow*stride) of the NHWC
+  // tensor A2 [*, H, Wd, lda2] -- output row m = (img, oh, ow) on the OH x OW grid (H, Wd, OH, OW, stride as in conv mode)
+  const float* A2; long lda2; int K1; unsigned a2_bytes;
   int stagger;              // K-step-16 kernel: the first resident round of blocks starts (slot on the CU) x stagger 10-ns ticks late (0: off)
 };
 

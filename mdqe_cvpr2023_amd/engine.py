@@ -40,6 +40,7 @@ def _fold_bn(sd, p, eps=1e-5):
 
 GEO_CACHE = max(1, int(os.environ.get("MDQE_GEO_CACHE", "16")))     # resolutions whose constants stay resident
 STEM_FUSED = os.environ.get("MDQE_STEM_FUSED", "1") != "0"      # 0: im2col + GEMM (debug / A-B)
+RESNET_CAT = os.environ.get("MDQE_RESNET_CAT", "1") != "0"      # 0: projection shortcut and conv3 as two launches (debug / A-B)
 
 
 def _krsc(w):
@@ -112,6 +113,13 @@ class Packed:
                     for cn in ("conv1", "conv2", "conv3"):
                         w, b = _fold_bn(sd, f"{q}.{cn}")
                         setattr(blk, cn, (up(_krsc(w)), up(b)))
+                    blk.cat = None
+                    if blk.shortcut is not None:                   # conv3 + projection shortcut as one product: W = [W3 | Ws] along K
+                        w3, b3 = blk.conv3
+                        ws, bs = blk.shortcut
+                        n3 = w3.shape[0]
+                        if w3.numel() // n3 % 16 == 0 and ws.numel() // n3 % 16 == 0:
+                            blk.cat = (torch.cat([w3.reshape(n3, -1), ws.reshape(n3, -1)], 1).contiguous(), (b3 + bs).contiguous())
                     blocks.append(blk)
                 bb.stages.append(blocks)
             self.bb = bb
@@ -378,6 +386,12 @@ class Engine:
         for si, blocks in enumerate(bb.stages):
             for blk in blocks:
                 s = blk.stride
+                if blk.cat is not None and RESNET_CAT and ops.get_gemm_precision() == "f32" and x.is_contiguous():
+                    # relu(conv3(y) + shortcut(x)) in one launch: the shortcut's output (as wide as the block's) is never written
+                    y = self._conv(x, blk.conv1, 1, 1, 0, "relu")
+                    y = self._conv(y, blk.conv2, 3, s, 1, "relu")
+                    x = ops.linear_cat2(y, x, s, *blk.cat, act="relu")
+                    continue
                 sc = x if blk.shortcut is None else self._conv(x, blk.shortcut, 1, s, 0, None)
                 y = self._conv(x, blk.conv1, 1, 1, 0, "relu")
                 y = self._conv(y, blk.conv2, 3, s, 1, "relu")

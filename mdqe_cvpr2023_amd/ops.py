@@ -181,6 +181,22 @@ def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratc
     return layernorm(y, gamma, beta, eps=eps, out=out)
 
 
+def linear_cat2(y, x_nhwc, stride, weight, bias, act=None, out=None):
+    """act([y | x'] @ weight^T + bias): a bottleneck's conv3 and its projection shortcut in one product (mdqe_gemm_nt_cat2_f32).
+    y [NI, OH, OW, K1] (contiguous), x_nhwc [NI, H2, W2, K2] read at (oh*stride, ow*stride), weight [N, K1 + K2] -> [NI, OH, OW, N]."""
+    _chk(y, "y"); _chk(x_nhwc, "x"); _chk(weight, "weight"); _chk(bias, "bias")
+    NI, OH, OW, K1 = y.shape
+    _, H2, W2, K2 = x_nhwc.shape
+    N = weight.shape[0]
+    if not (y.is_contiguous() and x_nhwc.is_contiguous() and weight.is_contiguous() and weight.shape[1] == K1 + K2):
+        raise RuntimeError("linear_cat2: contiguous operands and a [N, K1 + K2] weight required")
+    if out is None:
+        out = torch.empty((NI, OH, OW, N), dtype=torch.float32, device=y.device)
+    check(lib.mdqe_gemm_nt_cat2_f32(ptr(y), K1, K1, ptr(x_nhwc), K2, K2, NI, OH, OW, H2, W2, stride, ptr(weight), ptr(bias), ptr(out), N, N,
+                                    ACT[act], cur_stream()), "gemm_nt_cat2")
+    return out
+
+
 def layernorm(x, gamma, beta, res=None, eps=1e-5, out=None):
     _chk(x, "x"); _chk(res, "res"); _chk(gamma, "gamma"); _chk(beta, "beta")
     C = x.shape[-1]

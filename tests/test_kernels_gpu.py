@@ -580,3 +580,25 @@ def test_linear_with_a_few_output_columns(M, N, K, act):
     scale = float(ref.abs().max())
     assert float((out.double() - ref).abs().max()) < 2e-6 * max(scale, 1.0)
     assert float((out - out_mfma).abs().max()) < 4e-6 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("NI,H2,W2,K2,K1,N,stride", [(3, 24, 40, 64, 64, 256, 1), (2, 24, 40, 256, 128, 512, 2), (5, 13, 21, 512, 256, 1024, 2),
+                                                    (1, 7, 9, 1024, 512, 2048, 2), (40, 12, 20, 64, 64, 256, 1)])
+def test_bottleneck_conv3_and_projection_shortcut_as_one_product(NI, H2, W2, K2, K1, N, stride):
+    """mdqe_gemm_nt_cat2_f32 (second A operand = the block's input read with the shortcut's stride) against the two-launch form it
+    replaces and against fp64; odd map sizes (13 x 21 -> 7 x 11 at stride 2)."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(N + NI)
+    OH, OW = (H2 - 1) // stride + 1, (W2 - 1) // stride + 1
+    x = torch.randn(NI, H2, W2, K2, generator=g).cuda()
+    y = torch.randn(NI, OH, OW, K1, generator=g).cuda()
+    w3, ws = (torch.randn(N, K1, generator=g) / K1 ** 0.5).cuda(), (torch.randn(N, K2, generator=g) / K2 ** 0.5).cuda()
+    b3, bs = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    out = ops.linear_cat2(y, x, stride, torch.cat([w3, ws], 1).contiguous(), b3 + bs, act="relu")
+    xs = x[:, ::stride, ::stride].contiguous()
+    ref = torch.relu(y.double().reshape(-1, K1) @ w3.double().t() + xs.double().reshape(-1, K2) @ ws.double().t() + (b3 + bs).double()).view(NI, OH, OW, N)
+    sc = ops.conv2d_nhwc(x, ws.view(N, 1, 1, K2), bs, stride, 0)
+    two = ops.linear(y.view(-1, K1), w3, b3, act="relu", residual=sc.view(-1, N), res_first=True).view(NI, OH, OW, N)
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) < 3e-6 * scale
+    assert float((out - two).abs().max()) < 6e-6 * scale

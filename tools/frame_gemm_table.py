@@ -15,7 +15,7 @@ model = MDQE(cfg, state_dict=random_state(cfg, seed=0)).eval()
 video = synth_video(0, nfr, seed=0, h=fh, w=fw).cuda()
 rec = []
 L = _lib.load_library()
-raw = {n: getattr(L, n) for n in ("mdqe_gemm_nt_f32", "mdqe_gemm_ln_f32", "mdqe_conv2d_nhwc_f32")}
+raw = {n: getattr(L, n) for n in ("mdqe_gemm_nt_f32", "mdqe_gemm_ln_f32", "mdqe_conv2d_nhwc_f32", "mdqe_gemm_nt_cat2_f32")}
 
 
 class Wrapped:
@@ -35,6 +35,11 @@ class Wrapped:
     def mdqe_gemm_ln_f32(self, *a):
         M, N, K = a[6], a[7], a[8]
         return self._timed("mdqe_gemm_ln_f32", "gemm+LN  M=%7d N=%5d K=%5d" % (M, N, K), 2.0 * M * N * K, a)
+
+    def mdqe_gemm_nt_cat2_f32(self, *a):
+        K1, K2, NI, OH, OW, N = a[2], a[5], a[6], a[7], a[8], a[16]
+        M = NI * OH * OW
+        return self._timed("mdqe_gemm_nt_cat2_f32", "gemm cat M=%7d N=%5d K=%5d" % (M, N, K1 + K2), 2.0 * M * N * (K1 + K2), a)
 
     def mdqe_conv2d_nhwc_f32(self, *a):
         NI, H, W, Cin, Cout, KH, KW, stride, pad = a[6:15]
