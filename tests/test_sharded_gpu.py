@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 VIDEO_MODES = ["round_robin", "root_only", "contiguous", "halo_exchange", "decreasing", "decreasing_halo_exchange"]
 STREAM_MODES = ["stream", "stream_root_only", "stream_two_window_chunks", "stream_halo_exchange"]
 ONE_RANK_MODES = ["round_robin", "root_only", "stream_root_only", "halo_exchange", "stream_halo_exchange"]
-FOUR_RANK_MODES = ["round_robin", "root_only", "halo_exchange", "decreasing_halo_exchange", "stream_root_only", "stream_halo_exchange"]
+FOUR_RANK_MODES = ["round_robin", "halo_exchange", "stream_root_only", "stream_halo_exchange"]
 
 
 def _cfg():
