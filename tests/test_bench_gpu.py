@@ -1,0 +1,30 @@
+"""GPU: the bench's one JSON line keeps the driver's contract (keys, types, internal consistency) -- a short run of the real script."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "24", "--no-cpu-baseline", "--no-fast-mode"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["unit"] == "frames/s"
+    assert "workload" in d["config"] and "model" not in d["config"] and "H2D included" in d["config"]["workload"]
+    assert abs(d["value"] - 24 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]             # value = frames per step / time per step
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["traffic"] is None
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] < 1.0 and rf["peak"] == 157.3
+    assert d["config"]["clips_per_step"] == 24 - 2 and d["config"]["instances_out"] >= 1
