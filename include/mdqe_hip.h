@@ -130,6 +130,7 @@ int mdqe_f16x3_split_f32(const float* w, long n, void* planes, void* stream);
 int mdqe_debug_gemm_stamps(void* buf);
 /* tools/ only: fp32 GEMM kernel form, 0 = K-step 32 (gemm.hip), 1 = K-step 16 (gemm_k16.hip), 2 = chosen by shape (default). */
 int mdqe_debug_gemm_variant(int v);
+int mdqe_debug_gemm_tile_rule(int v); /* auto tile rule variants (tools/ A/B); 0 = default */
 int mdqe_debug_gemm_rows_dot(int v); /* products with N <= 8 columns: 1 (default) = rows_dot_kernel, 0 = MFMA tiles */
 int mdqe_debug_gemm_stagger(int v);  /* K-step-16 kernel: start offset between the blocks of a CU's first round, 10-ns ticks; 0 = off */
 int mdqe_debug_gemm_stages(int v);   /* K-step-16 kernel, 64x64 and smaller tiles: LDS stages 2 / 4; 0 = by grid size (default) */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mdqe_f16x3_split_f32": [p, l, p, p],
     "mdqe_debug_gemm_stamps": [p],
     "mdqe_debug_gemm_variant": [i],
+    "mdqe_debug_gemm_tile_rule": [i],
     "mdqe_debug_gemm_rows_dot": [i],
     "mdqe_debug_gemm_stagger": [i],
     "mdqe_debug_gemm_stages": [i],

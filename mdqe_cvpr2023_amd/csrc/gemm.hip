@@ -288,6 +288,8 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
 static unsigned long long* g_gemm_stamps = nullptr;   // tools/ only: in-kernel phase stamps of the f16x3w kernel
 extern "C" int mdqe_debug_gemm_stamps(void* buf) { g_gemm_stamps = (unsigned long long*)buf; return MDQE_OK; }
 
+static int g_gemm_tile_rule = 0;      // tools/ A/B of the auto tile rule
+extern "C" int mdqe_debug_gemm_tile_rule(int v) { g_gemm_tile_rule = v; return MDQE_OK; }
 static int g_gemm_rows_dot = 1;       // tools/ A/B: 0 = N <= 8 products stay on the MFMA tiles
 extern "C" int mdqe_debug_gemm_rows_dot(int v) { g_gemm_rows_dot = v; return MDQE_OK; }
 static int g_gemm_variant = 2;         // fp32 kernel form: 0 = K-step 32 (gemm.hip), 1 = K-step 16 (gemm_k16.hip), 2 = by shape
@@ -312,6 +314,8 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (g_gemm_precision == 1 && p.Wh != nullptr && b128 >= 192 && p.N > 64) tile = 1;      // f16x3w has its own tiling
     else if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
+    else if ((g_gemm_tile_rule & 1) && b128 >= 2000 && p.N >= 1024 && p.N < 2048 && p.K <= 256 && !p.conv) tile = 9;   // short K, wide N -> 64x128
+    else if ((g_gemm_tile_rule & 2) && p.conv && p.KH == 3 && b128 < 2000 && b128 >= 400 && p.N >= 256 && p.K < 4096) tile = 9;   // mid-grid 3x3 convs
     else if (b128 >= 2000 && (p.N >= 1024 || p.K >= 1024)) tile = 1;
     else if (b128 >= 2000 && (p.N > 256 || p.K > 256)) tile = 2;
     else tile = 3;                                   // incl. the encoder's [204000,256]x[256,256] (64x64: 288 vs 329 us)

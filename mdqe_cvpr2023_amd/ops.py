@@ -17,6 +17,8 @@ if os.environ.get("MDQE_MSDA_VARIANT"):                 # tools/ A/B of the fuse
 if os.environ.get("MDQE_MSDA_DEC_STAGED"):              # tools/ A/B: decoder box-level MSDA on the LDS-staged kernel (1, default) or v2 (0)
     check(lib.mdqe_debug_msda_dec_staged(int(os.environ["MDQE_MSDA_DEC_STAGED"])), "msda_dec_staged")
 
+if os.environ.get("MDQE_GEMM_TILE_RULE"):               # tools/ A/B of the auto tile rule (csrc/gemm.hip dispatch_gemm)
+    check(lib.mdqe_debug_gemm_tile_rule(int(os.environ["MDQE_GEMM_TILE_RULE"])), "gemm_tile_rule")
 if os.environ.get("MDQE_GEMM_STAGGER"):                 # tools/ A/B: start stagger between the blocks of a CU (csrc/gemm_k16.hip), 10-ns ticks
     check(lib.mdqe_debug_gemm_stagger(int(os.environ["MDQE_GEMM_STAGGER"])), "gemm_stagger")
 
