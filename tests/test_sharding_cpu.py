@@ -3,6 +3,7 @@ equal the single-process schedule (the N>1 path of bench.py / SURVEY.md §8e).""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.multiprocessing as mp
 
@@ -344,3 +345,26 @@ def test_producer_failure_stops_the_replay_workers():
         assert threading.active_count() == base
     finally:
         MA.ClipMerger = old
+
+
+def test_chunk_plan_properties_on_random_inputs():
+    """chunk_plan over random video lengths, clip lengths, strides, world sizes and per-round chunk sizes: every clip exactly once and in
+    global order; the recompute form's frame range covers its clips; the halo form partitions the frames, puts a clip into the chunk of
+    its last frame, keeps a whole clip in every chunk (sizes >= T) and never reaches further left than T-1 frames."""
+    rng = np.random.RandomState(11)
+    for _ in range(400):
+        L_, T, stride, world = int(rng.randint(1, 400)), int(rng.randint(1, 6)), int(rng.randint(1, 4)), int(rng.randint(1, 9))
+        sizes = [int(v) for v in rng.randint(max(T, 1), 60, size=rng.randint(1, 4))]
+        chunk = sizes if rng.rand() < 0.7 else sizes[0]
+        clips = clip_schedule(L_, T, stride)
+        plan = sharding.chunk_plan(L_, T, stride, chunk, world=world)
+        assert [c for ch in plan for c in ch[0]] == clips
+        assert all(f0 <= s and e <= f1 for cl, f0, f1 in plan for s, e, _ in cl)
+        assert sorted(g for r in range(world) for g in sharding.owned_chunks(plan, world, r)) == list(range(len(plan)))
+        if stride == 1 and L_ >= T:
+            hp = sharding.chunk_plan(L_, T, stride, chunk, halo_exchange=True, world=world)
+            assert [c for ch in hp for c in ch[0]] == clips
+            assert hp[0][1] == 0 and hp[-1][2] == L_ and all(a[2] == b[1] for a, b in zip(hp[:-1], hp[1:]))
+            for cl, f0, f1 in hp:
+                assert f1 - f0 >= T or len(hp) == 1
+                assert all(f0 <= e - 1 < f1 and s >= f0 - (T - 1) for s, e, _ in cl)
