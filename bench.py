@@ -1,6 +1,6 @@
 """Benchmark of the MDQE eval-only hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks as a child `torch.distributed.run`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -169,40 +169,106 @@ def calibrate_synthetic_scores(model, sd, cfg, fh, fw):
     return delta
 
 
+def host_cpu():
+    """(model string, physical cores, logical CPUs this process may use) from /proc/cpuinfo: SURVEY.md §8(d) asks for the CPU
+    baseline's core count and model.  Physical = distinct (physical id, core id) pairs; falls back to the logical count."""
+    model, cores, phys, core = "unknown", set(), None, None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_phys = min(len(cores), logical) if cores else logical
+    return model, max(1, n_phys), logical
+
+
 def cpu_baseline(cfg, sd, frames4):
     """Oracle (CPU restatement) on BASELINE.json configs[0]: ONE video of 4 synthetic 360p frames through the driver in the
     reference's own schedule -- clips (0,4) and (1,4); the per-frame stages (backbone + encoder + mask head) are re-run on the
     remaining window for every clip (`window_end_idx` never advances, mdqe/mdqe.py:302,314).  The four parts are timed
     separately, so the compute-once schedule (the second clip reuses the first clip's frame features) is the same run minus
-    the recompute.  `value` = compute-once."""
+    the recompute.  `value` = compute-once, at the better of {physical cores, physical cores / 2} torch threads (more threads
+    than physical cores oversubscribe the oracle's GEMMs and would handicap the baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mdqe_oracle as O
     hp = O.Hyper()
     bb = lambda im: O.resnet(sd, "detr.backbone.0.backbone", im, 50)
     frames = list(frames4)
-    t = []
-    with torch.no_grad():
-        video = O.preprocess(hp, frames)
-        t0 = time.time()
-        x, sizes = O.pad_frames(video, 32)
-        enc, mask, shapes, mf = O.frame_features(sd, hp, x, sizes, bb)                       # window of clip 0: frames 0..3
-        t.append(time.time() - t0); t0 = time.time()
-        O.inference_clip(hp, O.transformer_dec(sd, hp, enc, mask, shapes), mf)
-        t.append(time.time() - t0); t0 = time.time()
-        x1, sizes1 = O.pad_frames(video[1:], 32)
-        enc1, mask1, shapes1, mf1 = O.frame_features(sd, hp, x1, sizes1, bb)                 # as-reference: window of clip 1 again
-        t.append(time.time() - t0); t0 = time.time()
-        O.inference_clip(hp, O.transformer_dec(sd, hp, enc1, mask1, shapes1), mf1)
-        t.append(time.time() - t0)
-    once, asref = t[0] + t[1] + t[3], sum(t)
-    return {"value": 4.0 / once, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    model_name, n_phys, n_logical = host_cpu()
+    before = torch.get_num_threads()
+
+    def once(n, with_recompute):
+        torch.set_num_threads(n)
+        t = []
+        with torch.no_grad():
+            video = O.preprocess(hp, frames)
+            t0 = time.time()
+            x, sizes = O.pad_frames(video, 32)
+            enc, mask, shapes, mf = O.frame_features(sd, hp, x, sizes, bb)                   # window of clip 0: frames 0..3
+            t.append(time.time() - t0); t0 = time.time()
+            O.inference_clip(hp, O.transformer_dec(sd, hp, enc, mask, shapes), mf)
+            t.append(time.time() - t0); t0 = time.time()
+            x1, sizes1 = O.pad_frames(video[1:], 32)
+            if with_recompute:
+                enc1, mask1, shapes1, mf1 = O.frame_features(sd, hp, x1, sizes1, bb)         # as-reference: window of clip 1 again
+            else:
+                enc1, mask1, shapes1, mf1 = enc[1:], mask[1:], shapes, mf[1:]
+            t.append(time.time() - t0 if with_recompute else None); t0 = time.time()
+            O.inference_clip(hp, O.transformer_dec(sd, hp, enc1, mask1, shapes1), mf1)
+            t.append(time.time() - t0)
+        return t
+
+    runs = {n_phys: once(n_phys, True)}
+    if n_phys >= 2:
+        runs[n_phys // 2] = once(n_phys // 2, False)
+    torch.set_num_threads(before)
+    tot = {n: t[0] + t[1] + t[3] for n, t in runs.items()}
+    best = min(tot, key=tot.get)
+    t = runs[best]
+    tr = runs[n_phys]
+    asref = tr[0] + tr[1] + tr[2] + tr[3]
+    return {"value": 4.0 / tot[best], "unit": "frames/s", "cores": best, "kind": "port",
+            "cpu_model": model_name, "physical_cores": n_phys, "logical_cpus": n_logical,
+            "threads_tried": {str(n): round(4.0 / v, 4) for n, v in sorted(tot.items())},
             "sample": "oracle/mdqe_oracle.py on configs[0]: one video of 4 synthetic 360x640 frames = clips (0,4) and (1,4); "
-                      "compute-once schedule: per-frame stages x4 frames (%.1f s) + 2 decoder/inference_clip passes (%.1f + %.1f s)"
-                      % (t[0], t[1], t[3]),
-            "as_reference": {"value": 4.0 / asref, "unit": "frames/s",
+                      "compute-once schedule on %d torch threads (%s, %d physical cores): per-frame stages x4 frames (%.1f s) + 2 decoder/"
+                      "inference_clip passes (%.1f + %.1f s)" % (best, model_name, n_phys, t[0], t[1], t[3]),
+            "as_reference": {"value": 4.0 / asref, "unit": "frames/s", "cores": n_phys,
                              "what": "the same video in the reference's schedule: the window's per-frame stages are recomputed for the "
                                      "second clip (+3 frames, %.1f s); on the bench's 120-frame video that schedule runs 3540 frame "
-                                     "passes instead of 120" % t[2]}}
+                                     "passes instead of 120" % tr[2]}}
+
+
+def spawn_ranks(n, rehearsal):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same args>` as a child and return its
+    exit code.  Called before this process has made any GPU call.  Without a rehearsal hook the box must show n GPUs."""
+    import socket
+    import subprocess
+    if not rehearsal and torch.cuda.device_count() < n:
+        print("bench.py: --gpus %d but only %d GPU(s) visible (MDQE_BENCH_BACKEND=gloo MDQE_BENCH_ONE_DEVICE=1 rehearses %d ranks on one)"
+              % (n, torch.cuda.device_count(), n), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -237,30 +303,63 @@ def main():
                     help="R50_ovis_360 is BASELINE.json's metric config; R50_ovis_720 = 640x1138 frames (configs[2]); "
                          "swinl_ovis = SwinV2-L, 480x853 frames, 2-frame clips (configs[3])")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # test hooks (1-GPU box): MDQE_BENCH_BACKEND=gloo + MDQE_BENCH_ONE_DEVICE=1 run all ranks on cuda:0 without RCCL;
+    # MDQE_BENCH_RANK_PROBE=1 (no GPU needed): ranks rendezvous, count each other and rank 0 prints the count -- the launch logic alone
+    one_dev = os.environ.get("MDQE_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("MDQE_BENCH_BACKEND", "nccl")
+    probe = os.environ.get("MDQE_BENCH_RANK_PROBE") == "1"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` starts its own N ranks, as the reference's CLI does from --num-gpus (train_net.py:264-271,
+        # detectron2 `launch`).  Nothing in THIS process has touched the GPU (device_count() does not initialise HIP on this image):
+        # the ranks are a CHILD process tree (torch.distributed.run), whose stdout/stderr are this process's and whose exit code
+        # is passed on.
+        sys.exit(spawn_ranks(args.gpus, one_dev or probe))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hooks (1-GPU box): MDQE_BENCH_BACKEND=gloo + MDQE_BENCH_ONE_DEVICE=1 run all ranks on cuda:0 without RCCL
-    one_dev = os.environ.get("MDQE_BENCH_ONE_DEVICE") == "1"
-    backend = os.environ.get("MDQE_BENCH_BACKEND", "nccl")
+    if world != args.gpus:
+        # (a wrapper that started a different number of ranks than --gpus says would otherwise print a line for the wrong N)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to run" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # MDQE_BENCH_FORCE_SHARDED=1: take the N > 1 path (chunks, per-round gather, replay thread) with whatever world size there is --
     # on a 1-GPU box that runs the sharded schedule through a ONE-rank RCCL communicator (the only RCCL execution a single GPU allows)
     sharded = world > 1 or os.environ.get("MDQE_BENCH_FORCE_SHARDED") == "1"
     if one_dev:
         local = 0
-    torch.cuda.set_device(local)
+    if not probe:
+        if not one_dev and world > 1 and torch.cuda.device_count() < world:
+            print("bench.py: --gpus %d but only %d visible" % (world, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local)
     dist = None
+    ranks_seen = 1
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
+        if backend == "nccl" and not probe:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo" if probe else backend)
+        # every rank adds a 1: the communicator really spans --gpus processes
+        one = torch.ones(1, dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            print("bench.py: rank %d counted %d ranks in a world of %d, --gpus %d" % (rank, ranks_seen, dist.get_world_size(), args.gpus), file=sys.stderr)
+            sys.exit(2)
+        if probe:
+            if rank == 0:
+                print(json.dumps({"probe": True, "n_gpus": world, "ranks_seen": ranks_seen, "backend": dist.get_backend()}))
+            dist.destroy_process_group()
+            return
 
     from mdqe_cvpr2023_amd import _lib
     _lib.load_library()                                   # loud if the HIP library is missing
@@ -415,7 +514,8 @@ def main():
                        "merge_on_cpu": bool(cfg.merge_on_cpu) if not sharded else True,     # (sharded videos stream their windows out: sharding._Job)
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
-                       "parallelism": ("1 process/GPU; %s-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
+                       "ranks_seen": ranks_seen, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
+                       "parallelism": ("%d ranks counted by all-reduce; 1 process/GPU;" % ranks_seen + " %s-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
                                        "clip results to rank 0, whose native tracker replay runs on a worker thread under the next round"
                                        % ("/".join(str(c) for c in chunk) + " (one size per round)" if isinstance(chunk, list) else str(chunk),
                                           "halo exchange (T-1 frames of encoder tokens + mask features by send/recv)" if args.halo_exchange

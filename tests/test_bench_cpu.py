@@ -39,3 +39,41 @@ def test_bench_shards_reassemble_the_video():
                 if world == 3:
                     seen.update(c[0] for c in clips)
     assert seen == {c[0] for c in __import__("mdqe_cvpr2023_amd.meta_arch", fromlist=["MDQE"]).MDQE.clip_schedule(L, T, stride)}
+
+
+def _bench(args, env_extra, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun around it) must run TWO ranks: the launcher spawns them as a child process tree before any
+    GPU call, the ranks count each other by all-reduce and rank 0 reports the count (MDQE_BENCH_RANK_PROBE=1 stops there: no GPU here).
+    Reference: train_net.py:264-271 (`launch(main, args.num_gpus, ...)`)."""
+    import json
+    for n in (2, 3):
+        r = _bench(["--gpus", str(n)], {"MDQE_BENCH_RANK_PROBE": "1"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["ranks_seen"] == n
+
+
+def test_bench_never_reports_the_wrong_world():
+    """Loud failures instead of a line for the wrong N: fewer visible GPUs than --gpus (no rehearsal hook), and a wrapper whose world
+    size differs from --gpus."""
+    r = _bench(["--gpus", "2"], {})
+    assert r.returncode != 0 and "{" not in r.stdout and "visible" in r.stderr
+    r = _bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "MDQE_BENCH_RANK_PROBE": "1"})
+    assert r.returncode != 0 and "{" not in r.stdout and "refusing" in r.stderr
+    r = _bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "MDQE_BENCH_RANK_PROBE": "1"})
+    assert r.returncode != 0 and "{" not in r.stdout
+
+
+def test_host_cpu_reports_model_and_physical_cores():
+    from bench import host_cpu
+    model, phys, logical = host_cpu()
+    assert isinstance(model, str) and model and 1 <= phys <= logical

@@ -28,3 +28,23 @@ def test_bench_line_contract():
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["traffic"] is None
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] < 1.0 and rf["peak"] == 157.3
     assert d["config"]["clips_per_step"] == 24 - 2 and d["config"]["instances_out"] >= 1
+
+
+def test_bench_gpus_2_runs_two_ranks_without_torchrun():
+    """`python bench.py --gpus 2` spawns its own ranks (rehearsal hooks: both on this box's one GPU, gloo instead of RCCL) and prints a
+    line for TWO ranks; without the hooks on a 1-GPU box it fails loudly instead of printing `n_gpus: 1`."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "24", "--no-cpu-baseline", "--no-fast-mode"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+        env.update(MDQE_BENCH_BACKEND="gloo", MDQE_BENCH_ONE_DEVICE="1")
+    r = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["frames_per_gpu"] == 24 and d["scaling"] == "weak"
+    assert abs(d["value"] - 48 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]              # whole-job frames / max-over-ranks time
+    assert d["config"]["instances_out"] >= 1
