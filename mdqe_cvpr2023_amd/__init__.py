@@ -9,11 +9,11 @@ from .d2_compat import add_mdqe_config, add_swinl_config, add_swinb_config, add_
 
 
 def __getattr__(name):                 # `from mdqe_cvpr2023_amd import MDQE` without importing torch.nn at package import
-    if name == "MDQE":
-        from .meta_arch import MDQE
-        return MDQE
+    if name in ("MDQE", "MDQE_MI355X", "register_with_detectron2"):
+        from . import meta_arch
+        return getattr(meta_arch, name)
     raise AttributeError(name)
 
 
-__all__ = ["lib", "load_library", "LibraryMissing", "MDQE", "add_mdqe_config", "add_swinl_config", "add_swinb_config",
+__all__ = ["lib", "load_library", "LibraryMissing", "MDQE", "MDQE_MI355X", "register_with_detectron2", "add_mdqe_config", "add_swinl_config", "add_swinb_config",
            "add_swins_config", "add_swint_config"]

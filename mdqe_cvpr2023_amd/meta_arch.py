@@ -7,8 +7,9 @@ eval-only VIS path.
     # -> {"image_size", "pred_scores", "pred_labels", "pred_masks": [BoolTensor[L,H,W] (CPU)]}
 
 Same call contract and output dict as MDQE.forward -> inference_vis -> inference_video.  When
-detectron2 is importable the class is registered in its META_ARCH_REGISTRY under the name "MDQE".
-Training and the COCO single-image branch are out of scope and raise.
+detectron2 is importable the class is registered in its META_ARCH_REGISTRY under the names "MDQE" (taking the slot over from the
+reference's model if `mdqe` was imported first) and "MDQE_MI355X" -- `register_with_detectron2` at the end of this file.
+COCO image sets (`DATASETS.TEST[0]` = coco*) take the single-image branch (`inference_image`); training is out of scope and raises.
 """
 import contextlib
 import os
@@ -847,8 +848,77 @@ class ClipMerger:
                                           emit_masks=self.emit_masks)
 
 
-try:                                              # drop-in registration when detectron2 is present
-    from detectron2.modeling import META_ARCH_REGISTRY
-    META_ARCH_REGISTRY.register(MDQE)
-except Exception:                                 # detectron2 absent in this image: d2-free entry only
-    pass
+class MDQE_MI355X(MDQE):
+    """The same model under a name of its own: `MODEL.META_ARCHITECTURE MDQE_MI355X` on the reference's command line selects this
+    implementation whatever else is registered as "MDQE"."""
+
+
+_REGISTRATION = {"state": "detectron2 not imported"}
+
+
+def register_with_detectron2(registry=None, takeover=None):
+    """Put this implementation into detectron2's `META_ARCH_REGISTRY` BESIDE the reference's `mdqe` package.
+
+    The reference registers its own torch model under the name "MDQE" the moment `mdqe` is imported (`mdqe/__init__.py:3` ->
+    `@META_ARCH_REGISTRY.register()` at `mdqe/mdqe.py:60-61`), and `train_net.py:39` / `demo/demo.py:16` import `mdqe` for
+    `add_mdqe_config` and the data loaders; fvcore's `Registry` asserts on a second registration of a name.  So:
+
+    * the alias `MDQE_MI355X` is always registered (no collision possible);
+    * the name "MDQE" -- what every config of the reference selects (`configs/*.yaml: META_ARCHITECTURE: "MDQE"`) -- is TAKEN OVER
+      (`takeover=True`, the default; `MDQE_MI355X_REGISTER=alias` in the environment turns it off): a reference model registered earlier
+      is moved to "MDQE_REFERENCE" and this class takes its slot, with a warning in the log; a registration of another "MDQE" that
+      comes LATER (this package imported before the reference's) is diverted to "MDQE_REFERENCE" instead of tripping fvcore's
+      assertion.  Both import orders end with `build_model(cfg)` constructing this class and the reference's model still selectable.
+
+    Returns a dict describing what was done (also kept in `registration_state()`); raises anything but a missing detectron2."""
+    import logging
+    log = logging.getLogger("mdqe_cvpr2023_amd")
+    if registry is None:
+        try:
+            from detectron2.modeling import META_ARCH_REGISTRY as registry
+        except ModuleNotFoundError as e:          # detectron2 absent in this image: the d2-free entry points are all there is
+            if (e.name or "").split(".")[0] != "detectron2":
+                raise                             # (a detectron2 that is there but broken is not "absent")
+            _REGISTRATION.update(state="detectron2 not importable")
+            return dict(_REGISTRATION)
+    if takeover is None:
+        takeover = os.environ.get("MDQE_MI355X_REGISTER", "replace") != "alias"
+    objs = registry._obj_map
+    if objs.get("MDQE_MI355X") is not MDQE_MI355X:
+        registry.register(MDQE_MI355X)            # (a foreign class of that name would assert here, as it should)
+    done = {"state": "alias only", "alias": "MDQE_MI355X", "MDQE": None, "MDQE_REFERENCE": None}
+    if takeover:
+        prev = objs.get("MDQE")
+        if prev is None:
+            registry.register(MDQE)
+        elif prev is not MDQE:
+            objs["MDQE_REFERENCE"] = prev
+            objs["MDQE"] = MDQE
+            log.warning("META_ARCH_REGISTRY['MDQE'] now builds mdqe_cvpr2023_amd.meta_arch.MDQE (MI355X); the class registered before "
+                        "(%s.%s) stays selectable as 'MDQE_REFERENCE'", getattr(prev, "__module__", "?"), getattr(prev, "__qualname__", "?"))
+        if not getattr(registry, "_mdqe_mi355x_guard", False):
+            inner = registry._do_register
+
+            def _do_register(name, obj, _inner=inner, _objs=objs):
+                if name == "MDQE" and _objs.get("MDQE") is MDQE and obj is not MDQE:
+                    _objs["MDQE_REFERENCE"] = obj
+                    log.warning("a second 'MDQE' (%s.%s) was registered after mdqe_cvpr2023_amd's: kept as 'MDQE_REFERENCE'; "
+                                "'MDQE' keeps building the MI355X implementation", getattr(obj, "__module__", "?"), getattr(obj, "__qualname__", "?"))
+                    return
+                _inner(name, obj)
+            registry._do_register = _do_register
+            registry._mdqe_mi355x_guard = True
+        done.update(state="MDQE taken over", MDQE="mdqe_cvpr2023_amd.meta_arch.MDQE")
+    ref = objs.get("MDQE_REFERENCE")
+    done["MDQE_REFERENCE"] = None if ref is None else "%s.%s" % (getattr(ref, "__module__", "?"), getattr(ref, "__qualname__", "?"))
+    _REGISTRATION.clear()
+    _REGISTRATION.update(done)
+    return dict(done)
+
+
+def registration_state():
+    """What `register_with_detectron2` did at import (for logs and tests)."""
+    return dict(_REGISTRATION)
+
+
+register_with_detectron2()                        # loud on anything but a missing detectron2

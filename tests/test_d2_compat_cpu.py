@@ -16,14 +16,24 @@ SCRIPT = textwrap.dedent('''
             try: return self[k]
             except KeyError: raise AttributeError(k)
         def __setattr__(self, k, v): self[k] = v
-    class Registry(dict):
+    class Registry:                                   # the contract of fvcore.common.registry.Registry (asserts on duplicates)
+        def __init__(self, name): self._name, self._obj_map = name, {}
+        def _do_register(self, name, obj):
+            assert name not in self._obj_map, "An object named '%s' was already registered in '%s' registry!" % (name, self._name)
+            self._obj_map[name] = obj
         def register(self, obj=None):
-            self[obj.__name__] = obj
-            return obj
-        def get(self, name): return self[name]
+            if obj is None:
+                def deco(o):
+                    self._do_register(o.__name__, o); return o
+                return deco
+            self._do_register(obj.__name__, obj)
+        def get(self, name):
+            ret = self._obj_map.get(name)
+            if ret is None: raise KeyError(name)
+            return ret
     d2 = types.ModuleType("detectron2"); d2.__path__ = []
     cfgm = types.ModuleType("detectron2.config"); cfgm.CfgNode = CN
-    mod = types.ModuleType("detectron2.modeling"); mod.META_ARCH_REGISTRY = Registry()
+    mod = types.ModuleType("detectron2.modeling"); mod.META_ARCH_REGISTRY = Registry("META_ARCH")
     sys.modules.update({"detectron2": d2, "detectron2.config": cfgm, "detectron2.modeling": mod})
 
     from mdqe_cvpr2023_amd import add_mdqe_config, add_swinl_config, MDQE
@@ -75,3 +85,144 @@ def test_d2_registration_and_config_functions_execute():
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and "D2_COMPAT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- coexistence with the reference's own `mdqe` package ---------------------------------------------------------
+# fvcore's Registry refuses a second registration of a name (`assert name not in self._obj_map`); the reference registers ITS model as
+# "MDQE" when `mdqe` is imported (mdqe/__init__.py:3, mdqe/mdqe.py:60-61) and train_net.py:39 / demo/demo.py:16 import `mdqe`.  The
+# stand-ins below keep exactly those two behaviours: a registry that asserts on duplicates, and an `mdqe` package whose import registers
+# a class named MDQE.  Both import orders must end with `build_model(cfg)` constructing THIS package's class.
+COEXIST = textwrap.dedent('''
+    import sys, types, logging
+    ORDER = sys.argv[1]
+    class CN(dict):
+        def __getattr__(self, k):
+            try: return self[k]
+            except KeyError: raise AttributeError(k)
+        def __setattr__(self, k, v): self[k] = v
+    class Registry:                                   # the contract of fvcore.common.registry.Registry
+        def __init__(self, name): self._name, self._obj_map = name, {}
+        def _do_register(self, name, obj):
+            assert name not in self._obj_map, "An object named '%s' was already registered in '%s' registry!" % (name, self._name)
+            self._obj_map[name] = obj
+        def register(self, obj=None):
+            if obj is None:
+                def deco(o):
+                    self._do_register(o.__name__, o); return o
+                return deco
+            self._do_register(obj.__name__, obj)
+        def get(self, name):
+            ret = self._obj_map.get(name)
+            if ret is None: raise KeyError("No object named '%s' found in '%s' registry!" % (name, self._name))
+            return ret
+    REG = Registry("META_ARCH")
+    d2 = types.ModuleType("detectron2"); d2.__path__ = []
+    cfgm = types.ModuleType("detectron2.config"); cfgm.CfgNode = CN
+    mod = types.ModuleType("detectron2.modeling"); mod.META_ARCH_REGISTRY = REG
+    def build_model(cfg):                             # detectron2/modeling/meta_arch/build.py: registry lookup by cfg.MODEL.META_ARCHITECTURE
+        return REG.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    mod.build_model = build_model
+    sys.modules.update({"detectron2": d2, "detectron2.config": cfgm, "detectron2.modeling": mod})
+
+    def import_reference():                           # what `from mdqe import add_mdqe_config, ...` triggers (train_net.py:39)
+        ref = types.ModuleType("mdqe"); ref.__path__ = []
+        sub = types.ModuleType("mdqe.mdqe")
+        @REG.register()
+        class MDQE:                                   # the reference's torch model
+            __module__ = "mdqe.mdqe"
+            def __init__(self, cfg): self.which = "reference"
+        sub.MDQE = MDQE; ref.MDQE = MDQE
+        sys.modules.update({"mdqe": ref, "mdqe.mdqe": sub})
+        return MDQE
+
+    records = []
+    class H(logging.Handler):
+        def emit(self, r): records.append(r.getMessage())
+    logging.getLogger("mdqe_cvpr2023_amd").addHandler(H())
+
+    if ORDER == "reference_first":
+        RefMDQE = import_reference()
+        import mdqe_cvpr2023_amd.meta_arch as ours
+    elif ORDER == "ours_first":
+        import mdqe_cvpr2023_amd.meta_arch as ours
+        RefMDQE = import_reference()                  # would trip fvcore's assertion without the guard
+    else:                                             # MDQE_MI355X_REGISTER=alias: the reference keeps its name
+        RefMDQE = import_reference()
+        import mdqe_cvpr2023_amd.meta_arch as ours
+
+    from mdqe_cvpr2023_amd import add_mdqe_config
+    def cfg_for(arch):
+        c = CN(); c.MODEL = CN(); c.INPUT = CN(); c.SOLVER = CN(); c.DATASETS = CN(); c.TEST = CN()
+        c.MODEL.BACKBONE = CN(); c.MODEL.FPN = CN(); c.MODEL.RESNETS = CN()
+        c.MODEL.DEVICE = "cuda"; c.MODEL.PIXEL_MEAN = [123.675, 116.280, 103.530]; c.MODEL.PIXEL_STD = [58.395, 57.120, 57.375]
+        c.MODEL.BACKBONE.NAME = "build_resnet_backbone"; c.MODEL.RESNETS.DEPTH = 50
+        c.INPUT.MIN_SIZE_TEST = 360; c.INPUT.MAX_SIZE_TEST = 1333; c.TEST.DETECTIONS_PER_IMAGE = 15
+        c.DATASETS.TEST = ("ytvis_ovis_val",)
+        add_mdqe_config(c)
+        c.MODEL.META_ARCHITECTURE = arch
+        return c
+
+    st = ours.registration_state()
+    if ORDER == "alias_only":
+        assert st["state"] == "alias only", st
+        assert type(build_model(cfg_for("MDQE"))) is RefMDQE               # untouched
+        assert type(build_model(cfg_for("MDQE_MI355X"))) is ours.MDQE_MI355X
+        assert "MDQE_REFERENCE" not in REG._obj_map
+    else:
+        m = build_model(cfg_for("MDQE"))              # every config of the reference says META_ARCHITECTURE: "MDQE"
+        assert type(m) is ours.MDQE, type(m)
+        assert any(n.startswith("detr.transformer_dec.") for n, _ in m.named_parameters())
+        assert type(build_model(cfg_for("MDQE_MI355X"))) is ours.MDQE_MI355X and isinstance(build_model(cfg_for("MDQE_MI355X")), ours.MDQE)
+        assert build_model(cfg_for("MDQE_REFERENCE")).which == "reference"  # the reference's model stays selectable
+        assert REG.get("MDQE_REFERENCE") is RefMDQE
+        assert any("MDQE_REFERENCE" in r for r in records), records          # the take-over is logged, never silent
+        ours.register_with_detectron2()                                     # idempotent
+        assert REG.get("MDQE") is ours.MDQE and REG.get("MDQE_REFERENCE") is RefMDQE
+        # the registry still refuses every OTHER duplicate
+        try:
+            REG.register(ours.MDQE_MI355X); raise SystemExit("duplicate alias accepted")
+        except AssertionError:
+            pass
+    print("COEXIST_OK", ORDER)
+''')
+
+
+def _coexist(order, env_extra=None):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("MDQE_MI355X_REGISTER", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, "-c", COEXIST, order], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and "COEXIST_OK " + order in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_coexists_with_reference_package_imported_first():
+    _coexist("reference_first")
+
+
+def test_coexists_with_reference_package_imported_after():
+    _coexist("ours_first")
+
+
+def test_alias_only_registration_leaves_the_reference_in_place():
+    _coexist("alias_only", {"MDQE_MI355X_REGISTER": "alias"})
+
+
+def test_a_broken_detectron2_is_not_swallowed():
+    """Only a MISSING detectron2 is tolerated at import; anything else propagates (round 2 swallowed every exception here)."""
+    script = textwrap.dedent('''
+        import sys, types
+        d2 = types.ModuleType("detectron2"); d2.__path__ = []
+        mod = types.ModuleType("detectron2.modeling")
+        class Bad:
+            _obj_map = {}
+            def register(self, obj=None): raise RuntimeError("registry is broken")
+        mod.META_ARCH_REGISTRY = Bad()
+        sys.modules.update({"detectron2": d2, "detectron2.modeling": mod})
+        try:
+            import mdqe_cvpr2023_amd.meta_arch
+        except RuntimeError as e:
+            assert "broken" in str(e); print("LOUD_OK")
+    ''')
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and "LOUD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
