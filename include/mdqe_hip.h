@@ -28,6 +28,7 @@ extern "C" {
 #define MDQE_EINVAL 1   /* bad size / unsupported shape */
 #define MDQE_ELAUNCH 2  /* hipGetLastError() != hipSuccess after launch */
 #define MDQE_ENULL 3    /* null pointer */
+#define MDQE_ESTATE 4   /* the object was left inconsistent by an earlier failed call (tracker: a device error in the middle of an update) and refuses further use */
 
 /* activation codes for fused epilogues */
 #define MDQE_ACT_NONE 0

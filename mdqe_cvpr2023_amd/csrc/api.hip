@@ -6,6 +6,7 @@ extern "C" const char* mdqe_strerror(int code) {
     case MDQE_EINVAL: return "invalid size or unsupported shape";
     case MDQE_ELAUNCH: return "kernel launch failed";
     case MDQE_ENULL: return "null pointer argument";
+    case MDQE_ESTATE: return "object left inconsistent by an earlier failed call; create a new one";
     default: return "unknown error";
   }
 }

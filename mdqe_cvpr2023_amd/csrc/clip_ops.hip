@@ -36,19 +36,40 @@ clip_assoc_kernel(const float* __restrict__ emb, const int* __restrict__ fidx, i
   }
   const float w = wdw * (float)abs(t - ct);
   const int ki = k / nb, kj = k % nb;
-  float best = -INFINITY;
-  int bi = 0;
-  bool have = false;
-  for (int q = 0; q < Q; ++q) {
-    const int qi = q / nb, qj = q % nb;
-    if ((float)abs(qi - ki) > w || (float)abs(qj - kj) > w) continue;
+  // The reference takes `masked_fill(-inf).softmax(-2).argmax(-2)` (transformer_dec.py:142-143): the FIRST index whose fp32
+  // softmax value equals the column's largest.  exp(s - max) rounds to 1.0f for every s with s - max > -2^-25, so a cell whose
+  // similarity is within half an ulp of 1 below the maximum ties with it and an earlier index wins.  Pass 1 finds the maximum
+  // (first index among exact ties) and the largest value strictly below it; only when that runner-up is inside the tie band --
+  // possible only for |max| < 0.5, where fp32 similarities are spaced more finely than 2^-25 -- a second pass looks for the first
+  // index in the band.  What stays open: the summation order of the 64-term dot product (torch's GEMM vs this loop) moves s by
+  // an ulp or two, so a near-tie of that size can still resolve differently; a NaN similarity makes the reference's whole column
+  // NaN (argmax -> index 0) while this loop keeps the first admissible cell.  tools/fuzz_inference_clip.py bounds how often.
+  constexpr float TIE = -2.98023223876953125e-8f;                       // -2^-25
+  auto sim = [&](int q) {
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < E; e += 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(sE + q * E + e);
       s += v[0] * c[e]; s += v[1] * c[e + 1]; s += v[2] * c[e + 2]; s += v[3] * c[e + 3];
     }
-    if (!have || s > best) { best = s; bi = q; have = true; }
+    return s;
+  };
+  float best = -INFINITY, second = -INFINITY;
+  int bi = 0;
+  bool have = false;
+  for (int q = 0; q < Q; ++q) {
+    const int qi = q / nb, qj = q % nb;
+    if ((float)abs(qi - ki) > w || (float)abs(qj - kj) > w) continue;
+    const float s = sim(q);
+    if (!have || s > best) { if (have) second = best; best = s; bi = q; have = true; }
+    else if (s < best && s > second) second = s;
+  }
+  if (have && second - best > TIE) {
+    for (int q = 0; q < bi; ++q) {                                      // rare: an earlier cell inside the tie band wins
+      const int qi = q / nb, qj = q % nb;
+      if ((float)abs(qi - ki) > w || (float)abs(qj - kj) > w) continue;
+      if (sim(q) - best > TIE) { bi = q; break; }
+    }
   }
   idx[((long)b * T + t) * Q + k] = bi;
 }

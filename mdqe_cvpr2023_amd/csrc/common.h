@@ -14,6 +14,24 @@ static inline int mdqe_launch_status() {
   return hipGetLastError() == hipSuccess ? MDQE_OK : MDQE_ELAUNCH;
 }
 
+// Dynamic LDS beyond 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize on EVERY kernel function that asks for it; the
+// attribute is per function, so the "already done" record is keyed by the function pointer (template instantiations of one
+// kernel share a pointer TYPE, not a pointer) and guarded: entry points are called from several host threads.
+#include <mutex>
+static inline hipError_t mdqe_allow_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static const void* fn[64];
+  static int cap[64];
+  static int n = 0;
+  std::lock_guard<std::mutex> g(mu);
+  int i = 0;
+  for (; i < n; ++i) if (fn[i] == kern) break;
+  if (i < n && cap[i] >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && i < 64) { fn[i] = kern; cap[i] = bytes; if (i == n) ++n; }
+  return e;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

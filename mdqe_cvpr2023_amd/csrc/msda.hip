@@ -360,9 +360,7 @@ extern "C" int mdqe_msda_forward_grouped_f32(const float* value, const int64_t* 
       const int chunk = staged < 45 * 1024 ? 128 : staged < 80 * 1024 ? 256 : 512;      // as msda_fused_v3 (measured there)
       const int nchunk = (Q + chunk - 1) / chunk;
       auto kern = msda_fwd_v3_kernel<4, 4, 1024>;
-      static bool attr_set = false;
-      if (!attr_set)
-        attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+      if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) return MDQE_ELAUNCH;
       hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * M * nchunk)), dim3(1024), (size_t)(staged + desc), st, value, (unsigned)vbytes, shapes,
                          level_start, loc, attn, B, S, M, Q, (int)budget, chunk, nchunk, scale, out);
       return mdqe_launch_status();

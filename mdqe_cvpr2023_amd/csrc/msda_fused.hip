@@ -478,11 +478,8 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         const int nchunk = (Q + chunk - 1) / chunk;
         const long nb3 = (long)B * M * nchunk;
         auto launch3 = [&](auto kern) {
-          static bool attr_set = false;                                       // (one static per instantiation of this lambda body)
-          if (!attr_set) {
-            attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024 - 256) == hipSuccess;   // (a failure shows as a launch error below)
-          }
+          // per kernel FUNCTION (the six instantiations share this lambda's one operator()): keyed by pointer in mdqe_allow_lds
+          if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) return;   // (shows as a launch error below)
           hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
                              ref, ref_bstride, ref_dim, mode, grid, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
         };

@@ -161,7 +161,12 @@ struct Tracker {
   }
 
   // frames of the clip [f0, f0+nf_clip) already saved in this window: bank frame s0, clip frame a, count
+  // set when a call failed AFTER part of its work reached the device bank (a kernel / copy error in the middle of an update or
+  // of a run of clips): host and device halves may disagree from then on, so every later call is refused (MDQE_ESTATE).
+  bool poisoned = false;
+
   int overlap(int f0, int nf_clip, int* s0, int* a, int* nf) const {
+    if (poisoned) return MDQE_ESTATE;
     int first = -1, lastf = -1, count = 0;
     for (int o = 0; o < nf_clip; ++o) {
       const int f = f0 + o;
@@ -181,12 +186,20 @@ struct Tracker {
   int decide(int f0, int nf_clip, int n_in, const float* scores, const float* cls_probs, const float* emb,
              const float* counts3, int have_counts, int* s0_out, int* a_out, int* nf_out) {
     r_idx.clear(); c_idx.clear();
+    // everything that can refuse the clip is checked BEFORE any state changes (the object is reused after an error)
+    if (poisoned) return MDQE_ESTATE;
+    if (num_clip >= num_clips) return MDQE_EINVAL;
+    const int s0 = std::max(f0 - start_frame, 0);
+    const int s1 = f0 + nf_clip - 1 - start_frame;
+    if (s1 >= mem_len || s1 < s0) return MDQE_EINVAL;
     std::vector<float> siou, sm;
     int ni = 0;
+    int n_first = 0;                                  // rows created by the very first clip (all of its instances)
     std::vector<char> matched(n_in, 0);
     if (num_inst == 0) {
+      if (n_in > max_inst) return MDQE_EINVAL;
       for (int i = 0; i < n_in; ++i) { r_idx.push_back(i); c_idx.push_back(i); matched[i] = 1; }
-      num_inst += n_in;
+      n_first = n_in;
     } else {
       ni = num_inst;
       std::vector<int> lo, sh;
@@ -246,13 +259,9 @@ struct Tracker {
       if (!rep && scores[i] > (float)(2.0 * (double)thr)) fresh.push_back(i);
     }
     const int n_new = (int)fresh.size();
+    if (num_inst + n_first + n_new > max_inst) { r_idx.clear(); c_idx.clear(); return MDQE_EINVAL; }   // (nothing committed yet)
     for (int k = 0; k < n_new; ++k) { r_idx.push_back(num_inst + k); c_idx.push_back(fresh[k]); }
-    // _update_memory (:65-90)
-    if (num_clip >= num_clips) return MDQE_EINVAL;
-    for (int r : r_idx) if (r >= max_inst) return MDQE_EINVAL;
-    const int s0 = std::max(f0 - start_frame, 0);
-    const int s1 = f0 + nf_clip - 1 - start_frame;
-    if (s1 >= mem_len || s1 < s0) return MDQE_EINVAL;
+    // _update_memory (:65-90) -- from here on the clip is committed
     const int a = start_frame + s0 - f0;
     *s0_out = s0; *a_out = a; *nf_out = s1 - s0 + 1;
     for (auto& x : untracked) x += 1.f;
@@ -284,12 +293,13 @@ struct Tracker {
     }
     for (int o = 0; o < nf_clip; ++o) saved_idx.insert(f0 + o);
     num_clip += 1;
-    num_inst += n_new;
+    num_inst += n_first + n_new;
     return MDQE_OK;
   }
 
   // OverTracker.get_result (:195-225), host part.  out_cls [n, K]; carry_valid [n, mem_len - win] (only when !is_last).
   int result(int is_last, float* out_cls, int* n_out, int* ln_out, unsigned char* carry_valid) {
+    if (poisoned) return MDQE_ESTATE;
     const int n = num_inst;
     if (saved_idx.empty()) return MDQE_EINVAL;
     const int nv = *saved_idx.rbegin() - start_frame + 1;
@@ -432,7 +442,7 @@ static int tracker_update_one(Tracker* t, float* bank_sum, float* bank_cnt, long
       const long bank_stride = (long)t->mem_len * hw;
       int rc2 = mdqe_trk_siou_f32(bank_sum + (long)s0 * hw, bank_stride, ni, masks + (long)a * hw, inst_stride, n_in, (long)nf * hw,
                                   counts_dev, st);
-      if (rc2 != MDQE_OK) return rc2;
+      if (rc2 != MDQE_OK) return rc2;                                    // (read-only so far: the tracker is still consistent)
       if (hipMemcpyAsync(counts_host, counts_dev, (size_t)ni * n_in * 3 * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess)
         return MDQE_ELAUNCH;
       if (hipStreamSynchronize(st) != hipSuccess) return MDQE_ELAUNCH;     // the one host sync of an update
@@ -440,10 +450,13 @@ static int tracker_update_one(Tracker* t, float* bank_sum, float* bank_cnt, long
     }
   }
   const int rc = t->decide(f0, n_frames, n_in, scores, cls_probs, embeds, c3, c3 != nullptr, &s0, &a, &nf);
-  if (rc != MDQE_OK) return rc;
-  if (!t->r_idx.empty())
-    return mdqe_trk_accumulate_f32(bank_sum + (long)s0 * hw, (long)t->mem_len * hw, bank_cnt + s0, t->mem_len, masks + (long)a * hw,
-                                   inst_stride, (long)nf * hw, nf, t->r_idx.data(), t->c_idx.data(), (int)t->r_idx.size(), st);
+  if (rc != MDQE_OK) return rc;                                          // (decide validates before it commits)
+  if (!t->r_idx.empty()) {
+    const int rc3 = mdqe_trk_accumulate_f32(bank_sum + (long)s0 * hw, (long)t->mem_len * hw, bank_cnt + s0, t->mem_len, masks + (long)a * hw,
+                                            inst_stride, (long)nf * hw, nf, t->r_idx.data(), t->c_idx.data(), (int)t->r_idx.size(), st);
+    if (rc3 != MDQE_OK) t->poisoned = true;                              // host half committed, device half not
+    return rc3;
+  }
   return MDQE_OK;
 }
 
@@ -469,13 +482,20 @@ extern "C" int mdqe_tracker_update_many(void* handle, float* bank_sum, float* ba
   if (n_clips == 0) return MDQE_OK;
   MDQE_CHECK_PTR(f0); MDQE_CHECK_PTR(n_frames); MDQE_CHECK_PTR(n_in); MDQE_CHECK_PTR(row0); MDQE_CHECK_PTR(masks); MDQE_CHECK_PTR(inst_stride);
   Tracker* t = static_cast<Tracker*>(handle);
+  if (t->poisoned) return MDQE_ESTATE;
+  for (int i = 0; i < n_clips; ++i) {                                   // argument checks for the WHOLE run before its first clip is committed
+    MDQE_REQUIRE(n_frames[i] > 0 && n_in[i] >= 0 && inst_stride[i] % 4 == 0 && row0[i] >= 0);
+    if (n_in[i] > 0) { MDQE_CHECK_PTR(scores); MDQE_CHECK_PTR(cls_probs); MDQE_CHECK_PTR(embeds); MDQE_CHECK_PTR(masks[i]); }
+  }
   for (int i = 0; i < n_clips; ++i) {
-    MDQE_REQUIRE(n_frames[i] > 0 && n_in[i] >= 0 && inst_stride[i] % 4 == 0);
     const long o = row0[i];
     const int rc = tracker_update_one(t, bank_sum, bank_cnt, hw, f0[i], n_frames[i], n_in[i], scores ? scores + o : nullptr,
                                       cls_probs ? cls_probs + o * t->K : nullptr, embeds ? embeds + o * t->E : nullptr, masks[i],
                                       inst_stride[i], counts_dev, counts_host, (hipStream_t)stream);
-    if (rc != MDQE_OK) return rc;
+    if (rc != MDQE_OK) {
+      if (i > 0) t->poisoned = true;                                    // earlier clips of the run are committed: the run is not atomic, so
+      return rc;                                                        // the object refuses further use instead of going on half-updated
+    }
   }
   return MDQE_OK;
 }
@@ -493,7 +513,7 @@ extern "C" int mdqe_tracker_get_result(void* handle, int is_last, float* bank_su
   const int rc = t->result(is_last, out_cls, n, ln, nullptr);
   if (rc != MDQE_OK) return rc;
   int rc2 = mdqe_trk_window_mean_f32(bank_sum, bank_cnt, hw, t->mem_len, *n, *ln, 0, out_masks, stream);
-  if (rc2 != MDQE_OK) return rc2;
-  if (!is_last) rc2 = mdqe_trk_carry_f32(bank_sum, bank_cnt, hw, t->mem_len, *n, t->mem_len - t->win, t->win, carry, stream);
+  if (rc2 == MDQE_OK && !is_last) rc2 = mdqe_trk_carry_f32(bank_sum, bank_cnt, hw, t->mem_len, *n, t->mem_len - t->win, t->win, carry, stream);
+  if (rc2 != MDQE_OK && !is_last) t->poisoned = true;                   // the host half has re-based its window, the device bank has not
   return rc2;
 }

@@ -331,7 +331,7 @@ class MDQE(nn.Module):
                 cb, on_frames_queued = on_frames_queued, None
                 cb()
 
-        tail_state = {"views": None, "ev": None}
+        tail_state = {"views": None, "ev": None, "consuming": False}
 
         def send_tail():
             """The grouped send/recv of the halo exchange, on the frame stream behind the chunk's last pass.  Never while the
@@ -340,6 +340,9 @@ class MDQE(nn.Module):
             a rank's operations in issue order, would deadlock against a rank that queued it after."""
             if halo is None or halo.tail_sent or tail_state["views"] is None:
                 return
+            if not tail_state["consuming"]:       # (guard for future edits: calling this from plan_next / prepare / the priming loop hangs ranks)
+                raise RuntimeError("halo exchange: send_tail() while the generator is being primed -- the grouped send/recv must be "
+                                   "issued between the gathers of two rounds on every rank")
             ctx = torch.cuda.stream(fstream) if cuda else contextlib.nullcontext()
             with ctx:
                 if cuda:
@@ -375,6 +378,7 @@ class MDQE(nn.Module):
             while len(states) < NR and plan_next():
                 pass
             yield None                            # per-frame work of the first passes is queued; the caller resumes later
+        tail_state["consuming"] = True            # from here on the caller has gathered the previous round: the exchange may be issued
         while states:
             # `lookahead` passes are queued BEFORE this group's clip work: with one, the frame stream ran dry at every group
             # boundary -- the clip kernels share the chip with the pass queued behind them and finish together with it, and

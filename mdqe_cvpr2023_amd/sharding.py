@@ -280,7 +280,14 @@ class _Halo:
         self.works = []
         if self.recv_buf is None:
             return None
-        return self.recv_buf.to(self.device, non_blocking=True) if self.host else self.recv_buf
+        if self.host:
+            return self.recv_buf.to(self.device, non_blocking=True)
+        # the buffer was allocated under the FRAME stream (on_tail) and is read on the caller's stream: tell the caching allocator,
+        # or the block could be handed to a later frame-stream allocation while the reader's kernels are still queued
+        self.recv_buf.record_stream(torch.cuda.current_stream(self.recv_buf.device))
+        if self.send_buf is not None and self.send_buf.is_cuda:
+            self.send_buf.record_stream(torch.cuda.current_stream(self.send_buf.device))
+        return self.recv_buf
 
     def head(self):
         """(encoder tokens [T-1, N, C], mask features [T-1, Hm, Wm, M]) of the T-1 frames before this chunk."""

@@ -75,3 +75,35 @@ def test_native_core_equals_the_oracle_tracker_on_random_sequences():
     import fuzz_tracker
     for seed in range(40):
         assert fuzz_tracker.run(seed) is None, seed
+
+
+def test_a_refused_clip_leaves_the_tracker_untouched():
+    """`decide` validates before it mutates.  A first clip with more instances than MAX_NUM_INSTANCES, and a clip beyond
+    the window's memory, are refused (the reference raises there too) -- and the object, which the product reuses, is exactly as
+    before: a valid clip afterwards behaves as if the refused one had never been offered."""
+    import torch
+    from _standins import Clips, TorchBankTracker
+    from mdqe_cvpr2023_amd._lib import MdqeError
+    E, K, hw = 8, 3, (4, 4)
+
+    def clip(frames, n, seed):
+        rng = np.random.RandomState(seed)
+        host = {"scores": np.full(n, 0.9, np.float32), "cls_probs": rng.rand(n, K).astype(np.float32),
+                "query_embeds": (np.eye(E, dtype=np.float32)[np.arange(n) % E] * 6 + rng.rand(n, E).astype(np.float32) * 0.01)}
+        return Clips(frames, {"pred_masks": torch.from_numpy(rng.randn(n, len(frames), *hw).astype(np.float32)), "host": host})
+
+    a = TorchBankTracker(3, 2, 4, 1, K, 4, E, hw, torch.device("cpu"), 0.1)
+    b = TorchBankTracker(3, 2, 4, 1, K, 4, E, hw, torch.device("cpu"), 0.1)
+    with pytest.raises(MdqeError):
+        a.update(clip([0, 1], 5, 0))                            # 5 first-clip instances > max_inst 3
+    assert a.num_inst == 0 and a.num_clip == 0
+    for t in (a, b):
+        t.update(clip([0, 1], 2, 1))
+    with pytest.raises(MdqeError):
+        a.update(clip([40, 41], 2, 2))                          # frames far beyond the window's memory
+    assert (a.num_inst, a.num_clip) == (b.num_inst, b.num_clip) == (2, 1)
+    for t in (a, b):
+        t.update(clip([1, 2], 3, 3))
+    ca, ma = a.get_result(is_last_clip=True)
+    cb, mb = b.get_result(is_last_clip=True)
+    assert torch.equal(ca, cb) and torch.equal(ma, mb) and a.num_inst == b.num_inst
