@@ -58,6 +58,15 @@ int mdqe_msda_backward_f32(const float* value, const int64_t* shapes, const int6
                            const float* attn, const float* grad_out, int B, int S, int M, int D, int L, int Q, int P,
                            float* grad_value, float* grad_loc, float* grad_attn, void* stream);
 
+/* The same two exports in float64 -- the reference dispatches float and double (AT_DISPATCH_FLOATING_TYPES,
+ * src/cuda/ms_deform_attn_cuda.cu:64 forward, :134 backward) and its own test script checks the double forward against the
+ * PyTorch core and the backward by gradcheck in double (mdqe/models/ops/test.py:32-44, :63-86).  csrc/msda_f64.hip. */
+int mdqe_msda_forward_f64(const double* value, const int64_t* shapes, const int64_t* level_start, const double* loc,
+                          const double* attn, int B, int S, int M, int D, int L, int Q, int P, double* out, void* stream);
+int mdqe_msda_backward_f64(const double* value, const int64_t* shapes, const int64_t* level_start, const double* loc,
+                           const double* attn, const double* grad_out, int B, int S, int M, int D, int L, int Q, int P,
+                           double* grad_value, double* grad_loc, double* grad_attn, void* stream);
+
 /* Grouped form used for temporal_clip_forward (mdqe/models/ops/modules/ms_deform_attn.py:219-236):
  * the reference issues G (= #spatial levels) separate native calls that share loc/attn and averages
  * them.  Here: shapes/level_start are [G*L] tables into ONE value buffer, out = scale * sum_g (...). */
@@ -112,6 +121,15 @@ int mdqe_gemm_nt_cat2_f32(const float* A1, long lda1, int K1, const float* A2, l
  * C = LN(A W^T + bias + residual) * gamma + beta, N must be 256; C may alias the residual.  Exact fp32 MFMA. */
 int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
                      const float* residual, long ldr, const float* gamma, const float* beta, float eps, void* stream);
+
+/* A projection of `x + pos` whose pos is a linear function of four numbers per row -- the decoder's query position embedding
+ * point2pos_proj(box centre) (mdqe/models/transformer_dec.py:42,469,480,495,503), consumed as `x + pos` by the self-attention q/k
+ * projections (:348-353, :397-402) and by the sampling-offset / attention-weight projections of cross_attn / temp_attn_inst
+ * (ops/modules/ms_deform_attn.py:141-147,198-203):  C = A W^T + bias;  C[:, n < side_cols] += side [M,4] . side_w[n, 0:4]
+ * with side_w = W P and the bias carrying W b_P (folded once on the host).  The [M, C] position tensor is never materialised and
+ * the q, k (with position) and v (without) projections of one x are ONE product.  side_cols % 4 == 0. */
+int mdqe_gemm_nt_side_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
+                          const float* side, const float* side_w, int side_cols, const void* w_split, void* stream);
 
 /* GEMM arithmetic of the 128x128 tile (process-wide): 0 = exact fp32 MFMA (default), 1 = "f16x3": operands split
  * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752). */
@@ -284,6 +302,14 @@ int mdqe_box_refine_f32(const float* delta, const float* prev, int Bc, int T, in
 int mdqe_add_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long rows, int C, void* stream);
 int mdqe_time_fuse_f32(const float* w, const float* x, int Bc, int T, int Q, int C, float* out, const float* pos,
                        float* out_plus_pos, void* stream);
+/* Round 3, fewer launches between the decoder's GEMMs.  box_head_refine: bbox_embed's last Linear(C -> 4) + the refinement
+ * sigmoid(delta + inverse_sigmoid(prev)) + the clip-circumscribed box (transformer_dec.py:473-480,492-503) in one kernel; h [Bc*T*Q, K]
+ * is the head's second hidden activation, W [4, K], bias [4].  time_fuse_dot: time_weights Linear(C -> 1) of the frame queries xw, the
+ * softmax over the clip's frames and the weighted sum of src (:374-376) in one kernel.  Same arithmetic as the kernels they replace. */
+int mdqe_box_head_refine_f32(const float* h, long ldh, const float* W, const float* bias, const float* prev, int Bc, int T, int Q, int K,
+                             int t0, int t1, float* boxes, float* ibox, void* stream);
+int mdqe_time_fuse_dot_f32(const float* xw, const float* wt, const float* bt, const float* src, int Bc, int T, int Q, int C, float* out,
+                           void* stream);
 
 /* inference_clip (mdqe/mdqe.py:368-428) for a batch of B clips.
  * clip_select (:373-379): cls [B,Q,K], emb [B,Q,C] -> kept [B,Q] (query indices of the kept ranks, score order), n_keep [B]:

@@ -6,8 +6,9 @@ mdqe/models/ops/src/vision.cpp:13-16).
     out = MSDA.ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
 
 Same argument meaning and error behaviour as ms_deform_attn_cuda_forward
-(src/cuda/ms_deform_attn_cuda.cu:20-80): tensors must be contiguous and on the GPU, fp32 (callers
-force fp32, func.py:24), `batch % min(batch, im2col_step) == 0`; returns a NEW [B,Q,M*D] tensor;
+(src/cuda/ms_deform_attn_cuda.cu:20-80): tensors must be contiguous and on the GPU, float32 or float64 (the reference's
+AT_DISPATCH_FLOATING_TYPES, .cu:64,134; the eval path's callers force fp32, func.py:24; the reference's own test script runs
+double, ops/test.py:32-44,63-86), `batch % min(batch, im2col_step) == 0`; returns a NEW [B,Q,M*D] tensor;
 asynchronous on the current stream.  Violations raise RuntimeError (AT_ASSERTM -> RuntimeError there).
 The arithmetic runs in libmdqe_hip.so (csrc/msda.hip); torch only owns the memory and the stream.
 """
@@ -26,8 +27,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
                     ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
         _req(t.is_contiguous(), f"{name} tensor has to be contiguous")
         _req(t.is_cuda, f"{name} must be a CUDA tensor")
-    _req(value.dtype == torch.float32 and sampling_loc.dtype == torch.float32 and attn_weight.dtype == torch.float32,
-         "ms_deform_attn_forward: only float32 is implemented on gfx950")
+    _req(value.dtype in (torch.float32, torch.float64), f'"ms_deform_attn_forward_cuda" not implemented for \'{value.dtype}\'')
+    _req(sampling_loc.dtype == value.dtype and attn_weight.dtype == value.dtype,
+         "ms_deform_attn_forward: value, sampling_loc and attn_weight must have the same dtype")
     _req(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
          "spatial_shapes / level_start_index must be int64")
     B, S, M, D = value.shape
@@ -39,8 +41,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     _req(B == 0 or (step > 0 and B % step == 0), f"batch({B}) must divide im2col_step({step})")
     out = torch.empty((B, Q, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
-        check(lib.mdqe_msda_forward_f32(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
-                                        ptr(attn_weight), B, S, M, D, L, Q, P, ptr(out), cur_stream()),
+        fn = lib.mdqe_msda_forward_f32 if value.dtype == torch.float32 else lib.mdqe_msda_forward_f64
+        check(fn(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
+                 ptr(attn_weight), B, S, M, D, L, Q, P, ptr(out), cur_stream()),
               "ms_deform_attn_forward")
     return out
 
@@ -52,8 +55,9 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                     ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)):
         _req(t.is_contiguous(), f"{name} tensor has to be contiguous")
         _req(t.is_cuda, f"{name} must be a CUDA tensor")
-    _req(all(t.dtype == torch.float32 for t in (value, sampling_loc, attn_weight, grad_output)),
-         "ms_deform_attn_backward: only float32 is implemented on gfx950")
+    _req(value.dtype in (torch.float32, torch.float64), f'"ms_deform_attn_backward_cuda" not implemented for \'{value.dtype}\'')
+    _req(all(t.dtype == value.dtype for t in (sampling_loc, attn_weight, grad_output)),
+         "ms_deform_attn_backward: value, sampling_loc, attn_weight and grad_output must have the same dtype")
     _req(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
          "spatial_shapes / level_start_index must be int64")
     B, S, M, D = value.shape
@@ -68,7 +72,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gl = torch.empty_like(sampling_loc)
     ga = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
-        check(lib.mdqe_msda_backward_f32(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
-                                         ptr(attn_weight), ptr(grad_output), B, S, M, D, L, Q, P, ptr(gv), ptr(gl), ptr(ga),
-                                         cur_stream()), "ms_deform_attn_backward")
+        fn = lib.mdqe_msda_backward_f32 if value.dtype == torch.float32 else lib.mdqe_msda_backward_f64
+        check(fn(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
+                 ptr(attn_weight), ptr(grad_output), B, S, M, D, L, Q, P, ptr(gv), ptr(gl), ptr(ga),
+                 cur_stream()), "ms_deform_attn_backward")
     return [gv, gl, ga]

@@ -13,6 +13,8 @@ i, f, p, l = c_int, c_float, c_void_p, c_long
 SIGNATURES = {
     "mdqe_msda_forward_f32": [p, p, p, p, p, i, i, i, i, i, i, i, p, p],
     "mdqe_msda_backward_f32": [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p],
+    "mdqe_msda_forward_f64": [p, p, p, p, p, i, i, i, i, i, i, i, p, p],
+    "mdqe_msda_backward_f64": [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p],
     "mdqe_msda_forward_grouped_f32": [p, p, p, p, p, i, i, i, i, i, i, i, i, f, p, p],
     "mdqe_msda_fused_f32": [p, l, l, p, p, l, p, l, p, l, i, i, p, p, p, p, i, i, i, i, i, i, i, f, p, l, l, p],
     "mdqe_trk_siou_f32": [p, l, i, p, l, i, l, p, p],
@@ -34,6 +36,8 @@ SIGNATURES = {
     "mdqe_box_refine_f32": [p, p, i, i, i, i, i, p, p, p],
     "mdqe_add_rows_f32": [p, l, p, l, p, l, l, i, p],
     "mdqe_time_fuse_f32": [p, p, i, i, i, i, p, p, p, p],
+    "mdqe_box_head_refine_f32": [p, l, p, p, p, i, i, i, i, i, i, p, p, p],
+    "mdqe_time_fuse_dot_f32": [p, p, p, p, i, i, i, i, p, p],
     "mdqe_clip_select_f32": [p, p, i, i, i, i, f, i, p, p, p, p, p, p, p],
     "mdqe_dyn_mask_nms_f32": [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p],
     "mdqe_clip_finalize_f32": [p, p, p, p, p, i, i, i, i, f, p, p, p, p, p, p],
@@ -69,6 +73,7 @@ SIGNATURES = {
     "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p, i, p, p],
     "mdqe_layernorm_f32": [p, p, p, p, p, l, i, f, p],
     "mdqe_gemm_ln_f32": [p, l, p, p, p, l, i, i, i, p, l, p, p, f, p],
+    "mdqe_gemm_nt_side_f32": [p, l, p, p, p, l, i, i, i, p, p, i, p, p],
     "mdqe_gemm_nt_cat2_f32": [p, l, i, p, l, i, i, i, i, i, i, i, p, p, p, l, i, i, p],
     "mdqe_groupnorm_nhwc_f32": [p, l, l, p, l, l, i, i, i, i, p, p, f, i, p, p],
     "mdqe_resize_pil_bilinear_u8": [p, l, i, i, i, i, i, i, p, p, p, i, p, p, p, i, p, p],

@@ -241,6 +241,114 @@ extern "C" int mdqe_time_fuse_f32(const float* w, const float* x, int Bc, int T,
   return mdqe_launch_status();
 }
 
+// ---- fused forms (round 3): fewer, fatter launches between the decoder's GEMMs -------------------------------------------------
+// box_head_refine: the LAST layer of the box head (Linear(C -> 4), transformer_dec.py:492-493 `bbox_embed`) + the iterative
+// refinement sigmoid(delta + inverse_sigmoid(prev)) of every frame of a (clip, query) + the clip-circumscribed box (:473-480,
+// :496-503) in ONE kernel: one wave per (clip, query) walks its T rows of the head's hidden activation; a lane takes 4 consecutive k
+// of a row, the four weight rows come from L1, xor-shuffle sums -- the arithmetic of rows_dot_kernel<4> (gemm.hip) followed by the
+// arithmetic of box_refine_kernel, bit for bit, so the fused and the two-kernel forms are interchangeable.
+__global__ void __launch_bounds__(256)
+box_head_refine_kernel(const float* __restrict__ h, long ldh, const float* __restrict__ W, const float* __restrict__ bias,
+                       const float* __restrict__ prev, int T, int Q, int K, int t0, int t1, long n, float* __restrict__ boxes,
+                       float* __restrict__ ibox) {
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);             // (b, q)
+  if (i >= n) return;
+  const long b = i / Q;
+  const int q = (int)(i % Q);
+  float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+  for (int t = 0; t < T; ++t) {
+    const long r = (b * T + t) * Q + q;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 256) {
+      const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h + r * ldh + k0 + lane * 4));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)c * K + k0 + lane * 4);
+        acc[c] = fmaf(a[3], w[3], fmaf(a[2], w[2], fmaf(a[1], w[1], fmaf(a[0], w[0], acc[c]))));
+      }
+    }
+    f32x4 d;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = acc[c];
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) v += __shfl_xor(v, sft, 64);
+      d[c] = v + bias[c];
+    }
+    const f32x4 p = *reinterpret_cast<const f32x4*>(prev + r * 4);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = 1.0f / (1.0f + expf(-(d[c] + inv_sigmoid(p[c]))));
+    if (lane == 0) *reinterpret_cast<f32x4*>(boxes + r * 4) = o;
+    if (t >= t0 && t < t1) {
+      const float ax = fminf(fmaxf(o[0] - 0.5f * o[2], 0.f), 1.f), ay = fminf(fmaxf(o[1] - 0.5f * o[3], 0.f), 1.f);
+      const float bx = fminf(fmaxf(o[0] + 0.5f * o[2], 0.f), 1.f), by = fminf(fmaxf(o[1] + 0.5f * o[3], 0.f), 1.f);
+      x0 = fminf(x0, ax); y0 = fminf(y0, ay); x1 = fmaxf(x1, bx); y1 = fmaxf(y1, by);
+    }
+  }
+  if (lane == 0) *reinterpret_cast<f32x4*>(ibox + i * 4) = f32x4{(x0 + x1) / 2.f, (y0 + y1) / 2.f, x1 - x0, y1 - y0};
+}
+
+extern "C" int mdqe_box_head_refine_f32(const float* h, long ldh, const float* W, const float* bias, const float* prev, int Bc, int T,
+                                        int Q, int K, int t0, int t1, float* boxes, float* ibox, void* stream) {
+  MDQE_REQUIRE(Bc >= 0 && T > 0 && Q > 0 && K > 0 && K % 256 == 0 && ldh >= K && ldh % 4 == 0 && t0 >= 0 && t0 < t1);
+  if (Bc == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(h); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(bias); MDQE_CHECK_PTR(prev); MDQE_CHECK_PTR(boxes); MDQE_CHECK_PTR(ibox);
+  MDQE_REQUIRE((((uintptr_t)h | (uintptr_t)W | (uintptr_t)prev | (uintptr_t)boxes | (uintptr_t)ibox) & 15) == 0);
+  mdqe_clear_error();
+  const long n = (long)Bc * Q;
+  hipLaunchKernelGGL(box_head_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, ldh, W, bias, prev, T, Q, K,
+                     t0, t1 < T ? t1 : T, n, boxes, ibox);
+  return mdqe_launch_status();
+}
+
+// time_fuse_dot: the time weights Linear(C -> 1) (transformer_dec.py:374 `time_weights`) of the T frame queries of a (clip, query), their
+// softmax over t, and the weighted sum of the frame queries `src` (:375-376) in ONE kernel: one wave per (clip, query); the dot product
+// is rows_dot_kernel<1>'s arithmetic, the softmax / sum time_fuse_kernel's -- bit for bit the two-kernel form.  C == 256.
+__global__ void __launch_bounds__(256)
+time_fuse_dot_kernel(const float* __restrict__ xw, const float* __restrict__ wt, const float* __restrict__ bt,
+                     const float* __restrict__ src, int T, int Q, long n, float* __restrict__ out) {
+  constexpr int C = 256, TMAX = 8;
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);             // (b, q)
+  if (i >= n) return;
+  const long b = i / Q;
+  const int q = (int)(i % Q);
+  const f32x4 w = *reinterpret_cast<const f32x4*>(wt + lane * 4);
+  float tw[TMAX];
+  float m = -INFINITY;
+  for (int t = 0; t < T; ++t) {
+    const long r = (b * T + t) * Q + q;
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xw + r * C + lane * 4));
+    float v = fmaf(a[3], w[3], fmaf(a[2], w[2], fmaf(a[1], w[1], fmaf(a[0], w[0], 0.f))));
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) v += __shfl_xor(v, sft, 64);
+    tw[t] = v + bt[0];
+    m = fmaxf(m, tw[t]);
+  }
+  float den = 0.f;
+  for (int t = 0; t < T; ++t) den += expf(tw[t] - m);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t) {
+    const float p = expf(tw[t] - m) / den;
+    acc += p * *reinterpret_cast<const f32x4*>(src + ((b * T + t) * Q + q) * (long)C + lane * 4);
+  }
+  *reinterpret_cast<f32x4*>(out + i * (long)C + lane * 4) = acc;
+}
+
+extern "C" int mdqe_time_fuse_dot_f32(const float* xw, const float* wt, const float* bt, const float* src, int Bc, int T, int Q, int C,
+                                      float* out, void* stream) {
+  MDQE_REQUIRE(Bc >= 0 && T > 0 && T <= 8 && Q > 0 && C == 256);
+  if (Bc == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(xw); MDQE_CHECK_PTR(wt); MDQE_CHECK_PTR(bt); MDQE_CHECK_PTR(src); MDQE_CHECK_PTR(out);
+  MDQE_REQUIRE((((uintptr_t)xw | (uintptr_t)wt | (uintptr_t)src | (uintptr_t)out) & 15) == 0);
+  mdqe_clear_error();
+  const long n = (long)Bc * Q;
+  hipLaunchKernelGGL(time_fuse_dot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xw, wt, bt, src, T, Q, n, out);
+  return mdqe_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // a15, step 1 (mdqe/mdqe.py:373-374): per clip, sort the queries by their best class score (descending; equal scores by
 // query index) and keep those >= min(thr, best).  One block of 256 threads per clip (Q <= 256): bitonic sort in LDS.

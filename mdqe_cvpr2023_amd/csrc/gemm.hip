@@ -471,6 +471,56 @@ extern "C" int mdqe_gemm_nt_f32(const float* A, long lda, const float* W, const 
 }
 
 
+// C[m, n < side_cols] += side[m, 0:4] . side_w[n, 0:4] as a pass of its own: what the GEMM kernels without the in-epilogue
+// side term (split-precision tiles, the K-step-32 form) are followed by.
+__global__ void __launch_bounds__(256)
+side_add_kernel(const float* __restrict__ side, const float* __restrict__ side_w, float* __restrict__ C, long ldc, long M, int cols) {
+  const int c4n = cols / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M * c4n; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c4n; const int n = (int)(i % c4n) * 4;
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(side + m * 4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(C + m * ldc + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(side_w + (long)(n + e) * 4);
+      v[e] += (s4[0] * w4[0] + s4[1] * w4[1]) + (s4[2] * w4[2] + s4[3] * w4[3]);
+    }
+    *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
+  }
+}
+
+// C = A W^T + bias, and C[:, n < side_cols] += side [M, 4] x side_w[n, 0:4]^T -- a projection of `x + pos` where pos is itself a
+// linear function of four numbers per row (the decoder's query position embedding, point2pos_proj(box centre),
+// mdqe/models/transformer_dec.py:469,480,495,503 feeding :348-353, :397-402 and the sampling-offset / attention-weight projections
+// of ms_deform_attn.py): `(x + pos) W^T = x W^T + box (W P)^T + W b_P`, with `W P` [N, 4] and the bias folded on the host once.
+// One launch instead of add + GEMM, the [M, C] position tensor is never written; several projections of the same x with and
+// without the position (q, k | v) become ONE product with side_cols marking the columns that take it.
+extern "C" int mdqe_gemm_nt_side_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
+                                     const float* side, const float* side_w, int side_cols, const void* w_split, void* stream) {
+  MDQE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N && ldc % 4 == 0);
+  MDQE_REQUIRE(side_cols >= 0 && side_cols <= N && side_cols % 4 == 0 && N % 4 == 0);
+  if (M == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
+  if (side_cols > 0) { MDQE_CHECK_PTR(side); MDQE_CHECK_PTR(side_w); }
+  MDQE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)side | (uintptr_t)side_w) & 15) == 0);
+  const long ab = ((long)(M - 1) * lda + K) * 4, wb = (long)N * K * 4;
+  MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  GemmParams p = {};
+  p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
+  p.bias = bias; p.act = MDQE_ACT_NONE; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+  p.ksplit = 1; p.kchunk = K; p.ws = nullptr;
+  if (w_split != nullptr) { p.Wh = w_split; p.Wl = (const char*)w_split + (long)N * K * 2; }
+  mdqe_clear_error();
+  hipStream_t st = (hipStream_t)stream;
+  const bool in_epilogue = side_cols > 0 && g_gemm_precision == 0 && g_gemm_variant != 0;      // the K-step-16 fp32 kernel takes it itself
+  if (in_epilogue) { p.side = side; p.side_w = side_w; p.side_cols = side_cols; }
+  const int rc = dispatch_gemm(p, 0, st);
+  if (rc != MDQE_OK || in_epilogue || side_cols == 0) return rc;
+  long nb = ((long)M * (side_cols / 4) + 255) / 256; if (nb > 256L * 16) nb = 256L * 16;
+  hipLaunchKernelGGL(side_add_kernel, dim3((unsigned)nb), dim3(256), 0, st, side, side_w, C, ldc, (long)M, side_cols);
+  return mdqe_launch_status();
+}
+
 // C = act([A1 | A2'] W^T + bias): the last 1x1 conv of a ResNet bottleneck and its projection shortcut as ONE product -- W = [W3 | Ws]
 // along K, bias = b3 + bs -- so the shortcut's output (as wide as the block's output) is never written and read back.  A1: [M, K1]
 // rows (pitch lda1); A2: the block's input, NHWC [NI, H2, W2, lda2 >= K2], read at pixel (oh*stride, ow*stride) for output row

@@ -309,6 +309,14 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
         const bool masked = p.rowmask != nullptr && p.rowmask[m];
         if (vec && (n + 3 < p.N)) {
           if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (p.side != nullptr && n < p.side_cols) {        // rank-4 side term (side_cols % 4 == 0)
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.side + (long)m * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.side_w + (long)(n + e) * 4);
+              v[e] += (s4[0] * w4[0] + s4[1] * w4[1]) + (s4[2] * w4[2] + s4[3] * w4[3]);
+            }
+          }
           f32x4 rv = {0.f, 0.f, 0.f, 0.f};
           if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
           if (p.res_first) v += rv;
@@ -329,6 +337,10 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           for (int e = 0; e < 4; ++e) {
             if (n + e >= p.N) break;
             float x = v[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f);
+            if (p.side != nullptr && n + e < p.side_cols) {
+              const float* s4 = p.side + (long)m * 4; const float* w4 = p.side_w + (long)(n + e) * 4;
+              x += (s4[0] * w4[0] + s4[1] * w4[1]) + (s4[2] * w4[2] + s4[3] * w4[3]);
+            }
             const float rv = p.residual != nullptr ? p.residual[rrow * p.ldr + n + e] : 0.f;
             if (p.res_first) x += rv;
             if (p.act != MDQE_ACT_NONE && (p.act_cols <= 0 || n + e < p.act_cols)) x = mdqe_act(x, p.act);
@@ -385,6 +397,7 @@ static int launch_k16_(const GemmParams& p, hipStream_t st) {
 
 // tile: 1 128x128, 2 128x64, 3 64x64 (as gemm.hip), 7 32x64, 8 32x128, 9 64x128; the split-K reduce pass is launched by the caller
 int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
+  if (p.side != nullptr && (p.conv || p.ksplit > 1 || tile == 6 || p.A2 != nullptr)) return MDQE_EINVAL;   // side term: plain tiles only
   if (p.A2 != nullptr) {                                // cat mode: two A operands side by side along K
     if (p.conv || p.ksplit > 1) return MDQE_EINVAL;
     switch (tile) {

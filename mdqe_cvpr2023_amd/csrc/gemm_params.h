@@ -24,6 +24,10 @@ struct GemmParams {
   // cat mode (A2 != null, K-step-16 kernel, plain tiles): k < K1 comes from A, k >= K1 from row (img, oh*stride, ow*stride) of the NHWC
   // tensor A2 [*, H, Wd, lda2] -- output row m = (img, oh, ow) on the OH x OW grid (H, Wd, OH, OW, stride as in conv mode)
   const float* A2; long lda2; int K1; unsigned a2_bytes;
+  // rank-4 side term (K-step-16 kernel, plain tiles; everywhere else a second pass adds it): C[m, n] += side[m, 0:4] . side_w[n, 0:4]
+  // for n < side_cols, before the activation.  The decoder's `(x + pos) W^T` with pos = Linear(2 -> C)(box centre) is
+  // `x W^T + box (W P)^T`: the position embedding is never materialised (mdqe_gemm_nt_side_f32)
+  const float* side; const float* side_w; int side_cols;
   int stagger;              // K-step-16 kernel: the first resident round of blocks starts (slot on the CU) x stagger 10-ns ticks late (0: off)
 };
 

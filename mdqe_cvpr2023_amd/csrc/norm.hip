@@ -8,6 +8,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// The reduction tree of the LayerNorm EPILOGUE of the 64x256 GEMM tile (gemm_k16.hip: a lane's two 4-column chunks 32 columns apart,
+// then the 8 lanes of a 32-column group, then the four 64-column wave slices as (w0 + w1) + (w2 + w3)), replayed on one wave whose
+// lane i holds columns 4i .. 4i+3 of a 256-wide row: chunk i pairs with chunk i^8 first, then xor 1, 2, 4, then 16, 32.  With it
+// `linear -> layernorm_kernel` and the fused kernel give the SAME BITS, so which of the two a launch takes (a question of how many
+// rows there are to fill the chip, ops.linear_ln) never changes a result.
+__device__ __forceinline__ float wave_sum_c256(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 // y[r,:] = LN(x[r,:] + res[r,:]) * gamma + beta   (nn.LayerNorm eps=1e-5; transformer_enc.py:103-108,
 // transformer_dec.py:345-358).  Optional second output y2 = y + add2[(r % add2_mod), :].
 template <int NCH>
@@ -31,7 +43,8 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    const float mean = wave_sum(s) / C;
+    const bool tree256 = NCH == 1 && C == 256;
+    const float mean = (tree256 ? wave_sum_c256(s) : wave_sum(s)) / C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -41,7 +54,7 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
       }
     }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    const float rstd = rsqrtf((tree256 ? wave_sum_c256(q) : wave_sum(q)) / C + eps);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane * 4 + i * 256;

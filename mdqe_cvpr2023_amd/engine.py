@@ -232,6 +232,24 @@ class Packed:
                                    wo=up(sd[f"{q}.{mod}.output_proj.weight"]), bo=up(sd[f"{q}.{mod}.output_proj.bias"])))
                 vw.append(sd[f"{q}.{mod}.value_proj.weight"])
                 vb.append(sd[f"{q}.{mod}.value_proj.bias"])
+            # `(x + pos) W^T` with pos = point2pos_proj(box centre) is `x W^T + box (W P)^T + W b_P`: the rank-4 side term of
+            # mdqe_gemm_nt_side_f32 -- the position embedding is never materialised.  q and k take it, v does not, so the three
+            # self-attention projections are ONE [3C, C] product with side_cols = 2C.  Folded here once, in float64.
+            P64, bp64 = w.double().cpu(), sd[d + ".point2pos_proj.bias"].double().cpu()
+            for tag, mod in (("sa", "self_attn"), ("sai", "self_attn_inst")):
+                m = getattr(L, tag)
+                Wi, bi = sd[f"{q}.{mod}.in_proj_weight"].double().cpu(), sd[f"{q}.{mod}.in_proj_bias"].double().cpu()
+                sw = torch.zeros(3 * C, 4, dtype=torch.float64)
+                sw[:2 * C] = Wi[:2 * C] @ P64
+                bb = bi.clone()
+                bb[:2 * C] += Wi[:2 * C] @ bp64
+                m.wqkv, m.bqkv_pos, m.side_w = up(Wi.float()), up(bb.float()), up(sw.float())
+            for tag in ("ca", "ta"):
+                m = getattr(L, tag)
+                if m is None:
+                    continue
+                m.side_w = up((m.wq.double().cpu() @ P64).float())
+                m.bq_pos = up((m.bq.double().cpu() + m.wq.double().cpu() @ bp64).float())
             for nm in ("norm1", "norm2", "norm3", "norm1_inst", "norm2_inst", "norm3_inst"):
                 setattr(L, nm, (up(sd[f"{q}.{nm}.weight"]), up(sd[f"{q}.{nm}.bias"])))
             for nm in ("linear1", "linear2", "linear1_inst", "linear2_inst", "time_weights"):
@@ -342,6 +360,9 @@ def box_cxcywh_to_xyxy(b):
 def box_xyxy_to_cxcywh(b):
     x0, y0, x1, y1 = b.unbind(-1)
     return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], -1)
+
+
+DEC_FUSED = os.environ.get("MDQE_DEC_FUSED", "1") != "0"   # 0: position embedding materialised, separate q/k and v projections (A/B)
 
 
 class Engine:
@@ -531,13 +552,6 @@ class Engine:
                           mask_cols=self.P.dec_vw.shape[0], out=out).view(NI, N, -1)
 
     # ---- a11 (association) + a12-a14: decoder over one clip ---------------------------------------
-    def _mha(self, sa, qk_in, v_in, nh):
-        """nn.MultiheadAttention, q = k = x+pos, v = x, eval (transformer_dec.py:348-353,397-402)."""
-        B, Q, C = qk_in.shape
-        qk = ops.linear(qk_in.reshape(-1, C), sa.wqk, sa.bqk)
-        v = ops.linear(v_in.reshape(-1, C), sa.wv, sa.bv)
-        return ops.mha_small(qk, v, B, Q, C, nh), sa
-
     def _to_dev_i32(self, arr):
         """Small host int array -> device int32 through pinned memory (asynchronous, no host sync)."""
         h = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32))
@@ -569,11 +583,33 @@ class Engine:
         idx = ops.clip_assoc(cache["emb"], fidx, ct, cfg.window_inter_frame_asso / 2, cfg.n_bins) if T > 1 else None
         x, ref, x_inst = ops.clip_gather_init(content, cache["coords"], fidx, idx, ct)
         BT = Bc * T
-        bbox = lambda z: self._mlp(ops.layernorm(z, *P.dec_norm), P.bbox_embed)
+        fused = DEC_FUSED
+        small = fused and C == 256                                  # the two wave-per-(clip, query) kernels are written for C == 256
+
+        def refine(z, prev):
+            """bbox_embed(decoder_norm(z)) -> refined boxes + clip boxes (transformer_dec.py:473-480, 492-503)."""
+            z = ops.layernorm(z, *P.dec_norm)
+            if small:
+                h = ops.linear(ops.linear(z, *P.bbox_embed[0], act="gelu"), *P.bbox_embed[1], act="gelu")
+                return ops.box_head_refine(h, *P.bbox_embed[2], prev, Bc, T, Q, t0, t1)
+            return ops.box_refine(self._mlp(z, P.bbox_embed), prev, Bc, T, Q, t0, t1)
+
+        def qkv(sa, z, box, B_):
+            """Self-attention input projections, q = k = z + pos(box), v = z (transformer_dec.py:348-353, 397-402)."""
+            if fused:
+                o = ops.linear_side(z, sa.wqkv, sa.bqkv_pos, box, sa.side_w, 2 * C)
+                return ops.mha_small(o[:, :2 * C], o[:, 2 * C:], B_, Q, C, nh)
+            zp = ops.add_rows(z, ops.linear(box, *P.p2p))
+            return ops.mha_small(ops.linear(zp, sa.wqk, sa.bqk), ops.linear(z, sa.wv, sa.bv), B_, Q, C, nh)
+
+        def qproj(m, z, box):
+            """Sampling offsets + attention logits of a deformable attention from the query z + pos(box)."""
+            if fused:
+                return ops.linear_side(z, m.wq, m.bq_pos, box, m.side_w, m.wq.shape[0])
+            return ops.linear(ops.add_rows(z, ops.linear(box, *P.p2p)), m.wq, m.bq)
+
         t0, t1 = max(ct - int((Tc - 1) / 2), 0), ct + Tc
-        boxes, ibox = ops.box_refine(bbox(x), ref, Bc, T, Q, t0, t1)                            # warm-up boxes + clip boxes (:473-480)
-        x_pos = ops.linear(boxes, *P.p2p)
-        ipos = ops.linear(ibox, *P.p2p)
+        boxes, ibox = refine(x, ref)                                                          # warm-up boxes + clip boxes (:473-480)
         itv = max(int(T / Tc), 1)
         ts = max(ct - int((Tc - 1) / 2) * itv, 0)
         tca = list(range(ts, T, itv))[:Tc]
@@ -586,42 +622,37 @@ class Engine:
         vals2 = vals.view(-1, vals.shape[-1])
         vidx_sp = fidx.view(-1)                                                             # value block of (clip, frame)
         vidx_tp = self._to_dev_i32(fidx_h[:, 0])                                            # first frame of each clip
-        xq = torch.empty_like(x)
-        xiq = torch.empty_like(x_inst)
         vi = 0
         for L in P.dec:
             # ---- box level: CA -> SA -> FFN (transformer_dec.py:415-422)
-            pr = ops.linear(ops.add_rows(x, x_pos, out=xq), L.ca.wq, L.ca.bq)
+            pr = qproj(L.ca, x, boxes)
             a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * LP], pr[:, 2 * nh * LP:], boxes.view(BT, Q, 4), lv_sp,
                                BT, Q, nh, D, cfg.n_levels, cfg.dec_points, mode=1, grid=P.grid_sp, v_brows=N, vidx=vidx_sp)
             vi += 1
             x = ops.linear_ln(a, L.ca.wo, L.ca.bo, x, *L.norm2)
             sx = x
-            o, sa = self._mha(L.sa, ops.add_rows(x, x_pos, out=xq).view(BT, Q, C), x.view(BT, Q, C), nh)
-            x = ops.linear_ln(o, sa.wo, sa.bo, x, *L.norm1)
+            x = ops.linear_ln(qkv(L.sa, x, boxes, BT), L.sa.wo, L.sa.bo, x, *L.norm1)
             hdn = ops.linear(x, *L.linear1, act="gelu")
             x = ops.linear_ln(hdn, *L.linear2, x, *L.norm3)
             # ---- instance level (transformer_dec.py:361-409)
-            tw = ops.linear(x, *L.time_weights)                                             # [BT*Q, 1]
+            if small:
+                fq = ops.time_fuse_dot(x, *L.time_weights, sx, Bc, T, Q)
+            else:
+                fq = ops.time_fuse(ops.linear(x, *L.time_weights), sx, Bc, T, Q)
             if L.ta is not None:
-                fused, fpos = ops.time_fuse(tw, sx, Bc, T, Q, pos=ipos)
-                pr = ops.linear(fpos, L.ta.wq, L.ta.bq)
+                pr = qproj(L.ta, fq, ibox)
                 a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * TP], pr[:, 2 * nh * TP:], ibox.view(Bc, Q, 4), lv_tp,
                                    Bc, Q, nh, D, Tc, cfg.dec_points, mode=1, grid=P.grid_tp, groups=len(geo.shapes),
                                    scale=1.0 / len(geo.shapes), v_brows=N, vidx=vidx_tp)
                 vi += 1
-                xi2 = ops.linear(a, L.ta.wo, L.ta.bo)
+                x_inst = ops.linear_ln(a, L.ta.wo, L.ta.bo, x_inst, *L.norm2_inst)
             else:
-                xi2 = ops.time_fuse(tw, sx, Bc, T, Q)
-            x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=xi2)
-            o, sa = self._mha(L.sai, ops.add_rows(x_inst, ipos, out=xiq).view(Bc, Q, C), x_inst.view(Bc, Q, C), nh)
-            x_inst = ops.layernorm(ops.linear(o, sa.wo, sa.bo, residual=x_inst), *L.norm1_inst)
+                x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=fq)
+            x_inst = ops.linear_ln(qkv(L.sai, x_inst, ibox, Bc), L.sai.wo, L.sai.bo, x_inst, *L.norm1_inst)
             hdn = ops.linear(x_inst, *L.linear1_inst, act="gelu")
-            x_inst = ops.layernorm(ops.linear(hdn, *L.linear2_inst, residual=x_inst), *L.norm3_inst)
+            x_inst = ops.linear_ln(hdn, *L.linear2_inst, x_inst, *L.norm3_inst)
             # ---- iterative box refinement (transformer_dec.py:492-503)
-            boxes, ibox = ops.box_refine(bbox(x), boxes, Bc, T, Q, t0, t1)
-            x_pos = ops.linear(boxes, *P.p2p)
-            ipos = ops.linear(ibox, *P.p2p)
+            boxes, ibox = refine(x, boxes)
         n = ops.layernorm(x_inst, *P.dec_norm)
         return {"cls": self._mlp(n, P.cls_embed, "sigmoid").view(Bc, Q, -1),
                 "mask_coeff": self._mlp(n, P.mask_embed, "tanh").view(Bc, Q, -1),

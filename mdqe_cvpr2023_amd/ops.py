@@ -121,8 +121,8 @@ def linear(x, weight, bias=None, act=None, residual=None, res_mod=0, rowmask=Non
     if residual is not None:
         ldr = residual.stride(0) if residual.dim() == 2 else residual.shape[-1]
     ws = None
-    if ksplit == 0 and K >= 2048 and ((M + 63) // 64) * ((N + 63) // 64) <= 64:
-        ksplit = min(64, K // 256)                      # skinny product: spread K over the CUs
+    # (no automatic split-K here: a split changes the order of a row's K sum, and which arithmetic a row gets must not depend on
+    # how many rows share its launch -- the schedule tests demand identical bits across pass sizes; callers pass ksplit explicitly)
     if ksplit > 1:
         ws = _workspace(ksplit * M * N * 4 + 64, x.device)
     check(lib.mdqe_gemm_nt_f32(ptr(x2), lda, ptr(weight), ptr(bias), ptr(out), ldc_, M, N, K, ACT[act], act_cols,
@@ -150,8 +150,11 @@ def conv2d_nhwc(x, w_packed, bias=None, stride=1, pad=0, act=None, residual=None
     ldr = residual.stride(-2) if residual is not None else 0
     M, K = NI * OH * OW, KH * KW * Cin
     ws = None
-    if ksplit == 0 and K >= 4096 and ((M + 63) // 64) * ((Cout + 63) // 64) <= 256:
-        ksplit = min(16, K // 1024)                     # few output pixels, very deep K (input_proj's 3x3/s2 on res5)
+    if ksplit == 0 and K >= 4096 and ((OH * OW + 63) // 64) * ((Cout + 63) // 64) <= 16:
+        # few output pixels PER IMAGE, very deep K (input_proj's 3x3/s2 on res5: 60 pixels, K = 18432): spread K over the CUs.  Decided
+        # from one image's tiles, never from the batch: a split changes the order of the K sum, and a frame's bits must not depend on
+        # how many frames share its pass
+        ksplit = min(16, K // 1024)
     if ksplit > 1:
         ws = _workspace(ksplit * M * Cout * 4 + 64, x.device)
     check(lib.mdqe_conv2d_nhwc_f32(ptr(x), xis, ptr(w_packed), ptr(bias), ptr(out), ldy, NI, H, W, Cin, Cout, KH, KW, stride,
@@ -181,6 +184,21 @@ def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratc
         return out
     y = linear(x, weight, bias, residual=residual, out=scratch)
     return layernorm(y, gamma, beta, eps=eps, out=out)
+
+
+def linear_side(x, weight, bias, side, side_w, side_cols, out=None):
+    """out = x @ weight^T + bias, and out[:, :side_cols] += side [M,4] @ side_w[:side_cols, :4]^T (mdqe_gemm_nt_side_f32): a projection
+    of `x + pos` for a pos that is linear in four numbers per row, without materialising pos."""
+    M, K = x.shape
+    N = weight.shape[0]
+    _chk(weight, "weight"); _chk(bias, "bias"); _chk(side, "side"); _chk(side_w, "side_w")
+    if x.stride(1) != 1 or side.shape != (M, 4) or side_w.shape != (N, 4):
+        raise RuntimeError("linear_side: x rows contiguous, side [M,4], side_w [N,4] required")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(lib.mdqe_gemm_nt_side_f32(ptr(x), x.stride(0) if M > 1 else K, ptr(weight), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                                    ptr(side), ptr(side_w), side_cols, ptr(_wsplit(weight)), cur_stream()), "gemm_nt_side_f32")
+    return out
 
 
 def linear_cat2(y, x_nhwc, stride, weight, bias, act=None, out=None):
@@ -520,6 +538,25 @@ def box_refine(delta, prev, Bc, T, Q, t0, t1):
     ibox = torch.empty(Bc * Q, 4, device=delta.device)
     check(lib.mdqe_box_refine_f32(ptr(delta), ptr(prev), Bc, T, Q, t0, t1, ptr(boxes), ptr(ibox), cur_stream()), "box_refine")
     return boxes, ibox
+
+
+def box_head_refine(h, w, b, prev, Bc, T, Q, t0, t1):
+    """box_refine(h @ w^T + b, prev) with the 4-column product inside the kernel: h [Bc*T*Q, K] (K % 256 == 0), w [4, K], b [4]."""
+    _chk(h, "h"); _chk(w, "w"); _chk(b, "b"); _chk(prev, "prev")
+    boxes = torch.empty(Bc * T * Q, 4, device=h.device)
+    ibox = torch.empty(Bc * Q, 4, device=h.device)
+    check(lib.mdqe_box_head_refine_f32(ptr(h), h.stride(0), ptr(w), ptr(b), ptr(prev), Bc, T, Q, h.shape[1], t0, t1, ptr(boxes), ptr(ibox),
+                                       cur_stream()), "box_head_refine")
+    return boxes, ibox
+
+
+def time_fuse_dot(xw, wt, bt, src, Bc, T, Q):
+    """time_fuse(xw @ wt^T + bt, src): the time weights are computed inside the kernel.  xw, src [Bc*T*Q, 256], wt [1, 256], bt [1]."""
+    _chk(xw, "xw"); _chk(wt, "wt"); _chk(bt, "bt"); _chk(src, "src")
+    C = src.shape[-1]
+    out = torch.empty(Bc * Q, C, device=src.device)
+    check(lib.mdqe_time_fuse_dot_f32(ptr(xw), ptr(wt), ptr(bt), ptr(src), Bc, T, Q, C, ptr(out), cur_stream()), "time_fuse_dot")
+    return out
 
 
 def add_rows(a, b, out=None):

@@ -135,3 +135,92 @@ def test_batched_inference_clip_is_deterministic_and_handles_empty_batches():
         assert all(torch.equal(x[k], y[k]) for k in ("scores", "pred_classes", "cls_probs", "pred_masks", "query_embeds"))
         ref = O.inference_clip(hp, {"cls": cls[i:i + 1], "mask_coeff": coef[i:i + 1], "query_embed": emb[i:i + 1]}, mf[i:i + T].permute(3, 0, 1, 2))
         assert x["pred_classes"].tolist() == ref["pred_classes"].tolist() and maxdiff(x["pred_masks"].cpu(), ref["pred_masks"]) < 1e-4
+
+
+# ---- round 3: fewer launches between the decoder's GEMMs ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K,cols", [(29008, 768, 256, 512), (7252, 384, 256, 384), (5000, 576, 192, 384), (37, 768, 256, 512), (70000, 768, 256, 512)])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_linear_side_is_the_projection_of_x_plus_pos(M, N, K, cols, precision):
+    """mdqe_gemm_nt_side_f32: x W^T + b with the rank-4 side term on the first `cols` columns == the projection of (x + pos) for
+    pos = Linear(4 -> K)(box) on those columns and of x alone on the rest (float64 checker); every tile form the dispatcher picks
+    (M from 37 to 70 000 rows) and the split-precision mode, where the term is a pass of its own."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g); box = torch.rand(M, 4, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    Pw = torch.randn(K, 4, generator=g); Pb = torch.randn(K, generator=g)
+    sw = torch.zeros(N, 4, dtype=torch.float64); sw[:cols] = W[:cols].double() @ Pw.double()
+    bb = b.double().clone(); bb[:cols] += W[:cols].double() @ Pb.double()
+    ops.set_gemm_precision(precision)
+    try:
+        Wd = ops.const_weight(W.cuda())
+        out = ops.linear_side(x.cuda(), Wd, bb.float().cuda(), box.cuda(), sw.float().cuda(), cols).cpu().double()
+    finally:
+        ops.set_gemm_precision("f32")
+    pos = box.double() @ Pw.double().t() + Pb.double()
+    ref = torch.cat([(x.double() + pos) @ W[:cols].double().t() + b[:cols].double(), x.double() @ W[cols:].double().t() + b[cols:].double()], 1)
+    assert float((out - ref).abs().max() / ref.abs().max()) < (2e-6 if precision == "f32" else 8e-6)
+
+
+@pytest.mark.parametrize("Bc,T,Q", [(37, 4, 196), (3, 4, 196), (5, 1, 49), (2, 5, 100)])
+def test_box_head_refine_equals_the_two_kernel_form(Bc, T, Q):
+    """One kernel for bbox_embed's last Linear(256 -> 4) + refinement + clip boxes: the bits of rows_dot_kernel<4> followed by box_refine_kernel."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(Bc * T + Q)
+    h = torch.randn(Bc * T * Q, 256, generator=g).cuda(); w = (torch.randn(4, 256, generator=g) / 16).cuda(); b = torch.randn(4, generator=g).cuda()
+    prev = torch.rand(Bc * T * Q, 4, generator=g).cuda()
+    prev[::17] = 0.0; prev[5::23] = 1.0                                      # inverse_sigmoid's clamps
+    ct = int((T - 1) / 2)
+    t0, t1 = max(ct - 1, 0), ct + 4
+    b1, i1 = ops.box_head_refine(h, w, b, prev, Bc, T, Q, t0, t1)
+    b2, i2 = ops.box_refine(ops.linear(h, w, b), prev, Bc, T, Q, t0, t1)
+    assert torch.equal(b1, b2) and torch.equal(i1, i2)
+    ref = torch.sigmoid((h.double() @ w.double().t() + b.double()) + torch.logit(prev.double().clamp(0, 1), eps=1e-5))
+    assert float((b1.double() - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("Bc,T,Q", [(37, 4, 196), (3, 2, 196), (4, 1, 49), (2, 5, 100)])
+def test_time_fuse_dot_equals_the_two_kernel_form(Bc, T, Q):
+    """One kernel for time_weights Linear(256 -> 1) + softmax over the frames + weighted sum: the bits of rows_dot_kernel<1> + time_fuse_kernel."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(Bc + T + Q)
+    xw = torch.randn(Bc * T * Q, 256, generator=g).cuda(); src = torch.randn(Bc * T * Q, 256, generator=g).cuda()
+    wt = (torch.randn(1, 256, generator=g) / 4).cuda(); bt = torch.randn(1, generator=g).cuda()
+    a = ops.time_fuse_dot(xw, wt, bt, src, Bc, T, Q)
+    b = ops.time_fuse(ops.linear(xw, wt, bt), src, Bc, T, Q)
+    assert torch.equal(a, b)
+    p = torch.softmax((xw.double() @ wt.double().t() + bt.double()).view(Bc, T, Q), 1)
+    ref = (p[..., None] * src.double().view(Bc, T, Q, 256)).sum(1).view(Bc * Q, 256)
+    assert float((a.double() - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("config", ["R50_ovis_360", "swinl_ovis"])
+def test_decoder_with_folded_positions_equals_the_materialised_form(config):
+    """engine.DEC_FUSED: `(x + pos) W^T` as `x W^T + box (W P)^T` (one [3C, C] product for q, k, v; no position tensor; the fused box-head
+    and time-fuse kernels) against the form that materialises pos and projects q/k and v apart -- the same function up to fp32
+    reassociation: 2e-5 of the output scale on random weights, both hidden sizes (256: all fused kernels; 192: the side-term GEMM only)."""
+    from mdqe_cvpr2023_amd import engine as E
+    from mdqe_cvpr2023_amd.config import PRESETS
+    from mdqe_cvpr2023_amd.params import random_state
+    cfg = PRESETS[config]
+    sd = random_state(cfg, seed=5, remove_zero_init_trap=True)
+    eng = E.Engine(cfg, sd)
+    C, T, Q = cfg.hidden_dim, cfg.n_frames_test, cfg.n_bins ** 2
+    geo = eng.geometry(96, 160)
+    g = torch.Generator().manual_seed(1)
+    F_ = T + 3
+    cache = {"coords": torch.rand(F_, Q, 2, generator=g).cuda(), "content": torch.randn(F_, Q, C, generator=g).cuda(),
+             "emb": torch.randn(F_, Q, cfg.query_embed_dim, generator=g).cuda(),
+             "vals": torch.randn(F_, geo.N, eng.P.n_val * C, generator=g).cuda()}
+    outs = []
+    try:
+        for flag in (True, False):
+            E.DEC_FUSED = flag
+            with torch.no_grad():
+                outs.append(eng.decode_clips(cache, [0, 1, 2, 3], T, geo))
+    finally:
+        E.DEC_FUSED = True
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), k

@@ -162,3 +162,118 @@ def test_backward_contract():
         MSDA.ms_deform_attn_backward(value, shapes, st, loc, attn, go.cpu(), 64)
     with pytest.raises(RuntimeError):
         MSDA.ms_deform_attn_backward(value, shapes, st, loc.transpose(1, 2), attn, go, 64)
+
+
+# ---- float64: the reference dispatches float AND double (ms_deform_attn_cuda.cu:64,134), and two of the three checks of its own test script
+# (mdqe/models/ops/test.py) run in double.  Twins of all three checks, through the same drop-in module.
+
+class MSDeformAttnFunction(torch.autograd.Function):
+    """What mdqe/models/ops/functions/ms_deform_attn_func.py:22-42 wraps around the extension's two exports (kept by the reference; the
+    drop-in replaces only the extension module it imports)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+        import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+        ctx.im2col_step = im2col_step
+        output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+        value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = ctx.saved_tensors
+        grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
+            value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+def test_reference_known_answer_double():
+    """check_forward_equal_with_pytorch_double (ops/test.py:32-44): the op in float64 on the script's own draw (seed 3) against the
+    reference's PyTorch core run in double (fixture `double_out`, produced by executing the reference) -- `torch.allclose` with its
+    default tolerances, as the script asks; and 1e-12 on top."""
+    fx = Fixture("msda_reftest")
+    sh = torch.as_tensor(fx.shapes(), dtype=torch.int64).cuda()
+    st = fx.t("level_start").cuda()
+    args = [fx.t(k).double().cuda() for k in ("double_value", "double_loc", "double_attn")]
+    out = MSDeformAttnFunction.apply(args[0], sh, st, args[1], args[2], 2).detach().cpu()
+    ref = fx.t("double_out")
+    assert out.dtype == torch.float64 and ref.dtype == torch.float64
+    assert torch.allclose(out, ref)
+    assert maxdiff(out, ref) < 1e-12 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", ["enc", "dec_spatial", "dec_temporal", "swin_d24", "tiny_d8"])
+def test_golden_cases_double(case):
+    """The path-shaped cases in float64: against the oracle run in double (1e-12) and against the reference-run fp32 golden (2e-5)."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    fx = Fixture("msda_cases")
+    v, loc, at = (fx.t(f"{case}::{k}").double() for k in ("value", "loc", "attn"))
+    shapes, starts = fx.shapes(f"{case}::shapes"), fx.t(f"{case}::level_start")
+    out = MSDA.ms_deform_attn_forward(v.cuda(), torch.as_tensor(shapes, dtype=torch.int64).cuda(), starts.cuda(), loc.cuda(), at.cuda(), 64).cpu()
+    ref = O.msda_forward(v, shapes, starts.tolist(), loc, at)
+    assert out.dtype == torch.float64
+    assert maxdiff(out, ref) < 1e-12 * max(1.0, float(ref.abs().max()))
+    assert maxdiff(out.float(), fx.t(f"{case}::out")) < 2e-5
+
+
+@pytest.mark.parametrize("case", ["enc", "dec", "swin_d24", "tiny_d8"])
+def test_backward_double_vs_float64_autograd(case):
+    """ms_deform_attn_backward in float64 (double atomics) against float64 autograd through the oracle's restatement of the reference's
+    PyTorch core (itself pinned to the reference): 1e-10; and against the reference-run gradients of the fixture."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    fx = Fixture("msda_backward")
+    g = lambda k: fx.t(f"{case}::{k}")
+    v, loc, at, go = (g(k).double() for k in ("value", "loc", "attn", "grad_out"))
+    shapes, starts = fx.shapes(f"{case}::shapes"), g("level_start")
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v.cuda(), torch.as_tensor(shapes, dtype=torch.int64).cuda(), starts.cuda(), loc.cuda(), at.cuda(), go.cuda(), 64)
+    with torch.enable_grad():
+        v_, l_, a_ = (t.clone().requires_grad_(True) for t in (v, loc, at))
+        O.msda_forward(v_, shapes, starts.tolist(), l_, a_).backward(go)
+    for got, want, name in ((gv, v_.grad, "grad_value"), (gl, l_.grad, "grad_loc"), (ga, a_.grad, "grad_attn")):
+        scale = max(1.0, float(want.abs().max()))
+        assert got.dtype == torch.float64 and got.shape == want.shape
+        assert maxdiff(got.cpu(), want) <= 1e-10 * scale, (case, name, maxdiff(got.cpu(), want))
+        assert maxdiff(got.cpu().float(), g(name)) <= 3e-5 * scale
+
+
+@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025, 2048, 3096])
+def test_gradient_numerical_like_the_reference(channels):
+    """check_gradient_numerical (ops/test.py:63-86), every channel count of its `__main__`: `torch.autograd.gradcheck` of the autograd
+    function around the two exports, double inputs, the script's shapes (N, M = 1, 2; Lq, L, P = 2, 2, 2; levels 6x4 and 3x2)."""
+    from torch.autograd import gradcheck
+    N, M = 1, 2
+    Lq, L, P = 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    level_start_index = torch.cat((shapes.new_zeros((1, )), shapes.prod(1).cumsum(0)[:-1]))
+    S = sum([(H * W).item() for H, W in shapes])
+    torch.manual_seed(3)
+    value = torch.rand(N, S, M, channels).cuda() * 0.01
+    sampling_locations = torch.rand(N, Lq, M, L, P, 2).cuda()
+    attention_weights = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
+    attention_weights /= attention_weights.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    im2col_step = 2
+    value.requires_grad = True
+    sampling_locations.requires_grad = True
+    attention_weights.requires_grad = True
+    # (the three biggest channel counts use gradcheck's fast mode -- one random projection instead of a perturbation per element,
+    # 10^5 forward launches otherwise; the small ones run the full element-wise check the script runs)
+    assert gradcheck(MSDeformAttnFunction.apply, (value.double(), shapes, level_start_index, sampling_locations.double(), attention_weights.double(), im2col_step),
+                     fast_mode=channels > 100)
+
+
+def test_dtype_contract():
+    """float and double only, all floating operands alike -- anything else raises RuntimeError like AT_DISPATCH_FLOATING_TYPES."""
+    import mdqe_cvpr2023_amd.MultiScaleDeformableAttention as MSDA
+    sh = torch.tensor([[3, 4]], dtype=torch.int64).cuda(); st = torch.tensor([0], dtype=torch.int64).cuda()
+    v = torch.randn(1, 12, 2, 4).cuda(); loc = torch.rand(1, 3, 2, 1, 2, 2).cuda(); at = torch.rand(1, 3, 2, 1, 2).cuda()
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v.half(), sh, st, loc.half(), at.half(), 64)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v.double(), sh, st, loc, at, 64)                       # mixed
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_backward(v.double(), sh, st, loc.double(), at.double(), torch.randn(1, 3, 8).cuda(), 64)
+    o32 = MSDA.ms_deform_attn_forward(v, sh, st, loc, at, 64)
+    o64 = MSDA.ms_deform_attn_forward(v.double(), sh, st, loc.double(), at.double(), 64)
+    assert o32.dtype == torch.float32 and o64.dtype == torch.float64 and maxdiff(o32.cpu().double(), o64.cpu()) < 1e-5

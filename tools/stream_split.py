@@ -44,3 +44,11 @@ with torch.no_grad():
     print("frame stages alone   %.1f ms / 120 frames" % timed(frames_only))
     print("clip stages alone    %.1f ms / 120 frames" % timed(clips_only))
     print("full pipeline        %.1f ms / 120 frames" % timed(full))
+    # round 3: the decoder with folded positions / fused box-head + time-fuse kernels (engine.DEC_FUSED) against the round-2 form,
+    # alternated in one process
+    from mdqe_cvpr2023_amd import engine as E
+    for rep in range(3):
+        for flag in (False, True):
+            E.DEC_FUSED = flag
+            print("DEC_FUSED=%d  clip stages alone %.2f ms   full pipeline %.2f ms" % (flag, timed(clips_only, 6), timed(full, 6)), flush=True)
+    E.DEC_FUSED = True
