@@ -298,7 +298,7 @@ def main():
                          "encoder tokens + mask features (one grouped send/recv per rank and round) instead of recomputing them "
                          "(bit-identical; opt-in until it has been measured on a multi-GPU node)")
     ap.add_argument("--no-fast-mode", action="store_true",
-                    help="skip the extra passes reported beside the headline (`stream_mode`, `fast_mode`, `init_reference`, `merge_on_cpu_alt`, `frames_resident`)")
+                    help="skip the extra passes reported beside the headline (`stream_mode`, `fast_mode`, `init_reference`, `late_masks`, `frames_resident`)")
     ap.add_argument("--config", choices=["R50_ovis_360", "R50_ovis_720", "swinl_ovis"], default="R50_ovis_360",
                     help="R50_ovis_360 is BASELINE.json's metric config; R50_ovis_720 = 640x1138 frames (configs[2]); "
                          "swinl_ovis = SwinV2-L, 480x853 frames, 2-frame clips (configs[3])")
@@ -472,12 +472,11 @@ def main():
             d, _ = timed(args.precision, False, resident=res)
             extra["frames_resident"] = dict(rate(d), what="the same steps with the video already in HBM (no host->device copy in the step)")
             del res
-            model.merge_on_cpu = not cfg.merge_on_cpu
+            model.early_masks = False
             d, _ = timed(args.precision, False)
-            model.merge_on_cpu = None
-            extra["merge_on_cpu_alt"] = dict(rate(d), merge_on_cpu=not cfg.merge_on_cpu,
-                                            what="MODEL.MDQE.MERGE_ON_CPU flipped (the headline uses the config's own value): True = each window's final masks "
-                                                 "leave the device when the window is flushed, False = one pass + one copy at the end of the video")
+            model.early_masks = True
+            extra["late_masks"] = dict(rate(d), what="final masks in one pass + one device->host copy after the last window (the round-2 behaviour "
+                                                     "of MERGE_ON_CPU = False configs) instead of per flushed window under the later windows' compute")
             if args.init == "workload":
                 sd_ref = random_state(cfg, seed=0, remove_zero_init_trap=False)
                 m_ref = MDQE(cfg, state_dict=sd_ref).eval()
@@ -511,7 +510,7 @@ def main():
                        "instances_out": len(out["pred_scores"]),
                        "tracked_instances": len(set(m.data_ptr() for m in out["pred_masks"])) if "pred_masks" in out else None,
                        "output": "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
-                       "merge_on_cpu": bool(cfg.merge_on_cpu) if not sharded else True,     # (sharded videos stream their windows out: sharding._Job)
+                       "merge_on_cpu": bool(cfg.merge_on_cpu), "early_masks": bool(model.early_masks),
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
                        "ranks_seen": ranks_seen, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,

@@ -410,10 +410,160 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
   }
 }
 
+// ---- temporal form (decoder instance level, transformer_dec.py:378-390 -> ms_deform_attn.py:172-236): every (clip, query, head) takes
+// F frames x P points, each looked up on ALL G levels of its frame and averaged (scale = 1/G).  The four frames' coarse levels do not
+// fit the LDS together (4 x 38 KB at 360p), so the block walks the frames: stage frame f's coarse levels [LS, G) of its head, take
+// the P points of frame f on the G levels (16 look-ups, the staged half of them through ds_read_b128), next frame -- the accumulator
+// stays in registers, 2 barriers per frame.  Lane mapping of the set-up as v2 / v3 (lane j of a (query, head) group prepares look-ups
+// 2j and 2j+1 of the phase: level (2j+k) / P, point (2j+k) % P).  Sum order: frame-major (v2: level-major) -- the same value up to fp32
+// reassociation, held to v2 at 1e-5 (tests/test_kernels_gpu.py) and to the reference through the decoder goldens.
+template <int F, int P, int G, int DD, int NT>
+__global__ void __launch_bounds__(NT)
+msda_fused_tp_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
+                     const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
+                     const float* __restrict__ ref, long ref_bstride, const float* __restrict__ grid, MsdaLevels lv,
+                     int B, int M, int Q, int LS, int stage_px, int chunk, int nchunk, float scale,
+                     float* __restrict__ out, long ldout) {
+  constexpr int FP = F * P;                    // 16 (frame, point) samples share one softmax
+  constexpr int GP = G * P;                    // 16 look-ups per frame phase
+  constexpr int D = DD, HS = GP / 2;
+  static_assert(FP == 16 && GP == 16 && P == 4, "set-up lanes are wired for 16 samples of 4 points");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* stage = smem;
+  const int wave = threadIdx.x >> 6;
+  unsigned* soff = reinterpret_cast<unsigned*>(smem + (long)(stage_px + 1) * D) + wave * (8 * (HS + 1) * 4 * 2);
+  float* swgt = reinterpret_cast<float*>(soff + 8 * (HS + 1) * 4);
+  __shared__ int sH[16], sW[16], sS[16];       // [level g][frame f] as the host table: index g * F + f
+  if (threadIdx.x < 16) { sH[threadIdx.x] = lv.H[threadIdx.x]; sW[threadIdx.x] = lv.W[threadIdx.x]; sS[threadIdx.x] = lv.start[threadIdx.x]; }
+  const int nbq = M * nchunk;
+  const int b = blockIdx.x / nbq, blk = blockIdx.x % nbq;
+  if (b >= B) return;
+  const int m = blk % M, ck = blk / M;
+  const long brow = __builtin_amdgcn_readfirstlane(vidx != nullptr ? vidx[b] : b) * v_brows;
+  const long left = value_bytes - brow * ldv * 4;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(value + brow * ldv), 0, (unsigned)(left < 0xF0000000L ? left : 0xF0000000L), 0x00020000);
+  __syncthreads();
+  const int grp = (threadIdx.x >> 3) & 7, j = threadIdx.x & 7;
+  const bool chan = j * 4 < D;
+  const unsigned lane_off = chan ? (unsigned)((m * D + j * 4) * 4) : MSDA_OOB;
+  const unsigned lane_lds = chan ? (unsigned)(j * 16) : 0u;
+  const unsigned zero_row = (unsigned)(stage_px * D * 4);
+  const int q_end = min(Q, (ck + 1) * chunk);
+  for (int q0 = ck * chunk; q0 < q_end; q0 += NT / 8) {
+    const int q = q0 + (threadIdx.x >> 3);
+    const bool live = q < q_end;
+    const int qq = live ? q : q_end - 1;
+    const long t = (long)b * Q + qq;
+    // softmax over the FP logits of (query, head): lane j holds samples 2j, 2j+1 (sample = frame * P + point)
+    const f32x2 l2 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(logits + t * ldl + m * FP + 2 * j));
+    float mx = fmaxf(l2[0], l2[1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    float sm = expf(l2[0] - mx) + expf(l2[1] - mx);
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+    const float inv = 1.0f / sm;
+    const float* rp = ref + (long)b * ref_bstride + (long)qq * 4;
+    const float rx = rp[0], ry = rp[1], bw = rp[2], bh = rp[3];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < F; ++f) {
+      __syncthreads();                           // the previous frame's staged rows are no longer read
+      {                                          // stage the head's slice of levels [LS, G) of frame f: stage_px consecutive tokens
+        const int s0 = sS[LS * F + f];
+        for (int idx = threadIdx.x; idx < (stage_px + 1) * 8; idx += NT) {
+          const int px = idx >> 3, c = idx & 7;
+          if (c * 4 >= D) continue;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (px < stage_px) v = *reinterpret_cast<const f32x4*>(value + (brow + s0 + px) * ldv + m * D + c * 4);
+          *reinterpret_cast<f32x4*>(stage + (long)px * D + c * 4) = v;
+        }
+      }
+      __syncthreads();
+      // this lane's two look-ups of the phase: i = 2j + k -> level g = i / P, point p = i % P of frame f: sample s = f * P + p, whose
+      // offsets and logit are the pair (2 * (s / 2), +1) -- one 16-B and one 8-B load, L1-resident after the first frame
+      const int s_pair = f * P + ((2 * j) % P);   // even: samples s_pair (k = 0) and s_pair + 1 (k = 1)
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(offs + t * ldo + m * (2 * FP) + 2 * s_pair);
+      const f32x2 lg = *reinterpret_cast<const f32x2*>(logits + t * ldl + m * FP + s_pair);
+      u32x4 offv[2];
+      f32x4 wv[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int g = (2 * j + k) / P;
+        const int s = s_pair + k;
+        const float gx = grid[(m * FP + s) * 2], gy = grid[(m * FP + s) * 2 + 1];
+        float ox = o4[2 * k], oy = o4[2 * k + 1];
+        ox = fminf(fmaxf(ox, -bw * 8.f), bw * 8.f);
+        oy = fminf(fmaxf(oy, -bh * 8.f), bh * 8.f);
+        ox = gx * 0.5f * bw + ox;
+        oy = gy * 0.5f * bh + oy;
+        const float lx = rx + ox / 8.f, ly = ry + oy / 8.f;
+        const float aw = expf(lg[k] - mx) * inv;
+        const int H = sH[g * F + f], W = sW[g * F + f];
+        const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+        const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool h0 = in && h_low >= 0, h1 = in && h_low + 1 <= H - 1;
+        const bool w0 = w_low >= 0, w1 = w_low + 1 <= W - 1;
+        unsigned base, dW, d1, oob;
+        if (g >= LS) {
+          base = (unsigned)((sS[g * F + f] - sS[LS * F + f] + h_low * W + w_low) * (D * 4));
+          dW = (unsigned)(W * D * 4); d1 = (unsigned)(D * 4); oob = zero_row;
+        } else {
+          const long prow = sS[g * F + f] + (long)h_low * W + w_low;
+          base = (unsigned)(prow * ldv * 4);
+          dW = (unsigned)((long)W * ldv * 4); d1 = (unsigned)(ldv * 4); oob = MSDA_OOB;
+        }
+        offv[k][0] = (h0 && w0) ? base : oob;
+        offv[k][1] = (h0 && w1) ? base + d1 : oob;
+        offv[k][2] = (h1 && w0) ? base + dW : oob;
+        offv[k][3] = (h1 && w1) ? base + dW + d1 : oob;
+        wv[k][0] = hh * hw * aw; wv[k][1] = hh * lw * aw; wv[k][2] = lh * hw * aw; wv[k][3] = lh * lw * aw;
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if ((j >> 2) == half) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int slot = 2 * (j & 3) + k;
+            *reinterpret_cast<u32x4*>(soff + (grp * (HS + 1) + slot) * 4) = offv[k];
+            *reinterpret_cast<f32x4*>(swgt + (grp * (HS + 1) + slot) * 4) = wv[k];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          const int g = (half * HS + s) / P;      // compile-time
+          const u32x4 o = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + s) * 4);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + s) * 4);
+          if (g >= LS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[c] + lane_lds);
+              acc += v * w[c];
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
+              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
+              acc += v * w[c];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (chan && live) __builtin_nontemporal_store(acc * scale, reinterpret_cast<f32x4*>(out + t * ldout + m * D + j * 4));
+  }
+}
+
 static int g_msda_xcd_order = 1;   // tools/ A/B: 0 = plain block order in the fused kernel
 extern "C" int mdqe_debug_msda_xcd_order(int v) { g_msda_xcd_order = v; return MDQE_OK; }
 static int g_msda_variant = -1;    // tools/ A/B: block-to-query map (0, 1, 2) + 4 * (waves-per-SIMD hint 8 instead of none); -1 = by shape
 extern "C" int mdqe_debug_msda_variant(int v) { g_msda_variant = v; return MDQE_OK; }
+static int g_msda_tp_staged = 1;   // tools/ A/B: 0 = the decoder's temporal launch stays on v2
+extern "C" int mdqe_debug_msda_tp_staged(int v) { g_msda_tp_staged = v; return MDQE_OK; }
 static int g_msda_dec_staged = 1;  // tools/ A/B: 0 = the decoder's box-level launch stays on v2 (the encoder keeps its default)
 extern "C" int mdqe_debug_msda_dec_staged(int v) { g_msda_dec_staged = v; return MDQE_OK; }
 
@@ -486,6 +636,36 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
         else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
         else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
+        return mdqe_launch_status();
+      }
+    }
+    if ((var & 8) && g_msda_tp_staged && mode == 1 && ref_dim == 4 && G == 4 && L == 4 && P == 4 && vidx != nullptr && Q <= 4096) {
+      // temporal form: G levels of each of L frames; the table is [level g][frame f].  Needs every frame to carry the same pyramid,
+      // contiguous within the frame (level g + 1 right behind level g), so that levels [LS, G) of a frame are one run of tokens
+      bool ok = true;
+      for (int g = 0; g < G && ok; ++g)
+        for (int f = 0; f < L && ok; ++f) {
+          ok = lv.H[g * L + f] == lv.H[g * L] && lv.W[g * L + f] == lv.W[g * L];
+          if (g + 1 < G) ok = ok && lv.start[(g + 1) * L + f] == lv.start[g * L + f] + lv.H[g * L] * lv.W[g * L];
+        }
+      const int runs = (Q + 127) / 128;
+      const int chunk = (Q + runs - 1) / runs;
+      const int nt = chunk <= 64 ? 512 : chunk <= 104 ? 832 : 1024;
+      const long desc = (nt / 64) * 8L * (8 + 1) * 4 * 2 * 4;
+      int LS = G;
+      long px = 0;
+      while (ok && LS > 1 && ((px + (long)lv.H[(LS - 1) * L] * lv.W[(LS - 1) * L] + 1) * D * 4 + desc) <= 72L * 1024) { --LS; px += (long)lv.H[LS * L] * lv.W[LS * L]; }
+      if (ok && LS < G) {                        // (<= 72 KB: two blocks per CU, one stages while the other gathers)
+        const size_t smem = (size_t)((px + 1) * D * 4 + desc);
+        const long nbt = (long)B * M * runs;
+        auto launch_tp = [&](auto kern) {
+          if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) return;
+          hipLaunchKernelGGL(kern, dim3((unsigned)nbt), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
+                             ref, ref_bstride, grid, lv, B, M, Q, LS, (int)px, chunk, runs, scale, out, ldout);
+        };
+        if (nt == 1024) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 1024>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 1024>); }
+        else if (nt == 832) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 832>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 832>); }
+        else { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 512>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 512>); }
         return mdqe_launch_status();
       }
     }

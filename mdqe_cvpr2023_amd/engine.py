@@ -362,6 +362,7 @@ def box_xyxy_to_cxcywh(b):
     return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], -1)
 
 
+DEC_TWO_STREAMS = os.environ.get("MDQE_DEC_TWO_STREAMS", "1") != "0"   # instance-level chain of a decoder layer beside the next layer's box level
 DEC_FUSED = os.environ.get("MDQE_DEC_FUSED", "1") != "0"   # 0: position embedding materialised, separate q/k and v projections (A/B)
 
 
@@ -623,6 +624,38 @@ class Engine:
         vidx_sp = fidx.view(-1)                                                             # value block of (clip, frame)
         vidx_tp = self._to_dev_i32(fidx_h[:, 0])                                            # first frame of each clip
         vi = 0
+        # Two streams (DEC_TWO_STREAMS): the instance-level chain of layer l reads only what the box level of layer l has produced
+        # (x, sx) and the clip boxes of the refinement before it; the box level of layer l + 1 reads x and the new boxes, never x_inst
+        # (transformer_dec.py:415-431: `x_inst` feeds only the next layer's instance level and the heads).  So the instance chain -- 14
+        # launches on Bc*Q rows, a quarter of the box level's, which fill half the chip at best -- runs on a side stream beside the
+        # next layer's box level.  Same kernels on the same inputs: identical bits.  Tensors that cross streams are recorded with the
+        # caching allocator (a block must not be recycled while the other stream still reads it).
+        main = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
+        two = DEC_TWO_STREAMS and main is not None and len(P.dec) > 1
+        if two:
+            if getattr(self, "_inst_stream", None) is None:
+                self._inst_stream = torch.cuda.Stream(self.dev, priority=-1)
+            side = self._inst_stream
+            side.wait_stream(main)                      # x_inst, ibox and the gathers above
+            x_inst.record_stream(side)
+
+        def inst_level(L, x, sx, x_inst, ibox, vi):
+            if small:
+                fq = ops.time_fuse_dot(x, *L.time_weights, sx, Bc, T, Q)
+            else:
+                fq = ops.time_fuse(ops.linear(x, *L.time_weights), sx, Bc, T, Q)
+            if L.ta is not None:
+                pr = qproj(L.ta, fq, ibox)
+                a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * TP], pr[:, 2 * nh * TP:], ibox.view(Bc, Q, 4), lv_tp,
+                                   Bc, Q, nh, D, Tc, cfg.dec_points, mode=1, grid=P.grid_tp, groups=len(geo.shapes),
+                                   scale=1.0 / len(geo.shapes), v_brows=N, vidx=vidx_tp)
+                x_inst = ops.linear_ln(a, L.ta.wo, L.ta.bo, x_inst, *L.norm2_inst)
+            else:
+                x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=fq)
+            x_inst = ops.linear_ln(qkv(L.sai, x_inst, ibox, Bc), L.sai.wo, L.sai.bo, x_inst, *L.norm1_inst)
+            hdn = ops.linear(x_inst, *L.linear1_inst, act="gelu")
+            return ops.linear_ln(hdn, *L.linear2_inst, x_inst, *L.norm3_inst)
+
         for L in P.dec:
             # ---- box level: CA -> SA -> FFN (transformer_dec.py:415-422)
             pr = qproj(L.ca, x, boxes)
@@ -635,24 +668,26 @@ class Engine:
             hdn = ops.linear(x, *L.linear1, act="gelu")
             x = ops.linear_ln(hdn, *L.linear2, x, *L.norm3)
             # ---- instance level (transformer_dec.py:361-409)
-            if small:
-                fq = ops.time_fuse_dot(x, *L.time_weights, sx, Bc, T, Q)
-            else:
-                fq = ops.time_fuse(ops.linear(x, *L.time_weights), sx, Bc, T, Q)
+            vi_inst = vi
             if L.ta is not None:
-                pr = qproj(L.ta, fq, ibox)
-                a = ops.msda_fused(vals2[:, vi * C:(vi + 1) * C], pr[:, :2 * nh * TP], pr[:, 2 * nh * TP:], ibox.view(Bc, Q, 4), lv_tp,
-                                   Bc, Q, nh, D, Tc, cfg.dec_points, mode=1, grid=P.grid_tp, groups=len(geo.shapes),
-                                   scale=1.0 / len(geo.shapes), v_brows=N, vidx=vidx_tp)
                 vi += 1
-                x_inst = ops.linear_ln(a, L.ta.wo, L.ta.bo, x_inst, *L.norm2_inst)
+            if two:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    x_inst = inst_level(L, x, sx, x_inst, ibox, vi_inst)
+                for tns in (x, sx, ibox):
+                    tns.record_stream(side)
             else:
-                x_inst = ops.layernorm(x_inst, *L.norm2_inst, res=fq)
-            x_inst = ops.linear_ln(qkv(L.sai, x_inst, ibox, Bc), L.sai.wo, L.sai.bo, x_inst, *L.norm1_inst)
-            hdn = ops.linear(x_inst, *L.linear1_inst, act="gelu")
-            x_inst = ops.linear_ln(hdn, *L.linear2_inst, x_inst, *L.norm3_inst)
-            # ---- iterative box refinement (transformer_dec.py:492-503)
-            boxes, ibox = refine(x, boxes)
+                x_inst = inst_level(L, x, sx, x_inst, ibox, vi_inst)
+            # ---- iterative box refinement (transformer_dec.py:492-503); the boxes behind the LAST layer feed nothing at eval (the
+            # decoder's outputs are the instance queries' heads, :505-513), so that refinement is not run
+            if L is not P.dec[-1]:
+                boxes, ibox = refine(x, boxes)
+        if two:
+            main.wait_stream(side)
+            x_inst.record_stream(main)
         n = ops.layernorm(x_inst, *P.dec_norm)
         return {"cls": self._mlp(n, P.cls_embed, "sigmoid").view(Bc, Q, -1),
                 "mask_coeff": self._mlp(n, P.mask_embed, "tanh").view(Bc, Q, -1),

@@ -68,6 +68,10 @@ class MDQE(nn.Module):
         self.resize_on_device = False               # True: frames arrive at native size and get the mapper's ResizeShortestEdge here
         self.rle_output = False                     # True: forward() returns per-frame COCO RLEs ("pred_rles") instead of dense masks
         self.merge_on_cpu = None                    # None: cfg.merge_on_cpu (MODEL.MDQE.MERGE_ON_CPU); True / False override it
+        # Final masks of a tracker window leave the device when the window is flushed (pinned host buffers, copied under the later
+        # windows' compute) instead of in one pass + one 100-MB copy after the last window.  Independent of MERGE_ON_CPU, which in the
+        # reference only picks the device the window results wait on (mdqe/mdqe.py:185-186,337,354-355) and never changes an output.
+        self.early_masks = os.environ.get("MDQE_EARLY_MASKS", "1") != "0"
         self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.clip_priority = os.environ.get("MDQE_CLIP_PRIORITY", "1") != "0"       # per-clip stages on a high-priority stream
         self._work_stream = None
@@ -721,12 +725,14 @@ class ClipMerger:
         self.emit_masks = emit_masks                # False: scores / labels only (ranks > 0 of a sharded video)
         self.n_frames = n_frames                    # total frames of the video when known: enables the early mask path
         self.early = None
-        # MODEL.MDQE.MERGE_ON_CPU (mdqe/mdqe.py:185-186,354-355; True in R50_ovis_720 / swinl_ovis): where the windows' masks
-        # wait for the end of the video.  True: each window's final masks leave the device as soon as the window is flushed
-        # (pinned host buffers, copied under the later windows' compute) and the video is merged on the host; False: the
-        # windows' stride-4 logits stay on the device, final masks are produced and copied in one pass at the end.  Same
-        # outputs either way (MDQE.merge_on_cpu overrides the config value).
+        # MODEL.MDQE.MERGE_ON_CPU (mdqe/mdqe.py:185-186,337,354-355; True in R50_ovis_720 / swinl_ovis): the device the window results
+        # wait on for the end of the video -- a memory-placement switch, the outputs are the same.  Here: False keeps every flushed
+        # window's stride-4 logits in HBM until the video ends (as the reference keeps them on the GPU), True drops them once their
+        # final masks are on the host.  WHEN the final masks are produced is a separate choice (`model.early_masks`, default on for
+        # both settings since round 3: per window, under the later windows' compute; off = one pass + one copy at the end, which
+        # needs the logits and therefore keeps them whatever MERGE_ON_CPU says).
         self.merge_on_cpu = bool(model.cfg.merge_on_cpu if model.merge_on_cpu is None else model.merge_on_cpu)
+        self.early_on = bool(getattr(model, "early_masks", True))
         self.dev = model.device
         self.use_side = self.dev.type == "cuda"
         self.main = torch.cuda.current_stream(self.dev) if self.use_side else None
@@ -788,9 +794,9 @@ class ClipMerger:
                 m = m.contiguous()
                 if not self.emit_masks:
                     self.windows.append((self.f_off, None))
-                elif self.use_side and self.n_frames is not None and (self.merge_on_cpu or self.model.rle_output):
+                elif self.use_side and self.n_frames is not None and (self.early_on or self.model.rle_output):
                     self._early_masks(m)
-                    self.windows.append((self.f_off, None))
+                    self.windows.append((self.f_off, None if self.merge_on_cpu else m))
                 else:
                     self.windows.append((self.f_off, m))
                 self.f_off += m.shape[1]

@@ -224,3 +224,36 @@ def test_decoder_with_folded_positions_equals_the_materialised_form(config):
     for k in outs[0]:
         a, b = outs[0][k], outs[1][k]
         assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), k
+
+
+def test_decoder_instance_chain_on_a_side_stream_is_bit_identical():
+    """engine.DEC_TWO_STREAMS: the instance-level chain of layer l on a side stream beside the box level of layer l + 1 -- the same
+    kernels on the same inputs, so every output bit is the same; repeated calls reuse the stream and the allocator's blocks."""
+    from mdqe_cvpr2023_amd import engine as E
+    from mdqe_cvpr2023_amd.config import PRESETS
+    from mdqe_cvpr2023_amd.params import random_state
+    cfg = PRESETS["R50_ovis_360"]
+    eng = E.Engine(cfg, random_state(cfg, seed=6, remove_zero_init_trap=True))
+    C, T, Q = cfg.hidden_dim, cfg.n_frames_test, cfg.n_bins ** 2
+    geo = eng.geometry(96, 160)
+    g = torch.Generator().manual_seed(2)
+    F_ = T + 8
+    cache = {"coords": torch.rand(F_, Q, 2, generator=g).cuda(), "content": torch.randn(F_, Q, C, generator=g).cuda(),
+             "emb": torch.randn(F_, Q, cfg.query_embed_dim, generator=g).cuda(),
+             "vals": torch.randn(F_, geo.N, eng.P.n_val * C, generator=g).cuda()}
+    outs = []
+    try:
+        for flag in (True, False, True):
+            E.DEC_TWO_STREAMS = flag
+            with torch.no_grad():
+                for _ in range(3):                                  # back-to-back calls: blocks recycled across the two streams
+                    o = eng.decode_clips(cache, list(range(9)), T, geo)
+                    junk = torch.randn(1 << 22, device="cuda")      # allocator pressure between calls
+                    del junk
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        E.DEC_TWO_STREAMS = True
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all()
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k

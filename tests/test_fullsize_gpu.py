@@ -170,15 +170,15 @@ def _chain(ref, model, fh, fw):
         torch.cuda.synchronize()
         # a16-a18: tracker + window flushes + final masks on the ORACLE's clip results, both mask-merge modes
         ms = cfg.match_stride
-        for merge_on_cpu in (True, False):
-            model.merge_on_cpu = merge_on_cpu
+        for merge_on_cpu, early in ((True, True), (False, True), (False, False), (True, False)):
+            model.merge_on_cpu, model.early_masks = merge_on_cpu, early    # (early: masks per flushed window; late: one pass at the end)
             m = ClipMerger(model, (fh, fw), (fh, fw), (geo.Hp // ms, geo.Wp // ms), n_frames=len(ref["frames"]))
             m.feed_many([(s, e, l, dict(r)) for s, e, l, r in items])
             assert len(m.cls_clips) == len(ref["cls_w"])
             for a, b in zip(m.cls_clips, ref["cls_w"]):
                 assert maxdiff(a, b) < 1e-5
             _check_video(m.finish(), ref["video"])
-        model.merge_on_cpu = None
+        model.merge_on_cpu, model.early_masks = None, True
 
 
 def _direct(ref, model, fh, fw):

@@ -602,3 +602,41 @@ def test_bottleneck_conv3_and_projection_shortcut_as_one_product(NI, H2, W2, K2,
     scale = float(ref.abs().max())
     assert float((out.double() - ref).abs().max()) < 3e-6 * scale
     assert float((out - two).abs().max()) < 6e-6 * scale
+
+
+@pytest.mark.parametrize("shapes,D,Q,Bc", [([(48, 80), (24, 40), (12, 20), (6, 10)], 32, 196, 37), ([(12, 20), (6, 10), (3, 5), (2, 3)], 32, 49, 5),
+                                            ([(60, 108), (30, 54), (15, 27), (8, 14)], 24, 196, 6), ([(80, 144), (40, 72), (20, 36), (10, 18)], 32, 196, 3)])
+def test_temporal_msda_with_frame_by_frame_staging_equals_the_gather_form(shapes, D, Q, Bc):
+    """The decoder's instance-level launch (every (clip, query, head): 4 frames x 4 points, each on all 4 levels of its frame, averaged):
+    msda_fused_tp_kernel -- the block walks the frames, staging each frame's coarse levels in LDS -- against msda_fused_v2_kernel (every
+    corner through the texture path).  Frame-major instead of level-major summation: 1e-5 of the output scale.  360p / small / Swin-L
+    (D = 24) / 640p level tables (the last two stage the coarsest level only)."""
+    from mdqe_cvpr2023_amd import ops
+    from mdqe_cvpr2023_amd._lib import lib
+    g = torch.Generator(device="cuda").manual_seed(Q + D)
+    M, L, P, Tc = 8, 4, 4, 4
+    C = M * D
+    N = sum(h * w for h, w in shapes)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+    Fr = Bc + Tc - 1
+    vals = torch.randn(Fr * N, C, device="cuda", generator=g)
+    nq = 2 * M * Tc * P
+    pr = 2.0 * torch.randn(Bc * Q, 3 * M * Tc * P, device="cuda", generator=g)
+    ibox = torch.rand(Bc, Q, 4, device="cuda", generator=g) * torch.tensor([1, 1, 0.6, 0.6], device="cuda")
+    ibox[0, :5, :2] = torch.tensor([0.0, 1.0], device="cuda")                     # boxes on the frame's corners: corners outside the maps
+    grid = torch.randn(M * Tc * P * 2, device="cuda", generator=g)
+    lv_tp = ([s[0] for s in shapes for _ in range(Tc)], [s[1] for s in shapes for _ in range(Tc)], [f * N + starts[gi] for gi in range(L) for f in range(Tc)])
+    vidx = torch.arange(Bc, dtype=torch.int32, device="cuda")
+    outs = []
+    try:
+        for staged in (1, 0):
+            lib.mdqe_debug_msda_tp_staged(staged)
+            out = torch.full((Bc * Q, C), float("nan"), device="cuda")
+            ops.msda_fused(vals, pr[:, :nq], pr[:, nq:], ibox, lv_tp, Bc, Q, M, D, Tc, P, mode=1, grid=grid, groups=L, scale=0.25, v_brows=N, vidx=vidx, out=out)
+            outs.append(out)
+    finally:
+        lib.mdqe_debug_msda_tp_staged(1)
+    assert torch.isfinite(outs[0]).all() and not torch.equal(outs[0], torch.zeros_like(outs[0]))
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * float(outs[1].abs().max())

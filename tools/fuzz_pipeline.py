@@ -31,6 +31,7 @@ for it in range(first, n_cases):
     model.frame_batch = [0, 2, 5, 9][it % 4]
     model.lookahead = 1 + it % 3
     model.merge_on_cpu = bool(it % 2)
+    model.early_masks = bool((it // 2) % 2)
     trace, ref_trace = [], []
     try:
         with torch.no_grad():

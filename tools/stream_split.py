@@ -47,8 +47,12 @@ with torch.no_grad():
     # round 3: the decoder with folded positions / fused box-head + time-fuse kernels (engine.DEC_FUSED) against the round-2 form,
     # alternated in one process
     from mdqe_cvpr2023_amd import engine as E
+    from mdqe_cvpr2023_amd._lib import lib
     for rep in range(3):
-        for flag in (False, True):
-            E.DEC_FUSED = flag
-            print("DEC_FUSED=%d  clip stages alone %.2f ms   full pipeline %.2f ms" % (flag, timed(clips_only, 6), timed(full, 6)), flush=True)
-    E.DEC_FUSED = True
+        for fused, two, tp in ((False, False, 0), (True, False, 0), (True, False, 1), (True, True, 1)):
+            E.DEC_FUSED, E.DEC_TWO_STREAMS = fused, two
+            lib.mdqe_debug_msda_tp_staged(tp)
+            print("DEC_FUSED=%d TP_STAGED=%d TWO_STREAMS=%d  clip stages alone %.2f ms   full pipeline %.2f ms"
+                  % (fused, tp, two, timed(clips_only, 6), timed(full, 6)), flush=True)
+    E.DEC_FUSED, E.DEC_TWO_STREAMS = True, True
+    lib.mdqe_debug_msda_tp_staged(1)
