@@ -242,6 +242,24 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
                                        emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange))
 
 
+_HALO_GROUPS = {}
+
+
+def halo_group(dist, world):
+    """A process group (its own RCCL communicator) for the halo exchange's send/recv.  The per-round gathers run on the default group;
+    with the point-to-point traffic on a communicator of its own, the order in which a rank issues a halo exchange relative to a
+    gather can no longer pair it with the wrong operation of a peer -- RCCL matches operations per communicator, in issue order --
+    so the exchange does not depend on every rank reaching it at the same program point.  Created once per (backend, world), by all
+    ranks together (the first halo-exchange job of a process: `new_group` is itself collective)."""
+    if dist is None or not hasattr(dist, "new_group") or not dist.is_initialized():
+        return None
+    default = getattr(getattr(dist, "group", None), "WORLD", None)     # a re-initialised process group is a new object: no stale handle
+    hit = _HALO_GROUPS.get(world)
+    if hit is None or hit[0] is not default:
+        hit = _HALO_GROUPS[world] = (default, dist.new_group(ranks=list(range(world))))
+    return hit[1]
+
+
 class _Halo:
     """The halo exchange of one (rank, round): this chunk's last T-1 frames go to the right neighbour as [encoder tokens | mask
     features] (7.5 MB per frame at 360p instead of 1.1 ms of per-frame work each), the left neighbour's arrive the same way.
@@ -250,8 +268,9 @@ class _Halo:
     of two rounds.  Rank 0's left neighbour is the LAST rank of the previous round: what rank 0 receives in round q it uses in
     round q+1 (`carry`).  gloo (the 1-GPU tests) moves host copies."""
 
-    def __init__(self, dist, send_to, recv_from, dims, device, carry_src=None):
+    def __init__(self, dist, send_to, recv_from, dims, device, carry_src=None, group=None):
         self.dist, self.send_to, self.recv_from, self.dims, self.device = dist, send_to, recv_from, dims, device
+        self.group = group                         # the exchange's own communicator (halo_group); None = the default group
         self.tail_sent = False
         self.works, self.recv_buf, self.send_buf = [], None, None
         self.carry_src = carry_src                 # rank 0: the _Halo of the previous round (its message is this round's head)
@@ -266,10 +285,10 @@ class _Halo:
             k = enc_tail.shape[0]
             flat = torch.cat([enc_tail.reshape(k, -1), mf_tail.reshape(k, -1)], 1).contiguous()
             self.send_buf = flat.cpu() if self.host else flat
-            ops.append(self.dist.P2POp(self.dist.isend, self.send_buf, self.send_to))
+            ops.append(self.dist.P2POp(self.dist.isend, self.send_buf, self.send_to, self.group))
         if self.recv_from is not None:
             self.recv_buf = torch.empty(T1, N * C + Hm * Wm * M, dtype=torch.float32, device="cpu" if self.host else self.device)
-            ops.append(self.dist.P2POp(self.dist.irecv, self.recv_buf, self.recv_from))
+            ops.append(self.dist.P2POp(self.dist.irecv, self.recv_buf, self.recv_from, self.group))
         if ops:
             self.works = self.dist.batch_isend_irecv(ops)
 
@@ -321,6 +340,7 @@ class _Job:
         self.halo_carry = None                     # rank 0: the last rank's tail of the previous round
         self.halos = {}
         self.halo_dims = (geo.N, cfg.hidden_dim, mask_hw[0], mask_hw[1], cfg.mask_dim) if halo_exchange else None
+        self.halo_pg = halo_group(dist, world) if halo_exchange else None
         self.merger = self.replay = None
         if not root_only or rank == 0:
             self.merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
@@ -361,7 +381,7 @@ class _Job:
             carry_src = self.halos.get(q - 1) if g > 0 else None
         if world == 1 and self.dist is None:
             send_to = recv_from = None                 # (with a backend, one rank sends to itself: the 1-GPU RCCL rehearsal)
-        h = _Halo(self.dist, send_to, recv_from, (self.T - 1,) + self.halo_dims, self.device, carry_src=carry_src)
+        h = _Halo(self.dist, send_to, recv_from, (self.T - 1,) + self.halo_dims, self.device, carry_src=carry_src, group=self.halo_pg)
         self.halos[q] = h
         self.halos.pop(q - 2, None)
         return h
