@@ -30,9 +30,18 @@ class GemmMeter:
     """HIP-event timing of the dominant kernel (the 128x128-tile fp32 GEMM / implicit-GEMM conv) inside the timed region:
     an event pair on the launch stream around each of its launches + the launch's algorithmic FLOPs."""
 
-    def __init__(self):
+    def __init__(self, stride=5):
         self.rec = []
         self.enabled = False
+        # An event pair per launch costs the timed region 1.2 % (tools/early_late_ab.py: 746 -> 737 frames/s at 360p; a record is a
+        # barrier packet on the stream): every `stride`-th qualifying launch is timed instead.  A step has 442 of them (not a multiple
+        # of 5), so over the K steps every launch position is sampled.
+        self.stride = max(1, int(os.environ.get("MDQE_BENCH_METER_STRIDE", stride)))
+        self.count = 0
+
+    def take(self):
+        self.count += 1
+        return self.enabled and self.count % self.stride == 0
 
     def install(self):
         from mdqe_cvpr2023_amd import ops, _lib
@@ -50,7 +59,7 @@ class GemmMeter:
             def mdqe_gemm_nt_f32(self_, *a):
                 M, N, K, tile = a[6], a[7], a[8], a[16]
                 big = (tile == 1) or (tile == 0 and N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 192)
-                if not (meter.enabled and big):
+                if not (big and meter.take()):
                     return raw(*a)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -61,7 +70,7 @@ class GemmMeter:
 
             def mdqe_gemm_ln_f32(self_, *a):                  # same kernel template, LayerNorm epilogue (64x256 tile)
                 M, N, K = a[6], a[7], a[8]
-                if not (meter.enabled and ((M + 127) // 128) * ((N + 127) // 128) >= 192):
+                if not (((M + 127) // 128) * ((N + 127) // 128) >= 192 and meter.take()):
                     return raw_ln(*a)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -73,7 +82,7 @@ class GemmMeter:
             def mdqe_gemm_nt_cat2_f32(self_, *a):             # bottleneck conv3 + projection shortcut as one product (same kernel template)
                 K1, K2, NI, OH, OW, N = a[2], a[5], a[6], a[7], a[8], a[16]
                 M = NI * OH * OW
-                if not (meter.enabled and N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 192):
+                if not (N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 192 and meter.take()):
                     return raw_cat(*a)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -86,7 +95,7 @@ class GemmMeter:
                 NI, H, W, Cin, Cout, KH, KW, stride, pad, tile = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[19]   # (include/mdqe_hip.h)
                 M = NI * ((H + 2 * pad - KH) // stride + 1) * ((W + 2 * pad - KW) // stride + 1)
                 big = (tile == 1) or (tile == 0 and Cout > 64 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 192)
-                if not (meter.enabled and big):
+                if not (big and meter.take()):
                     return raw_conv(*a)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -531,6 +540,7 @@ def main():
                                 "traffic": None,
                                 "traffic_ref": "profiles/r02_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: 2 x FETCH_SIZE + WRITE_SIZE = 340 + 836 = 1175 MB per launch vs 1046 MB algorithmic = 1.12x)",
                                 "launches": g["launches"], "avg_launch_us": g["avg_us"],
+                                "sampled": "an event pair around every %d-th qualifying launch of the timed region (a pair per launch costs the region 1.2 %%)" % meter.stride,
                                 "note": "timed region: launches overlap with the clip-stream and tracker-stream kernels"}
             if g_iso:
                 line["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": g_iso["tflops"], "peak": pk,

@@ -25,6 +25,21 @@ out = torch.empty(Bf * Nq, C, device="cuda")
 nq = 2 * Mh * L * P
 COMP = Nq * (2 * C + 3 * Mh * L * P) * 4.0         # compulsory bytes per frame: value + offsets + logits + output (18.3 MB at 360p)
 run = lambda: ops.msda_fused(proj[:, :C], proj[:, C:C + nq], proj[:, C + nq:], ref, levels, Bf, Nq, Mh, D, L, P, mode=0, v_brows=Nq, out=out)
+if os.environ.get("MSDA_FORM") == "temporal":      # round 3: the decoder's instance-level launch of a 37-clip batch (msda_fused_tp_kernel; MDQE_TP_STAGED=0: v2)
+    from mdqe_cvpr2023_amd._lib import lib
+    lib.mdqe_debug_msda_tp_staged(int(os.environ.get("MDQE_TP_STAGED", "1")))
+    Bc, Q, Tc = 37, 196, 4
+    vals = torch.randn((Bc + Tc - 1) * Nq, C, generator=g).cuda()
+    pr = (2.0 * torch.randn(Bc * Q, 3 * Mh * Tc * P, generator=g)).cuda()
+    ibox = (torch.rand(Bc, Q, 4, generator=g) * torch.tensor([1, 1, 0.5, 0.5])).cuda()
+    grid = torch.randn(Mh * Tc * P * 2, generator=g).cuda()
+    lv_tp = ([s[0] for s in shapes for _ in range(Tc)], [s[1] for s in shapes for _ in range(Tc)], [f * Nq + starts[gi] for gi in range(L) for f in range(Tc)])
+    vidx = torch.arange(Bc, dtype=torch.int32).cuda()
+    out_t = torch.empty(Bc * Q, C, device="cuda")
+    nqt = 2 * Mh * Tc * P
+    # compulsory bytes of the launch: the 40 frames' value maps once + offsets / logits / output of the Bc*Q queries
+    COMP = ((Bc + Tc - 1) * Nq * C + Bc * Q * (3 * Mh * Tc * P + C)) * 4.0 / Bf
+    run = lambda: ops.msda_fused(vals, pr[:, :nqt], pr[:, nqt:], ibox, lv_tp, Bc, Q, Mh, D, Tc, P, mode=1, grid=grid, groups=L, scale=0.25, v_brows=Nq, vidx=vidx, out=out_t)
 if len(sys.argv) > 1 and sys.argv[1] == "variants":        # block-to-query maps x waves-per-SIMD hint, same box, output checked against variant 0
     from mdqe_cvpr2023_amd._lib import lib
     ref_out = None
