@@ -517,7 +517,7 @@ def main():
                                    % (args.config, args.frames, fh, fw, cfg.n_frames_test, cfg.n_frames_window_test),
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
                        "instances_out": len(out["pred_scores"]),
-                       "tracked_instances": len(set(m.data_ptr() for m in out["pred_masks"])) if "pred_masks" in out else None,
+                       "tracked_instances": getattr(model, "last_num_tracks", None),       # tracks the tracker held at the end of the video
                        "output": "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
                        "merge_on_cpu": bool(cfg.merge_on_cpu), "early_masks": bool(model.early_masks),
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,

@@ -663,6 +663,7 @@ class MDQE(nn.Module):
         from . import ops
         K = self.cfg.num_classes
         total = cls_clips[-1].shape[0]
+        self.last_num_tracks = int(total)                      # tracks of the video just merged (diagnostics; bench.py reports it)
         cc = torch.stack([torch.cat([c, c.new_zeros(total - c.shape[0], c.shape[1])]) for c in cls_clips])
         out_cls = (0.75 * cc.mean(0) + 0.25 * cc.max(0)[0]).flatten().cpu()
         k = min(max(int(out_cls.gt(0.05).sum()), 10), out_cls.numel())   # (the reference's topk(max(.,10)), :449-450, assumes >= 10 scores)
