@@ -538,7 +538,7 @@ def main():
                                 # HBM bytes need rocprofv3 --pmc passes, which cannot run inside this process: not a live figure -> null;
                                 # the per-launch counters of the dominant launch shape are in the file named below
                                 "traffic": None,
-                                "traffic_ref": "profiles/r02_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: 2 x FETCH_SIZE + WRITE_SIZE = 340 + 836 = 1175 MB per launch vs 1046 MB algorithmic = 1.12x)",
+                                "traffic_ref": "profiles/r03_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: 2 x FETCH_SIZE + WRITE_SIZE = 346 + 836 = 1182 MB per launch vs 1046 MB algorithmic = 1.13x; MFMA pipe busy 0.71 of the kernel's cycles, 0 LDS bank conflicts: r03_pmc_gemm_ffn1_SQ_BUSY_CYCLES.csv)",
                                 "launches": g["launches"], "avg_launch_us": g["avg_us"],
                                 "sampled": "an event pair around every %d-th qualifying launch of the timed region (a pair per launch costs the region 1.2 %%)" % meter.stride,
                                 "note": "timed region: launches overlap with the clip-stream and tracker-stream kernels"}
