@@ -633,9 +633,10 @@ class Engine:
         main = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
         two = DEC_TWO_STREAMS and main is not None and len(P.dec) > 1
         if two:
-            if getattr(self, "_inst_stream", None) is None:
-                self._inst_stream = torch.cuda.Stream(self.dev, priority=-1)
-            side = self._inst_stream
+            pool = self.__dict__.setdefault("_inst_streams", {})       # one side stream per launch stream (two decoders may run at once)
+            side = pool.get(main.cuda_stream)
+            if side is None:
+                side = pool[main.cuda_stream] = torch.cuda.Stream(self.dev, priority=-1)
             side.wait_stream(main)                      # x_inst, ibox and the gathers above
             x_inst.record_stream(side)
 

@@ -72,6 +72,8 @@ class MDQE(nn.Module):
         # windows' compute) instead of in one pass + one 100-MB copy after the last window.  Independent of MERGE_ON_CPU, which in the
         # reference only picks the device the window results wait on (mdqe/mdqe.py:185-186,337,354-355) and never changes an output.
         self.early_masks = os.environ.get("MDQE_EARLY_MASKS", "1") != "0"
+        self.decode_ahead = os.environ.get("MDQE_DECODE_AHEAD", "1") != "0"         # trailing short clips decoded beside the last full group
+        self._ahead_stream = None
         self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.clip_priority = os.environ.get("MDQE_CLIP_PRIORITY", "1") != "0"       # per-clip stages on a high-priority stream
         self._work_stream = None
@@ -281,6 +283,7 @@ class MDQE(nn.Module):
                     if free_ev[slot] is not None:
                         fstream.wait_event(free_ev[slot])
                 base, count = ls, 0
+                nxt_before = nxt
                 if prev is not None:                               # carry frames [ls, prev end) -- never more than T-1
                     keep = prev["base"] + prev["count"] - ls
                     if keep > 0:
@@ -324,7 +327,7 @@ class MDQE(nn.Module):
                 if cuda:
                     ready = torch.cuda.Event()
                     ready.record(fstream)
-            return {"slot": slot, "base": base, "count": count, "ready": ready, "covered": nxt,
+            return {"slot": slot, "base": base, "count": count, "ready": ready, "covered": nxt, "new_frames": nxt - nxt_before,
                     "cache": {k: v[:count] for k, v in rings[slot].items()}}
 
         def frames_queued():
@@ -409,7 +412,28 @@ class MDQE(nn.Module):
                 starts = starts + [cnt + c[0] - (frame_offset - (Tn - 1)) for c in strad]
                 group = group + strad
                 strad = []
-            outs = eng.decode_clips(cache, starts, T, geo)
+            outs = cur.pop("outs", None)
+            if outs is None:
+                outs = eng.decode_clips(cache, starts, T, geo)
+            elif cuda:
+                clip_stream.wait_stream(self._ahead_stream)        # decoded ahead (below) on the auxiliary stream
+                for v in outs.values():
+                    v.record_stream(clip_stream)
+            # Decode-ahead: a following group that needs NO new frame pass -- the short clips at the end of a video, whose frames the
+            # last pass has already produced -- is decoded now, on an auxiliary stream beside this group's decoder, instead of after
+            # this group's inference_clip syncs and tracker run.  Both decoders are chains of small dependent launches (latency-bound
+            # at these sizes), so the second one is nearly free: the tail of a 120-frame video drops by the 2.6 ms the lone 3-frame
+            # clip took (tools/tail_time.py).  Same kernels, same inputs, same bits.
+            nx = states[0] if states else None
+            if (cuda and self.decode_ahead and nx is not None and nx["new_frames"] == 0 and not strad and trace is None
+                    and "outs" not in nx):
+                if self._ahead_stream is None:
+                    self._ahead_stream = torch.cuda.Stream(frames_dev.device, priority=-1)
+                aux = self._ahead_stream
+                aux.wait_event(nx["ready"])                        # its frames (the pass this group waits for too) + its ring's carried rows
+                with torch.cuda.stream(aux):
+                    g2 = clips[nx["i"]:nx["j"]]
+                    nx["outs"] = eng.decode_clips(nx["cache"], [c[0] - frame_offset - nx["base"] for c in g2], nx["T"], geo)
             ress = eng.inference_clips(outs, cache["mf"], starts, T)
             ready = None
             if cuda:

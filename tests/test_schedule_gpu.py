@@ -237,3 +237,21 @@ def test_clip_stride_larger_than_the_clip_vs_oracle():
         assert out["pred_labels"] == ref["pred_labels"]
         got, want = torch.stack(out["pred_masks"]), torch.stack(ref["pred_masks"])
         assert got.shape == want.shape and (got != want).float().mean() < 2e-3
+
+
+def test_decode_ahead_of_trailing_short_clips_is_bit_identical():
+    """MDQE.decode_ahead: the short clips at the end of a video (no new frame pass needed) are decoded on an auxiliary stream beside the
+    last full-length group instead of after its tracker run -- same kernels, same inputs: identical outputs; videos whose length leaves
+    1, 2 and 3 trailing short clips (stride 1: one; stride 2 / other lengths: none), repeated calls."""
+    cfg, model = _small_model()
+    for L in (17, 9, 6, 5):
+        frames = _video(L).cuda()
+        inp = [{"image": frames, "height": 96, "width": 160}]
+        model.decode_ahead = True
+        a = model(inp)
+        a2 = model(inp)
+        model.decode_ahead = False
+        b = model(inp)
+        model.decode_ahead = True
+        _same(a, b)
+        _same(a, a2)
