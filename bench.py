@@ -233,7 +233,7 @@ def cpu_baseline(cfg, sd, frames4):
             if with_recompute:
                 enc1, mask1, shapes1, mf1 = O.frame_features(sd, hp, x1, sizes1, bb)         # as-reference: window of clip 1 again
             else:
-                enc1, mask1, shapes1, mf1 = enc[1:], mask[1:], shapes, mf[1:]
+                enc1, mask1, shapes1, mf1 = enc[1:], mask[1:], shapes, mf[:, 1:]     # (mask features are [M, T, h, w])
             t.append(time.time() - t0 if with_recompute else None); t0 = time.time()
             O.inference_clip(hp, O.transformer_dec(sd, hp, enc1, mask1, shapes1), mf1)
             t.append(time.time() - t0)

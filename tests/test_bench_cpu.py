@@ -77,3 +77,17 @@ def test_host_cpu_reports_model_and_physical_cores():
     from bench import host_cpu
     model, phys, logical = host_cpu()
     assert isinstance(model, str) and model and 1 <= phys <= logical
+
+
+def test_cpu_baseline_runs_and_reports_cores_and_model():
+    """bench.cpu_baseline on configs[0] (4 synthetic 360p frames through the oracle, both schedules, two thread counts): the leg the
+    driver's bench line carries -- it must not be able to break unnoticed (it runs last in bench.py, after minutes of GPU work)."""
+    from bench import cpu_baseline, synth_video
+    from mdqe_cvpr2023_amd.config import PRESETS
+    from mdqe_cvpr2023_amd.params import random_state
+    cfg = PRESETS["R50_ovis_360"]
+    sd = random_state(cfg, seed=0, remove_zero_init_trap=True)
+    r = cpu_baseline(cfg, sd, synth_video(0, 4, seed=0))
+    assert r["kind"] == "port" and r["unit"] == "frames/s" and r["value"] > 0 and 1 <= r["cores"] <= r["physical_cores"] <= r["logical_cpus"]
+    assert r["cpu_model"] and len(r["threads_tried"]) >= 1 and abs(max(r["threads_tried"].values()) - r["value"]) < 1e-3
+    assert 0 < r["as_reference"]["value"] < r["value"]           # the reference's window recompute costs three more frame passes
