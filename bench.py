@@ -208,8 +208,9 @@ def cpu_baseline(cfg, sd, frames4):
     reference's own schedule -- clips (0,4) and (1,4); the per-frame stages (backbone + encoder + mask head) are re-run on the
     remaining window for every clip (`window_end_idx` never advances, mdqe/mdqe.py:302,314).  The four parts are timed
     separately, so the compute-once schedule (the second clip reuses the first clip's frame features) is the same run minus
-    the recompute.  `value` = compute-once, at the better of {physical cores, physical cores / 2} torch threads (more threads
-    than physical cores oversubscribe the oracle's GEMMs and would handicap the baseline)."""
+    the recompute.  `value` = compute-once, at the best of {physical cores, half, (a quarter on hosts with >= 64 cores)} torch threads: more
+    threads than physical cores oversubscribe the oracle's GEMMs, and on a two-socket host half the cores beat all of them (0.325 against
+    0.162 frames/s on 2 x EPYC 9575F) -- the baseline is never the target, but it should not be handicapped."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mdqe_oracle as O
     hp = O.Hyper()
@@ -218,7 +219,8 @@ def cpu_baseline(cfg, sd, frames4):
     model_name, n_phys, n_logical = host_cpu()
     before = torch.get_num_threads()
 
-    def once(n, with_recompute):
+    def once(n):
+        """Compute-once schedule at n torch threads: [per-frame stages x4, decoder + inference_clip of clip 0, of clip 1 (3 frames)]."""
         torch.set_num_threads(n)
         t = []
         with torch.no_grad():
@@ -229,35 +231,38 @@ def cpu_baseline(cfg, sd, frames4):
             t.append(time.time() - t0); t0 = time.time()
             O.inference_clip(hp, O.transformer_dec(sd, hp, enc, mask, shapes), mf)
             t.append(time.time() - t0); t0 = time.time()
-            x1, sizes1 = O.pad_frames(video[1:], 32)
-            if with_recompute:
-                enc1, mask1, shapes1, mf1 = O.frame_features(sd, hp, x1, sizes1, bb)         # as-reference: window of clip 1 again
-            else:
-                enc1, mask1, shapes1, mf1 = enc[1:], mask[1:], shapes, mf[:, 1:]     # (mask features are [M, T, h, w])
-            t.append(time.time() - t0 if with_recompute else None); t0 = time.time()
-            O.inference_clip(hp, O.transformer_dec(sd, hp, enc1, mask1, shapes1), mf1)
+            O.inference_clip(hp, O.transformer_dec(sd, hp, enc[1:], mask[1:], shapes), mf[:, 1:])     # (mask features are [M, T, h, w])
             t.append(time.time() - t0)
         return t
 
-    runs = {n_phys: once(n_phys, True)}
-    if n_phys >= 2:
-        runs[n_phys // 2] = once(n_phys // 2, False)
-    torch.set_num_threads(before)
-    tot = {n: t[0] + t[1] + t[3] for n, t in runs.items()}
+    def recompute(n):
+        """What the reference's schedule adds for the second clip: the per-frame stages of its window (frames 1..3) again."""
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            video = O.preprocess(hp, frames)
+            t0 = time.time()
+            x1, sizes1 = O.pad_frames(video[1:], 32)
+            O.frame_features(sd, hp, x1, sizes1, bb)
+            return time.time() - t0
+
+    cand = [n_phys] + ([n_phys // 2] if n_phys >= 2 else []) + ([n_phys // 4] if n_phys >= 64 else [])      # (big two-socket hosts: a quarter can win)
+    runs = {n: once(n) for n in cand}
+    tot = {n: sum(t) for n, t in runs.items()}
     best = min(tot, key=tot.get)
     t = runs[best]
-    tr = runs[n_phys]
-    asref = tr[0] + tr[1] + tr[2] + tr[3]
+    t_re = recompute(best)
+    torch.set_num_threads(before)
+    asref = tot[best] + t_re
     return {"value": 4.0 / tot[best], "unit": "frames/s", "cores": best, "kind": "port",
             "cpu_model": model_name, "physical_cores": n_phys, "logical_cpus": n_logical,
             "threads_tried": {str(n): round(4.0 / v, 4) for n, v in sorted(tot.items())},
             "sample": "oracle/mdqe_oracle.py on configs[0]: one video of 4 synthetic 360x640 frames = clips (0,4) and (1,4); "
-                      "compute-once schedule on %d torch threads (%s, %d physical cores): per-frame stages x4 frames (%.1f s) + 2 decoder/"
-                      "inference_clip passes (%.1f + %.1f s)" % (best, model_name, n_phys, t[0], t[1], t[3]),
-            "as_reference": {"value": 4.0 / asref, "unit": "frames/s", "cores": n_phys,
+                      "compute-once schedule on %d torch threads (%s, %d physical cores; best of %s): per-frame stages x4 frames (%.1f s) + 2 decoder/"
+                      "inference_clip passes (%.1f + %.1f s)" % (best, model_name, n_phys, "/".join(str(n) for n in cand), t[0], t[1], t[2]),
+            "as_reference": {"value": 4.0 / asref, "unit": "frames/s", "cores": best,
                              "what": "the same video in the reference's schedule: the window's per-frame stages are recomputed for the "
                                      "second clip (+3 frames, %.1f s); on the bench's 120-frame video that schedule runs 3540 frame "
-                                     "passes instead of 120" % tr[2]}}
+                                     "passes instead of 120" % t_re}}
 
 
 def spawn_ranks(n, rehearsal):
