@@ -333,6 +333,15 @@ def main():
         # is passed on.
         sys.exit(spawn_ranks(args.gpus, one_dev or probe))
 
+    # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints a five-line version banner
+    # there when a communicator is created, gloo its connection messages) are sent to stderr for the rest of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(json_fd, (line + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -371,7 +380,7 @@ def main():
             sys.exit(2)
         if probe:
             if rank == 0:
-                print(json.dumps({"probe": True, "n_gpus": world, "ranks_seen": ranks_seen, "backend": dist.get_backend()}))
+                emit(json.dumps({"probe": True, "n_gpus": world, "ranks_seen": ranks_seen, "backend": dist.get_backend()}))
             dist.destroy_process_group()
             return
 
@@ -555,7 +564,7 @@ def main():
         line.update(extra)
         if not sharded and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
-        print(json.dumps(line))
+        emit(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 

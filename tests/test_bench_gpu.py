@@ -45,8 +45,8 @@ def test_bench_gpus_2_runs_two_ranks_without_torchrun():
         env.update(MDQE_BENCH_BACKEND="gloo", MDQE_BENCH_ONE_DEVICE="1")
     r = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]     # nothing but the JSON line on stdout (gloo / RCCL banners -> stderr)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["frames_per_gpu"] == 24 and d["scaling"] == "weak"
     assert abs(d["value"] - 48 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]              # whole-job frames / max-over-ranks time
