@@ -566,7 +566,7 @@ class Engine:
         out = self.decode_clips({"coords": coords, "content": content, "emb": emb, "vals": values}, [0], T, geo)
         return {k: v[0] for k, v in out.items()}
 
-    def decode_clips(self, cache, starts, T, geo):
+    def decode_clips(self, cache, starts, T, geo, two_streams=True):
         """Decoder for a BATCH of clips that all have T frames (clips are independent through a11-a14).
         cache: per-frame tensors of one chunk (coords/content/emb/vals, leading dim = frames); starts: first frame
         (index into the cache) of each clip.  Returns cls [B,Q,K], mask_coeff [B,Q,M], query_embed [B,Q,C].
@@ -628,17 +628,20 @@ class Engine:
         # (x, sx) and the clip boxes of the refinement before it; the box level of layer l + 1 reads x and the new boxes, never x_inst
         # (transformer_dec.py:415-431: `x_inst` feeds only the next layer's instance level and the heads).  So the instance chain -- 14
         # launches on Bc*Q rows, a quarter of the box level's, which fill half the chip at best -- runs on a side stream beside the
-        # next layer's box level.  Same kernels on the same inputs: identical bits.  Tensors that cross streams are recorded with the
-        # caching allocator (a block must not be recycled while the other stream still reads it).
+        # next layer's box level.  Same kernels on the same inputs: identical bits.
         main = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
-        two = DEC_TWO_STREAMS and main is not None and len(P.dec) > 1
+        two = DEC_TWO_STREAMS and two_streams and main is not None and len(P.dec) > 1
         if two:
             pool = self.__dict__.setdefault("_inst_streams", {})       # one side stream per launch stream (two decoders may run at once)
             side = pool.get(main.cuda_stream)
             if side is None:
                 side = pool[main.cuda_stream] = torch.cuda.Stream(self.dev, priority=-1)
             side.wait_stream(main)                      # x_inst, ibox and the gathers above
-            x_inst.record_stream(side)
+            # Tensors that cross the two streams are kept alive in `hold` until the streams have joined at the end of this call,
+            # instead of being recorded with the caching allocator: a block freed after the join is recycled on its own stream behind
+            # the join.  (`record_stream` on ~20 tensors per call leaves that many pending events for the allocator to poll on every
+            # later allocation -- with the sharded schedule's replay thread allocating too it cost 25 ms per 120 frames.)
+            hold = [x_inst]
 
         def inst_level(L, x, sx, x_inst, ibox, vi):
             if small:
@@ -678,8 +681,7 @@ class Engine:
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
                     x_inst = inst_level(L, x, sx, x_inst, ibox, vi_inst)
-                for tns in (x, sx, ibox):
-                    tns.record_stream(side)
+                hold += [x, sx, ibox]
             else:
                 x_inst = inst_level(L, x, sx, x_inst, ibox, vi_inst)
             # ---- iterative box refinement (transformer_dec.py:492-503); the boxes behind the LAST layer feed nothing at eval (the
@@ -687,8 +689,8 @@ class Engine:
             if L is not P.dec[-1]:
                 boxes, ibox = refine(x, boxes)
         if two:
-            main.wait_stream(side)
-            x_inst.record_stream(main)
+            main.wait_stream(side)                      # (x_inst lives in the side stream's pool; the next call's side work starts behind
+            del hold                                    #  `side.wait_stream(main)` above, i.e. behind everything that reads it on main)
         n = ops.layernorm(x_inst, *P.dec_norm)
         return {"cls": self._mlp(n, P.cls_embed, "sigmoid").view(Bc, Q, -1),
                 "mask_coeff": self._mlp(n, P.mask_embed, "tanh").view(Bc, Q, -1),

@@ -229,7 +229,7 @@ class MDQE(nn.Module):
         return clips
 
     def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None, h2d=None,
-                          halo=None):
+                          halo=None, side_streams=True):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
@@ -414,7 +414,11 @@ class MDQE(nn.Module):
                 strad = []
             outs = cur.pop("outs", None)
             if outs is None:
-                outs = eng.decode_clips(cache, starts, T, geo)
+                # side_streams=False (the sharded schedule): HIP multiplexes its streams onto 4 hardware queues, and with RCCL's stream
+                # and the replay thread's tracker stream in play the decoder's instance-chain stream lands on a queue behind the frame
+                # stream's long GEMMs -- 616 against 708 frames/s per rank (tools/hwq_ab2.sh; GPU_MAX_HW_QUEUES=8 recovers most of it,
+                # 697, but costs the single-GPU path 1.6 %)
+                outs = eng.decode_clips(cache, starts, T, geo, two_streams=side_streams)
             elif cuda:
                 clip_stream.wait_stream(self._ahead_stream)        # decoded ahead (below) on the auxiliary stream
                 for v in outs.values():
@@ -425,7 +429,7 @@ class MDQE(nn.Module):
             # at these sizes), so the second one is nearly free: the tail of a 120-frame video drops by the 2.6 ms the lone 3-frame
             # clip took (tools/tail_time.py).  Same kernels, same inputs, same bits.
             nx = states[0] if states else None
-            if (cuda and self.decode_ahead and nx is not None and nx["new_frames"] == 0 and not strad and trace is None
+            if (cuda and self.decode_ahead and side_streams and nx is not None and nx["new_frames"] == 0 and not strad and trace is None
                     and "outs" not in nx):
                 if self._ahead_stream is None:
                     self._ahead_stream = torch.cuda.Stream(frames_dev.device, priority=-1)

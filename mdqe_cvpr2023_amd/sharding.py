@@ -364,7 +364,9 @@ class _Job:
         kw = {"h2d": h2d} if h2d else {}
         if self.halo_exchange:
             kw["halo"] = self._halo(q, g)
-        gen = self.model.iter_clip_results(fr, self.plan[g][0], self.plan[g][1], primed=True, **kw)
+        # (no side streams inside the decoder here: the sharded schedule already runs RCCL's stream and the replay thread's tracker
+        # stream beside the frame / clip / copy streams, and HIP has 4 hardware queues for all of them -- meta_arch.iter_clip_results)
+        gen = self.model.iter_clip_results(fr, self.plan[g][0], self.plan[g][1], primed=True, side_streams=False, **kw)
         next(gen)
         return gen
 
