@@ -69,6 +69,7 @@ SIGNATURES = {
     "mdqe_debug_msda_dec_staged": [i],
     "mdqe_debug_msda_op_staged": [i],
     "mdqe_debug_msda_tp_staged": [i],
+    "mdqe_debug_msda_stage_kb": [i],
     "mdqe_debug_msda_variant": [i],
     "mdqe_mask_row_stats_f32": [p, i, i, i, i, i, p, p, p, p],
     "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p, i, p, p],

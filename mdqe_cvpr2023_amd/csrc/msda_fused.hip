@@ -562,6 +562,8 @@ static int g_msda_xcd_order = 1;   // tools/ A/B: 0 = plain block order in the f
 extern "C" int mdqe_debug_msda_xcd_order(int v) { g_msda_xcd_order = v; return MDQE_OK; }
 static int g_msda_variant = -1;    // tools/ A/B: block-to-query map (0, 1, 2) + 4 * (waves-per-SIMD hint 8 instead of none); -1 = by shape
 extern "C" int mdqe_debug_msda_variant(int v) { g_msda_variant = v; return MDQE_OK; }
+static int g_msda_stage_kb = 150;  // tools/ A/B: LDS budget (KB) of the levels staged by msda_fused_v3_kernel (how many coarse levels a block takes)
+extern "C" int mdqe_debug_msda_stage_kb(int v) { g_msda_stage_kb = v > 0 ? v : 150; return MDQE_OK; }
 static int g_msda_tp_staged = 1;   // tools/ A/B: 0 = the decoder's temporal launch stays on v2
 extern "C" int mdqe_debug_msda_tp_staged(int v) { g_msda_tp_staged = v; return MDQE_OK; }
 static int g_msda_dec_staged = 1;  // tools/ A/B: 0 = the decoder's box-level launch stays on v2 (the encoder keeps its default)
@@ -616,7 +618,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
       const long desc = (nt / 64) * 8L * (8 + 1) * 4 * 2 * 4;
       int LS = L;
       long px = 0;
-      while (LS > 1 && ((px + (long)lv.H[LS - 1] * lv.W[LS - 1] + 1) * D * 4 + desc) <= 150L * 1024) { --LS; px += (long)lv.H[LS] * lv.W[LS]; }
+      while (LS > 1 && ((px + (long)lv.H[LS - 1] * lv.W[LS - 1] + 1) * D * 4 + desc) <= (long)g_msda_stage_kb * 1024) { --LS; px += (long)lv.H[LS] * lv.W[LS]; }
       if (LS < L) {
         const size_t smem = (size_t)((px + 1) * D * 4 + desc);
         // queries per block, by what a block stages (tools/pmc_msda.py variants, us per launch): 38 KB (360p, 40 frames) 128: 380,

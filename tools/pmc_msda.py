@@ -8,6 +8,11 @@ g = torch.Generator().manual_seed(0)
 Bf, Mh, D, L, P = 40, 8, 32, 4, 4
 shapes = [(48, 80), (24, 40), (12, 20), (6, 10)]
 GEO = os.environ.get("MSDA_GEO", "360p")          # 360p (default) | 640p (R50_ovis_720, 20-frame passes) | swinl (480x864, D = 24)
+if os.environ.get("MSDA_STAGE_KB"):                # LDS budget of the staged levels (how many coarse levels a block takes)
+    from mdqe_cvpr2023_amd._lib import lib as _l
+    _l.mdqe_debug_msda_stage_kb(int(os.environ["MSDA_STAGE_KB"]))
+if GEO == "240p":                                  # a geometry whose level 1 fits the LDS beside levels 2 + 3: what staging THREE levels buys
+    Bf, shapes = 80, [(30, 52), (15, 26), (8, 13), (4, 7)]
 if GEO == "640p":
     Bf, shapes = 20, [(80, 144), (40, 72), (20, 36), (10, 18)]
 elif GEO == "swinl":
