@@ -368,3 +368,58 @@ def test_chunk_plan_properties_on_random_inputs():
             for cl, f0, f1 in hp:
                 assert f1 - f0 >= T or len(hp) == 1
                 assert all(f0 <= e - 1 < f1 and s >= f0 - (T - 1) for s, e, _ in cl)
+
+
+# ---- the halo exchange's ring on its own process group (gloo, 3 ranks, 2 rounds) ------------------------------------------------------
+def halo_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T1, N, C, Hm, Wm, M = 3, 5, 4, 2, 3, 2
+    job = sharding._Job.__new__(sharding._Job)                 # only what _halo() reads
+    job.world, job.rank, job.dist, job.T, job.device = world, rank, dist, T1 + 1, torch.device("cpu")
+    job.plan = [None] * (2 * world)                            # two rounds of `world` chunks
+    job.halo_dims, job.halos = (N, C, Hm, Wm, M), {}
+    job.halo_pg = sharding.halo_group(dist, world)
+    assert job.halo_pg is not None and job.halo_pg is not dist.group.WORLD        # its own communicator
+    assert sharding.halo_group(dist, world) is job.halo_pg                          # created once
+    got = {}
+    for q in range(2):
+        g = q * world + rank
+        h = job._halo(q, g)
+        # a collective on the DEFAULT group between the exchanges, issued on different sides of it by even and odd ranks: harmless now
+        t = torch.ones(1)
+        if rank % 2 == 0:
+            dist.all_reduce(t)
+        enc = torch.full((T1, N, C), float(g)); mf = torch.full((T1, Hm, Wm, M), float(g) + 0.5)
+        h.on_tail(enc, mf)
+        if rank % 2 == 1:
+            dist.all_reduce(t)
+        if g > 0:                                              # chunk g reads the tail of chunk g - 1
+            e, m = h.head()
+            got[g] = (float(e.mean()), float(m.mean()), tuple(e.shape), tuple(m.shape))
+    torch.save(got, os.path.join(outdir, f"halo{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_ring_on_its_own_process_group(tmp_path):
+    """sharding._Halo / halo_group over gloo with three ranks and two rounds: chunk g receives exactly the tail of chunk g - 1 (rank 0's
+    comes from the LAST rank of the previous round), on a process group of its own -- a default-group collective issued before the exchange
+    on some ranks and after it on others does not disturb it."""
+    world = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=halo_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    seen = {}
+    for r in range(world):
+        seen.update(torch.load(os.path.join(str(tmp_path), f"halo{r}.pt"), weights_only=False))
+    assert sorted(seen) == [1, 2, 3, 4, 5]
+    for g, (e, m, es, ms_) in seen.items():
+        assert e == float(g - 1) and m == float(g - 1) + 0.5 and es == (3, 5, 4) and ms_ == (3, 2, 3, 2), (g, e, m)
