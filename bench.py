@@ -208,9 +208,9 @@ def cpu_baseline(cfg, sd, frames4):
     reference's own schedule -- clips (0,4) and (1,4); the per-frame stages (backbone + encoder + mask head) are re-run on the
     remaining window for every clip (`window_end_idx` never advances, mdqe/mdqe.py:302,314).  The four parts are timed
     separately, so the compute-once schedule (the second clip reuses the first clip's frame features) is the same run minus
-    the recompute.  `value` = compute-once, at the best of {physical cores, half, (a quarter on hosts with >= 64 cores)} torch threads: more
-    threads than physical cores oversubscribe the oracle's GEMMs, and on a two-socket host half the cores beat all of them (0.325 against
-    0.162 frames/s on 2 x EPYC 9575F) -- the baseline is never the target, but it should not be handicapped."""
+    the recompute.  `value` = compute-once, at the best torch thread count of a short ascending sweep (an eighth .. all of the physical
+    cores): more threads than physical cores oversubscribe the oracle's GEMMs, and on a two-socket host a quarter of the cores beats all
+    of them (0.54 against 0.12 frames/s on 2 x EPYC 9575F) -- the baseline is never the target, but it should not be handicapped."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mdqe_oracle as O
     hp = O.Hyper()
@@ -245,8 +245,14 @@ def cpu_baseline(cfg, sd, frames4):
             O.frame_features(sd, hp, x1, sizes1, bb)
             return time.time() - t0
 
-    cand = [n_phys] + ([n_phys // 2] if n_phys >= 2 else []) + ([n_phys // 4] if n_phys >= 64 else [])      # (big two-socket hosts: a quarter can win)
-    runs = {n: once(n) for n in cand}
+    # thread counts, ascending, from an eighth of the physical cores (at least 4) up to all of them; the sweep stops once a count is 1.5x
+    # slower than the best so far (on a two-socket 128-core host 32 threads win: 0.54 frames/s against 0.28 at 64 and 0.12 at 128)
+    cand = sorted({c for c in (n_phys // 8, n_phys // 4, n_phys // 2, n_phys) if c >= 4} | ({n_phys} if n_phys < 8 else set()))
+    runs = {}
+    for n in cand:
+        runs[n] = once(n)
+        if sum(runs[n]) > 1.5 * min(sum(t) for t in runs.values()):
+            break
     tot = {n: sum(t) for n, t in runs.items()}
     best = min(tot, key=tot.get)
     t = runs[best]
@@ -258,7 +264,7 @@ def cpu_baseline(cfg, sd, frames4):
             "threads_tried": {str(n): round(4.0 / v, 4) for n, v in sorted(tot.items())},
             "sample": "oracle/mdqe_oracle.py on configs[0]: one video of 4 synthetic 360x640 frames = clips (0,4) and (1,4); "
                       "compute-once schedule on %d torch threads (%s, %d physical cores; best of %s): per-frame stages x4 frames (%.1f s) + 2 decoder/"
-                      "inference_clip passes (%.1f + %.1f s)" % (best, model_name, n_phys, "/".join(str(n) for n in cand), t[0], t[1], t[2]),
+                      "inference_clip passes (%.1f + %.1f s)" % (best, model_name, n_phys, "/".join(str(n) for n in sorted(runs)), t[0], t[1], t[2]),
             "as_reference": {"value": 4.0 / asref, "unit": "frames/s", "cores": best,
                              "what": "the same video in the reference's schedule: the window's per-frame stages are recomputed for the "
                                      "second clip (+3 frames, %.1f s); on the bench's 120-frame video that schedule runs 3540 frame "
