@@ -229,7 +229,7 @@ class MDQE(nn.Module):
         return clips
 
     def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None, h2d=None,
-                          halo=None, side_streams=True):
+                          halo=None, side_streams=True, prime_all=True):
         """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
@@ -381,8 +381,10 @@ class MDQE(nn.Module):
         plan_next()
         if primed:
             # a primed generator (sharded videos) is resumed only after the caller has gathered the previous round -- host syncs,
-            # collectives: the frame stream gets its whole look-ahead now so that it does not run dry meanwhile
-            while len(states) < NR and plan_next():
+            # collectives: the frame stream gets its whole look-ahead now so that it does not run dry meanwhile.  prime_all=False
+            # (forward_stream): only the first pass -- the host has the previous video's last decoder batch to launch right now, and
+            # three passes of launches (13 ms of host time) in front of it cost more than they hide
+            while prime_all and len(states) < NR and plan_next():
                 pass
             yield None                            # per-frame work of the first passes is queued; the caller resumes later
         tail_state["consuming"] = True            # from here on the caller has gathered the previous round: the exchange may be issued
@@ -576,7 +578,7 @@ class MDQE(nn.Module):
             def cb():
                 st["done_frames"] = True
                 look_ahead(st)
-            st["gen"] = self.iter_clip_results(frames_dev, clips, 0, None, primed=True, on_frames_queued=cb, h2d=h2d)
+            st["gen"] = self.iter_clip_results(frames_dev, clips, 0, None, primed=True, on_frames_queued=cb, h2d=h2d, prime_all=False)
             next(st["gen"])
             return st
 
