@@ -110,6 +110,29 @@ class MDQE(nn.Module):
         return self._engine
 
     # ---- forward (mdqe/mdqe.py:194-242) ------------------------------------------------------------
+    def _make_streams(self):
+        """The pipeline's normal-priority streams, created TOGETHER and in a fixed order (copy, frame, tracker) the first time the model
+        runs on a GPU.  HIP deals its streams onto 4 hardware queues in creation order and a queue is served in order, so WHICH streams
+        share a queue is decided here -- and it matters: with one / three foreign normal-priority streams created before these, the
+        same pipeline runs 5 % / 11 % slower (tools/stream_map_ab.py: 760 -> 719 / 679 frames/s; two: 754).  `MDQE_STREAM_PAD=k` shifts
+        the deal by k queues for a process that has created streams of its own before the model's first call."""
+        pad = int(os.environ.get("MDQE_STREAM_PAD", "0"))
+        self._pad_streams = [torch.cuda.Stream(self.device) for _ in range(max(pad, 0))]
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(self.device)
+        if self._frame_stream is None:
+            self._frame_stream = torch.cuda.Stream(self.device)
+        if self._trk_stream is None:
+            self._trk_stream = torch.cuda.Stream(self.device)
+        # a stream gets its hardware queue when it is first USED, not when it is created (unused foreign streams change nothing,
+        # tools/stream_pad_ab.sh).  The pipeline's natural first-use order (copy, frame, tracker, between the high-priority streams'
+        # first uses) is the best deal measured; MDQE_STREAM_TOUCH=1 instead touches [pads,] copy, frame, tracker here, in that order --
+        # a knob for a host process whose own streams have shifted the deal (tools/stream_touch_ab.sh: 731-735 against 737-745 frames/s)
+        if os.environ.get("MDQE_STREAM_TOUCH", "0") == "1":
+            for st in self._pad_streams + [self._copy_stream, self._frame_stream, self._trk_stream]:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
+
     @contextlib.contextmanager
     def work_stream(self):
         """The model's own HIGH-PRIORITY stream for the per-clip stages (decoder, inference_clip: hundreds of small kernels
@@ -123,6 +146,7 @@ class MDQE(nn.Module):
         cur = torch.cuda.current_stream(self.device)
         if self._work_stream is None:
             self._work_stream = torch.cuda.Stream(self.device, priority=-1)
+            self._make_streams()
         ws = self._work_stream
         if cur == ws:
             yield
