@@ -128,7 +128,20 @@ class MDQE(nn.Module):
         # tools/stream_pad_ab.sh).  The pipeline's natural first-use order (copy, frame, tracker, between the high-priority streams'
         # first uses) is the best deal measured; MDQE_STREAM_TOUCH=1 instead touches [pads,] copy, frame, tracker here, in that order --
         # a knob for a host process whose own streams have shifted the deal (tools/stream_touch_ab.sh: 731-735 against 737-745 frames/s)
-        if os.environ.get("MDQE_STREAM_TOUCH", "0") == "1":
+        order = os.environ.get("MDQE_STREAM_ORDER", "")          # tools/stream_order_ab.sh: first-use order of ALL the pipeline's streams
+        if order:
+            if self._ahead_stream is None:
+                self._ahead_stream = torch.cuda.Stream(self.device, priority=-1)
+            pool = self.engine.__dict__.setdefault("_inst_streams", {})
+            inst = pool.setdefault(self._work_stream.cuda_stream, torch.cuda.Stream(self.device, priority=-1))
+            table = {"w": self._work_stream, "i": inst, "a": self._ahead_stream, "c": self._copy_stream, "f": self._frame_stream, "t": self._trk_stream}
+            for ch in order:
+                st = table.get(ch) or torch.cuda.Stream(self.device, priority=-1 if ch == "X" else 0)
+                if ch not in table:
+                    self._pad_streams.append(st)
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
+        elif os.environ.get("MDQE_STREAM_TOUCH", "0") == "1":
             for st in self._pad_streams + [self._copy_stream, self._frame_stream, self._trk_stream]:
                 with torch.cuda.stream(st):
                     torch.zeros(1, device=self.device)
