@@ -300,7 +300,7 @@ class _Halo:
         if self.recv_buf is None:
             return None
         if self.host:
-            return self.recv_buf.to(self.device, non_blocking=True)
+            return self.recv_buf.to(self.device)       # (pageable host memory: a plain, blocking copy -- this is the gloo rehearsal path)
         # the buffer was allocated under the FRAME stream (on_tail) and is read on the caller's stream: tell the caching allocator,
         # or the block could be handed to a later frame-stream allocation while the reader's kernels are still queued
         self.recv_buf.record_stream(torch.cuda.current_stream(self.recv_buf.device))

@@ -153,10 +153,17 @@ def _load(d, mode, rank):
     return torch.load(path, weights_only=False)
 
 
-def _same(out, ref):
-    assert out["pred_labels"] == ref["pred_labels"]
-    assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6)
-    assert all(torch.equal(a, b) for a, b in zip(out["pred_masks"], ref["pred_masks"]))
+def _same(out, ref, who=""):
+    assert out["pred_labels"] == ref["pred_labels"], who
+    assert torch.allclose(torch.tensor(out["pred_scores"]), torch.tensor(ref["pred_scores"]), atol=1e-6), who
+    assert len(out["pred_masks"]) == len(ref["pred_masks"]), who
+    bad = []
+    for i, (a, b) in enumerate(zip(out["pred_masks"], ref["pred_masks"])):
+        if a.shape != b.shape or not torch.equal(a, b):       # say WHERE: instance, frames, pixels (a bare False tells nothing about a race)
+            d = (a != b) if a.shape == b.shape else None
+            bad.append("instance %d: %s" % (i, "shape %s vs %s" % (tuple(a.shape), tuple(b.shape)) if d is None else
+                                            "%d pixels in frames %s" % (int(d.sum()), d.flatten(1).any(1).nonzero().flatten().tolist())))
+    assert not bad, "%s masks differ from the single-GPU result: %s" % (who, "; ".join(bad))
 
 
 @pytest.mark.parametrize("mode", STREAM_MODES)
