@@ -1,5 +1,8 @@
 """Every GEMM / conv launch of one pass of the per-frame stages (40 frames of 360p by default), timed with HIP events on the launch
-stream, grouped by shape: count, average duration, achieved TFLOP/s, share of the pass.  python tools/frame_gemm_table.py [config] [frames]"""
+stream, grouped by shape: count, average duration, achieved TFLOP/s, share of the pass.  python tools/frame_gemm_table.py [config] [frames]
+Corresponds to ONE full-size frame pass of `python bench.py --config <config>` (40 frames at 360p, 20 at 640p, 35 for Swin-L) run ALONE on
+the chip with an event pair around every launch: the figures are the kernels' isolated rates (the bench's `roofline_isolated`), not what
+they reach beside the clip stream's kernels (`roofline`)."""
 import os, sys, collections, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_video

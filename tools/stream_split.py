@@ -1,5 +1,8 @@
 """Where does a 120-frame step go?  Times (same box) the per-frame stages alone (3 passes of 40 frames), the per-clip
-stages alone (decoder + inference_clip over the cached frames), and the full overlapped pipeline."""
+stages alone (decoder + inference_clip over the cached frames), and the full overlapped pipeline.
+Corresponds to `python bench.py` (R50_ovis_360, 120 frames, exact fp32, default schedule) with two differences that make its numbers
+a little better than the bench's: the video is already in HBM (`frames_resident` in the bench line) and the "alone" figures use three
+uniform 40-frame passes / three 40-clip decoder batches instead of the bench's 20/40/40/20 passes and 17/37/37/27 batches."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_video, calibrate_synthetic_scores
