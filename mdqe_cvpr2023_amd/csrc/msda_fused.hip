@@ -618,7 +618,10 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
       const long desc = (nt / 64) * 8L * (8 + 1) * 4 * 2 * 4;
       int LS = L;
       long px = 0;
-      while (LS > 1 && ((px + (long)lv.H[LS - 1] * lv.W[LS - 1] + 1) * D * 4 + desc) <= (long)g_msda_stage_kb * 1024) { --LS; px += (long)lv.H[LS] * lv.W[LS]; }
+      // the decoder's launch has few blocks per (frame, head): two blocks per CU (<= 72 KB each) beat one that stages more (640p: level 3
+      // alone 72.5 us, levels 2 + 3 = 115 KB 79.8 us, tools/msda_dec_640p.py); the encoder's long query runs take what fits
+      const long budget = (long)(dec_form && g_msda_stage_kb > 72 ? 72 : g_msda_stage_kb) * 1024;
+      while (LS > 1 && ((px + (long)lv.H[LS - 1] * lv.W[LS - 1] + 1) * D * 4 + desc) <= budget) { --LS; px += (long)lv.H[LS] * lv.W[LS]; }
       if (LS < L) {
         const size_t smem = (size_t)((px + 1) * D * 4 + desc);
         // queries per block, by what a block stages (tools/pmc_msda.py variants, us per launch): 38 KB (360p, 40 frames) 128: 380,
