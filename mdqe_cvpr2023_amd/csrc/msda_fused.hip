@@ -563,7 +563,8 @@ extern "C" int mdqe_debug_msda_xcd_order(int v) { g_msda_xcd_order = v; return M
 static int g_msda_variant = -1;    // tools/ A/B: block-to-query map (0, 1, 2) + 4 * (waves-per-SIMD hint 8 instead of none); -1 = by shape
 extern "C" int mdqe_debug_msda_variant(int v) { g_msda_variant = v; return MDQE_OK; }
 static int g_msda_stage_kb = 150;  // tools/ A/B: LDS budget (KB) of the levels staged by msda_fused_v3_kernel (how many coarse levels a block takes)
-extern "C" int mdqe_debug_msda_stage_kb(int v) { g_msda_stage_kb = v > 0 ? v : 150; return MDQE_OK; }
+static int g_msda_dec_stage_kb = 72;   // the decoder's box-level launch: cap of that budget (two blocks per CU)
+extern "C" int mdqe_debug_msda_stage_kb(int v) { g_msda_stage_kb = v > 0 ? v : 150; g_msda_dec_stage_kb = v > 0 ? v : 72; return MDQE_OK; }
 static int g_msda_tp_staged = 1;   // tools/ A/B: 0 = the decoder's temporal launch stays on v2
 extern "C" int mdqe_debug_msda_tp_staged(int v) { g_msda_tp_staged = v; return MDQE_OK; }
 static int g_msda_dec_staged = 1;  // tools/ A/B: 0 = the decoder's box-level launch stays on v2 (the encoder keeps its default)
@@ -605,7 +606,9 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
     // 40-frame launch with unstructured offsets (tools/pmc_msda.py variants), no difference end to end; the decoder keeps map 0
     int var = g_msda_variant >= 0 ? g_msda_variant : (mode == 0 ? (1 | 8) : (MSDA_DEFAULT_VARIANT | 8));
     const bool enc_form = mode == 0 && ntok == Q && vidx == nullptr && ref_dim == 2;      // the queries are the level tokens
-    const bool dec_form = mode == 1 && ref_dim == 4 && g_msda_dec_staged;                                      // box-level decoder launch: Q queries per (clip, frame)
+    // (24-wide heads -- Swin-L's 96-B rows -- gain nothing from the staged form in the decoder: 79-81 us staged against 73 us on the gather
+    // form for 34 clips, tools/msda_dec_640p.py; a forced budget, tools/ only, still takes the staged kernel)
+    const bool dec_form = mode == 1 && ref_dim == 4 && g_msda_dec_staged && (D == 32 || g_msda_stage_kb != 150);                                      // box-level decoder launch: Q queries per (clip, frame)
     if ((var & 8) && G == 1 && L == 4 && P == 4 && (enc_form || dec_form)) {
       // v3: the coarsest levels that fit beside the descriptors (2.3 KB per wave) in the 160-KB LDS are staged per (frame, head)
       int nt = (g_msda_variant >= 0 && (g_msda_variant & 128)) ? 512 : 1024;
@@ -620,7 +623,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
       long px = 0;
       // the decoder's launch has few blocks per (frame, head): two blocks per CU (<= 72 KB each) beat one that stages more (640p: level 3
       // alone 72.5 us, levels 2 + 3 = 115 KB 79.8 us, tools/msda_dec_640p.py); the encoder's long query runs take what fits
-      const long budget = (long)(dec_form && g_msda_stage_kb > 72 ? 72 : g_msda_stage_kb) * 1024;
+      const long budget = (long)(dec_form && g_msda_stage_kb > g_msda_dec_stage_kb ? g_msda_dec_stage_kb : g_msda_stage_kb) * 1024;
       while (LS > 1 && ((px + (long)lv.H[LS - 1] * lv.W[LS - 1] + 1) * D * 4 + desc) <= budget) { --LS; px += (long)lv.H[LS] * lv.W[LS]; }
       if (LS < L) {
         const size_t smem = (size_t)((px + 1) * D * 4 + desc);
