@@ -37,14 +37,18 @@ clip_assoc_kernel(const float* __restrict__ emb, const int* __restrict__ fidx, i
   const float w = wdw * (float)abs(t - ct);
   const int ki = k / nb, kj = k % nb;
   // The reference takes `masked_fill(-inf).softmax(-2).argmax(-2)` (transformer_dec.py:142-143): the FIRST index whose fp32
-  // softmax value equals the column's largest.  exp(s - max) rounds to 1.0f for every s with s - max > -2^-25, so a cell whose
-  // similarity is within half an ulp of 1 below the maximum ties with it and an earlier index wins.  Pass 1 finds the maximum
-  // (first index among exact ties) and the largest value strictly below it; only when that runner-up is inside the tie band --
-  // possible only for |max| < 0.5, where fp32 similarities are spaced more finely than 2^-25 -- a second pass looks for the first
-  // index in the band.  What stays open: the summation order of the 64-term dot product (torch's GEMM vs this loop) moves s by
-  // an ulp or two, so a near-tie of that size can still resolve differently; a NaN similarity makes the reference's whole column
-  // NaN (argmax -> index 0) while this loop keeps the first admissible cell.  tools/fuzz_inference_clip.py bounds how often.
-  constexpr float TIE = -2.98023223876953125e-8f;                       // -2^-25
+  // softmax value equals the column's largest.  Two roundings make cells below the maximum tie with it: (i) exp(s - max) rounds
+  // to 1.0f for every s with s - max > -2^-25; (ii) the division by the column sum: 1.0f / sum and (1 - 2^-24) / sum are half an
+  // ulp to one ulp of the quotient apart and can round to the same float (numerators from 1 - 2^-23 down are >= 1 ulp away and
+  // cannot).  Pass 1 finds the maximum (first index among exact ties) and the largest value strictly below it.  Only when that
+  // runner-up lies within 2^-23 of the maximum -- possible only for |max| < 1, where fp32 similarities are spaced that finely --
+  // the slow path evaluates what the reference evaluates: sum = sum over the admissible cells of expf(s - max) (index order),
+  // p(q) = expf(s_q - max) / sum in fp32, and the first admissible q < argmax with p(q) == 1.0f / sum wins.
+  // What stays open: torch's vectorised exp and its summation order (lanes of 8 / 16 partial sums) differ from expf and this
+  // loop by an ulp, as does the 64-term dot product itself (torch's GEMM vs this loop), so a near-tie of an ulp or two can still
+  // resolve differently; a NaN similarity makes the reference's whole column NaN (argmax -> index 0) while this loop keeps the
+  // first admissible cell.  tools/fuzz_inference_clip.py injects near-ties at 1-3 ulps and bounds how often.
+  constexpr float BAND = -1.1920928955078125e-7f;                       // -2^-23
   auto sim = [&](int q) {
     float s = 0.f;
 #pragma unroll
@@ -54,21 +58,28 @@ clip_assoc_kernel(const float* __restrict__ emb, const int* __restrict__ fidx, i
     }
     return s;
   };
+  auto admissible = [&](int q) {
+    const int qi = q / nb, qj = q % nb;
+    return !((float)abs(qi - ki) > w || (float)abs(qj - kj) > w);
+  };
   float best = -INFINITY, second = -INFINITY;
   int bi = 0;
   bool have = false;
   for (int q = 0; q < Q; ++q) {
-    const int qi = q / nb, qj = q % nb;
-    if ((float)abs(qi - ki) > w || (float)abs(qj - kj) > w) continue;
+    if (!admissible(q)) continue;
     const float s = sim(q);
     if (!have || s > best) { if (have) second = best; best = s; bi = q; have = true; }
     else if (s < best && s > second) second = s;
   }
-  if (have && second - best > TIE) {
-    for (int q = 0; q < bi; ++q) {                                      // rare: an earlier cell inside the tie band wins
-      const int qi = q / nb, qj = q % nb;
-      if ((float)abs(qi - ki) > w || (float)abs(qj - kj) > w) continue;
-      if (sim(q) - best > TIE) { bi = q; break; }
+  if (have && second - best > BAND) {                                   // rare: an earlier cell may tie with the maximum in fp32 softmax
+    float sum = 0.f;
+    for (int q = 0; q < Q; ++q)
+      if (admissible(q)) sum += expf(sim(q) - best);
+    const float top = 1.0f / sum;
+    for (int q = 0; q < bi; ++q) {
+      if (!admissible(q)) continue;
+      const float d = sim(q) - best;
+      if (d > BAND && expf(d) / sum == top) { bi = q; break; }
     }
   }
   idx[((long)b * T + t) * Q + k] = bi;

@@ -635,15 +635,17 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         if (g_msda_variant >= 0 && ((g_msda_variant >> 4) & 7)) chunk = 32 << (((g_msda_variant >> 4) & 7) - 1);       // tools/ sweep: 32 .. 2048
         const int nchunk = (Q + chunk - 1) / chunk;
         const long nb3 = (long)B * M * nchunk;
+        bool lds_ok = true;
         auto launch3 = [&](auto kern) {
           // per kernel FUNCTION (the six instantiations share this lambda's one operator()): keyed by pointer in mdqe_allow_lds
-          if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) return;   // (shows as a launch error below)
+          if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) { lds_ok = false; return; }   // nothing launched
           hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
                              ref, ref_bstride, ref_dim, mode, grid, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
         };
         if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
         else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
         else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
+        if (!lds_ok) { (void)hipGetLastError(); return MDQE_ELAUNCH; }     // `out` was never written: not MDQE_OK (as msda.hip does)
         return mdqe_launch_status();
       }
     }
@@ -666,14 +668,16 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
       if (ok && LS < G) {                        // (<= 72 KB: two blocks per CU, one stages while the other gathers)
         const size_t smem = (size_t)((px + 1) * D * 4 + desc);
         const long nbt = (long)B * M * runs;
+        bool lds_ok = true;
         auto launch_tp = [&](auto kern) {
-          if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) return;
+          if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) { lds_ok = false; return; }
           hipLaunchKernelGGL(kern, dim3((unsigned)nbt), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
                              ref, ref_bstride, grid, lv, B, M, Q, LS, (int)px, chunk, runs, scale, out, ldout);
         };
         if (nt == 1024) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 1024>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 1024>); }
         else if (nt == 832) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 832>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 832>); }
         else { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 512>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 512>); }
+        if (!lds_ok) { (void)hipGetLastError(); return MDQE_ELAUNCH; }
         return mdqe_launch_status();
       }
     }

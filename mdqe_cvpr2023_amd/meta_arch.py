@@ -97,7 +97,9 @@ class MDQE(nn.Module):
 
     def train(self, mode=True):
         if mode:
-            raise RuntimeError("mdqe_cvpr2023_amd.MDQE implements the eval-only path (SURVEY.md §8); training is out of scope")
+            raise RuntimeError("mdqe_cvpr2023_amd.MDQE implements the eval-only path (SURVEY.md §8); training is out of scope -- to train, "
+                               "select the reference's model: MODEL.META_ARCHITECTURE MDQE_REFERENCE, or MDQE_MI355X_REGISTER=alias in the "
+                               "environment so that 'MDQE' stays the reference's")
         return super().train(False)
 
     @property
@@ -787,6 +789,7 @@ class ClipMerger:
     with per-frame work the producer has already queued on the main stream."""
 
     tracker_cls = OverTracker               # (tests without a GPU substitute a stand-in bank, tests/_standins.py)
+    EARLY_TRACKS = 48                       # tracks per video the early-mask path budgets pinned memory for
 
     def __init__(self, model, frame_hw, out_size, mask_hw, n_frames=None, emit_masks=True):
         self.model, self.frame_hw, self.out_size, self.mask_hw = model, frame_hw, out_size, mask_hw
@@ -794,13 +797,20 @@ class ClipMerger:
         self.n_frames = n_frames                    # total frames of the video when known: enables the early mask path
         self.early = None
         # MODEL.MDQE.MERGE_ON_CPU (mdqe/mdqe.py:185-186,337,354-355; True in R50_ovis_720 / swinl_ovis): the device the window results
-        # wait on for the end of the video -- a memory-placement switch, the outputs are the same.  Here: False keeps every flushed
-        # window's stride-4 logits in HBM until the video ends (as the reference keeps them on the GPU), True drops them once their
-        # final masks are on the host.  WHEN the final masks are produced is a separate choice (`model.early_masks`, default on for
-        # both settings since round 3: per window, under the later windows' compute; off = one pass + one copy at the end, which
-        # needs the logits and therefore keeps them whatever MERGE_ON_CPU says).
+        # wait on for the end of the video -- a memory-placement switch, the outputs are the same.  WHEN the final masks are produced is
+        # a separate choice (`model.early_masks`, default on for both settings since round 3): per flushed window, into pinned host
+        # buffers under the later windows' compute -- the window's stride-4 logits are then dropped at once under EITHER setting (nothing
+        # reads them again) -- or, off, in one pass + one copy at the end, which needs the logits of every window and keeps them in HBM
+        # whatever MERGE_ON_CPU says.
         self.merge_on_cpu = bool(model.cfg.merge_on_cpu if model.merge_on_cpu is None else model.merge_on_cpu)
         self.early_on = bool(getattr(model, "early_masks", True))
+        # The early path holds one pinned [n_frames, Ho, Wo] buffer per TRACK (the late path: per selected output).  Budget: an estimate
+        # of EARLY_TRACKS tracks must fit into MDQE_EARLY_PINNED_GB (default 24) of pinned host memory, else the late path is taken for
+        # this video (a 120-frame 360p video: 27.6 MB per track; one rank's view of a 1920-frame one: 442 MB per track).
+        if self.early_on and n_frames is not None:
+            per_track = int(n_frames) * int(out_size[0]) * int(out_size[1])
+            if per_track * self.EARLY_TRACKS > float(os.environ.get("MDQE_EARLY_PINNED_GB", "24")) * 2 ** 30:
+                self.early_on = False
         self.dev = model.device
         self.use_side = self.dev.type == "cuda"
         self.main = torch.cuda.current_stream(self.dev) if self.use_side else None
@@ -864,7 +874,9 @@ class ClipMerger:
                     self.windows.append((self.f_off, None))
                 elif self.use_side and self.n_frames is not None and (self.early_on or self.model.rle_output):
                     self._early_masks(m)
-                    self.windows.append((self.f_off, None if self.merge_on_cpu else m))
+                    # inference_video returns from its `early` branch and never reads `windows` then: the stride-4 logits of a flushed
+                    # window are not kept for the rest of the video under either MERGE_ON_CPU setting (round 3 held them for nothing)
+                    self.windows.append((self.f_off, None))
                 else:
                     self.windows.append((self.f_off, m))
                 self.f_off += m.shape[1]
@@ -948,16 +960,30 @@ def register_with_detectron2(registry=None, takeover=None):
       comes LATER (this package imported before the reference's) is diverted to "MDQE_REFERENCE" instead of tripping fvcore's
       assertion.  Both import orders end with `build_model(cfg)` constructing this class and the reference's model still selectable.
 
-    Returns a dict describing what was done (also kept in `registration_state()`); raises anything but a missing detectron2."""
+    Returns a dict describing what was done (also kept in `registration_state()`).  A missing detectron2 is silent; a detectron2 that
+    is installed but fails to import (ImportError / OSError) is a logged warning recorded in `registration_state()` -- the d2-free
+    `MDQE(cfg)` keeps working -- unless `MDQE_MI355X_REGISTER=strict`; a failure of the registration itself propagates."""
     import logging
     log = logging.getLogger("mdqe_cvpr2023_amd")
     if registry is None:
         try:
             from detectron2.modeling import META_ARCH_REGISTRY as registry
-        except ModuleNotFoundError as e:          # detectron2 absent in this image: the d2-free entry points are all there is
-            if (e.name or "").split(".")[0] != "detectron2":
-                raise                             # (a detectron2 that is there but broken is not "absent")
-            _REGISTRATION.update(state="detectron2 not importable")
+        except (ImportError, OSError) as e:
+            # ModuleNotFoundError of detectron2 itself: absent in this image, the d2-free entry points are all there is (silent).
+            # Any other ImportError / OSError: a detectron2 that is installed but does not import here -- typically `from detectron2
+            # import _C` on a ROCm box without its compiled ops.  That must not take the d2-free `MDQE(cfg)` entry point down with it:
+            # warn, record, go on.  `MDQE_MI355X_REGISTER=strict` raises instead.  (A failure of the REGISTRATION below -- a registry
+            # that misbehaves -- still propagates.)
+            absent = isinstance(e, ModuleNotFoundError) and (e.name or "").split(".")[0] == "detectron2"
+            if not absent:
+                if os.environ.get("MDQE_MI355X_REGISTER", "") == "strict":
+                    raise
+                log.warning("detectron2 is installed but `detectron2.modeling` does not import (%s: %s): mdqe_cvpr2023_amd.MDQE is NOT in "
+                            "META_ARCH_REGISTRY; the detectron2-free entry point MDQE(cfg) works (MDQE_MI355X_REGISTER=strict makes this "
+                            "an error)", type(e).__name__, e)
+            _REGISTRATION.clear()
+            _REGISTRATION.update(state="detectron2 not importable" if absent else "detectron2 import failed",
+                                 error=None if absent else "%s: %s" % (type(e).__name__, e))
             return dict(_REGISTRATION)
     if takeover is None:
         takeover = os.environ.get("MDQE_MI355X_REGISTER", "replace") != "alias"
@@ -999,4 +1025,4 @@ def registration_state():
     return dict(_REGISTRATION)
 
 
-register_with_detectron2()                        # loud on anything but a missing detectron2
+register_with_detectron2()                        # silent without detectron2, a warning if it is there but does not import, loud otherwise

@@ -40,6 +40,40 @@ def test_assoc_and_gather_init_vs_torch():
     assert torch.equal(x.view(2, Q, C)[0].cpu(), content[1]) and torch.equal(xi.view(2, Q, C)[1].cpu(), content[0])
 
 
+def test_assoc_near_ties_follow_the_fp32_softmax_of_the_reference():
+    """`softmax(-2).argmax(-2)` (transformer_dec.py:142-143) picks the FIRST index whose fp32 softmax value equals the largest: a cell
+    1-3 ulps below the maximum can tie with it through the rounding of exp() and of the division by the column sum.  Similarities are
+    made exact (centre embedding = a unit vector, so sim(q) = the first component of q's embedding); all cells but the two contenders
+    sit at -100 (exp underflows to 0), so the column sum has two terms and no summation-order freedom.  The kernel must agree with
+    torch's CPU softmax on every case."""
+    from mdqe_cvpr2023_amd import ops
+    nb, E, T = 4, 16, 2
+    Q = nb * nb
+    cases = []
+    for best in (0.3, 0.11, -0.27, 0.9, 0.6, 0.051, -0.73, 1.7, 3.0):
+        for ulps in (1, 2, 3, 5):
+            for first in (2, 9):                                             # the lower contender comes BEFORE the maximum (index 12)
+                lo = np.float32(best)
+                for _ in range(ulps):
+                    lo = np.nextafter(lo, np.float32(-np.inf), dtype=np.float32)
+                cases.append((np.float32(best), lo, first))
+    emb = torch.zeros(2 * len(cases), Q, E)
+    for i, (best, lo, first) in enumerate(cases):
+        emb[2 * i, :, 0] = 1.0                                               # centre frame: every query is the unit vector e0
+        emb[2 * i + 1, :, 0] = -100.0
+        emb[2 * i + 1, 12, 0] = float(best)
+        emb[2 * i + 1, first, 0] = float(lo)
+    fidx = torch.tensor([[2 * i, 2 * i + 1] for i in range(len(cases))], dtype=torch.int32)
+    idx = ops.clip_assoc(emb.cuda(), fidx.cuda(), 0, 100.0, nb).cpu()        # window wide open: every cell admissible
+    n_tie = 0
+    for i, (best, lo, first) in enumerate(cases):
+        sim = emb[2 * i + 1, :, 0].view(Q, 1).expand(Q, Q).contiguous()       # [q, k]
+        want = sim.softmax(-2).argmax(-2)                                     # the reference's expression on the CPU
+        n_tie += int(want[0]) == first
+        assert torch.equal(idx[i, 1].long(), want), (float(best), float(lo), first, idx[i, 1, :4].tolist(), want[:4].tolist())
+    assert n_tie > 0                                                          # the construction does produce softmax ties below the maximum
+
+
 def test_box_refine_time_fuse_add_vs_torch():
     from mdqe_cvpr2023_amd import ops
     g = torch.Generator().manual_seed(1)
