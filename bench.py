@@ -24,85 +24,129 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_TBPS = 8.0                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-class GemmMeter:
-    """HIP-event timing of the dominant kernel (the 128x128-tile fp32 GEMM / implicit-GEMM conv) inside the timed region:
-    an event pair on the launch stream around each of its launches + the launch's algorithmic FLOPs."""
+class Meter:
+    """HIP-event timing inside the timed region, on the stream the kernel is launched on: an event pair around sampled launches of
+    (i) the dominant kernel -- the fp32 MFMA GEMM / implicit-GEMM conv in its large forms -- with the launch's algorithmic FLOPs, and
+    (ii) the fused deformable gather `mdqe_msda_fused_f32` (encoder, decoder box level, decoder temporal) with the launch's
+    algorithmic bytes (value + sampling offsets + attention logits + output).  It can also just COUNT the FLOPs of every
+    GEMM-type launch (the per-clip stage's figure)."""
 
-    def __init__(self, stride=5):
-        self.rec = []
-        self.enabled = False
+    def __init__(self, stride=5, msda_stride=3):
+        self.rec = []                     # (e0, e1, flops) of sampled GEMM launches
+        self.msda = {"encoder": [], "decoder_box": [], "decoder_temporal": []}       # (e0, e1, bytes)
+        self._enabled = False
         # An event pair per launch costs the timed region 1.2 % (tools/early_late_ab.py: 746 -> 737 frames/s at 360p; a record is a
         # barrier packet on the stream): every `stride`-th qualifying launch is timed instead.  A step has 442 of them (not a multiple
         # of 5), so over the K steps every launch position is sampled.
         self.stride = max(1, int(os.environ.get("MDQE_BENCH_METER_STRIDE", stride)))
-        self.count = 0
+        self.msda_stride = max(1, int(os.environ.get("MDQE_BENCH_MSDA_STRIDE", msda_stride)))
+        self.count = self.total = 0       # qualifying GEMM launches since the meter was last switched on: all of them / position counter
+        self.msda_count = {k: 0 for k in self.msda}
+        self.counting = False
+        self.flops = 0.0
+
+    @property
+    def enabled(self):
+        return self._enabled
+
+    @enabled.setter
+    def enabled(self, on):
+        if on and not self._enabled:      # which launch positions are sampled must not depend on earlier (warm-up, disabled) phases
+            self.count = self.total = 0
+            self.msda_count = {k: 0 for k in self.msda}
+        self._enabled = bool(on)
+
+    def reset(self):
+        self.rec = []
+        self.msda = {k: [] for k in self.msda}
 
     def take(self):
+        if not self._enabled:
+            return False
         self.count += 1
-        return self.enabled and self.count % self.stride == 0
+        self.total += 1
+        return self.count % self.stride == 0
+
+    def take_msda(self, kind):
+        if not self._enabled:
+            return False
+        self.msda_count[kind] += 1
+        return self.msda_count[kind] % self.msda_stride == 0
 
     def install(self):
         from mdqe_cvpr2023_amd import ops, _lib
-        import ctypes
-        raw = _lib.load_library().mdqe_gemm_nt_f32
-        raw_conv = _lib.load_library().mdqe_conv2d_nhwc_f32
-        raw_ln = _lib.load_library().mdqe_gemm_ln_f32
-        raw_cat = _lib.load_library().mdqe_gemm_nt_cat2_f32
+        L = _lib.load_library()
+        raw, raw_conv, raw_ln, raw_cat = L.mdqe_gemm_nt_f32, L.mdqe_conv2d_nhwc_f32, L.mdqe_gemm_ln_f32, L.mdqe_gemm_nt_cat2_f32
+        raw_side, raw_msda = L.mdqe_gemm_nt_side_f32, L.mdqe_msda_fused_f32
         meter = self
+
+        def timed(fn, a, sink, work):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            sink.append((e0, e1, work))
+            return rc
 
         class Wrapped:
             def __getattr__(self_, name):
-                return getattr(_lib.load_library(), name)
+                return getattr(L, name)
 
             def mdqe_gemm_nt_f32(self_, *a):
                 M, N, K, tile = a[6], a[7], a[8], a[16]
+                if meter.counting:
+                    meter.flops += 2.0 * M * N * K
                 big = (tile == 1) or (tile == 0 and N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 192)
                 if not (big and meter.take()):
                     return raw(*a)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = raw(*a)
-                e1.record()
-                meter.rec.append((e0, e1, 2.0 * M * N * K))
-                return rc
+                return timed(raw, a, meter.rec, 2.0 * M * N * K)
+
+            def mdqe_gemm_nt_side_f32(self_, *a):             # (decoder-sized: counted, never among the dominant launches)
+                if meter.counting:
+                    meter.flops += 2.0 * a[6] * a[7] * a[8]
+                return raw_side(*a)
 
             def mdqe_gemm_ln_f32(self_, *a):                  # same kernel template, LayerNorm epilogue (64x256 tile)
                 M, N, K = a[6], a[7], a[8]
+                if meter.counting:
+                    meter.flops += 2.0 * M * N * K
                 if not (((M + 127) // 128) * ((N + 127) // 128) >= 192 and meter.take()):
                     return raw_ln(*a)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = raw_ln(*a)
-                e1.record()
-                meter.rec.append((e0, e1, 2.0 * M * N * K))
-                return rc
+                return timed(raw_ln, a, meter.rec, 2.0 * M * N * K)
 
             def mdqe_gemm_nt_cat2_f32(self_, *a):             # bottleneck conv3 + projection shortcut as one product (same kernel template)
                 K1, K2, NI, OH, OW, N = a[2], a[5], a[6], a[7], a[8], a[16]
                 M = NI * OH * OW
+                if meter.counting:
+                    meter.flops += 2.0 * M * N * (K1 + K2)
                 if not (N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 192 and meter.take()):
                     return raw_cat(*a)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = raw_cat(*a)
-                e1.record()
-                meter.rec.append((e0, e1, 2.0 * M * N * (K1 + K2)))
-                return rc
+                return timed(raw_cat, a, meter.rec, 2.0 * M * N * (K1 + K2))
 
             def mdqe_conv2d_nhwc_f32(self_, *a):
                 NI, H, W, Cin, Cout, KH, KW, stride, pad, tile = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[19]   # (include/mdqe_hip.h)
                 M = NI * ((H + 2 * pad - KH) // stride + 1) * ((W + 2 * pad - KW) // stride + 1)
+                if meter.counting:
+                    meter.flops += 2.0 * M * Cout * KH * KW * Cin
                 big = (tile == 1) or (tile == 0 and Cout > 64 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 192)
                 if not (big and meter.take()):
                     return raw_conv(*a)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = raw_conv(*a)
-                e1.record()
-                meter.rec.append((e0, e1, 2.0 * M * Cout * KH * KW * Cin))
-                return rc
+                return timed(raw_conv, a, meter.rec, 2.0 * M * Cout * KH * KW * Cin)
+
+            def mdqe_msda_fused_f32(self_, *a):
+                # (value, ldv, v_brows, vidx, offs, ldo, logits, ldl, ref, ref_bstride, ref_dim, mode, grid, H, W, start, B, M, D, G, L, Q, P, ...)
+                v_brows, mode, B, M, D, G, L, Q, P = a[2], a[11], a[16], a[17], a[18], a[19], a[20], a[21], a[22]
+                kind = "encoder" if mode == 0 else ("decoder_temporal" if G > 1 else "decoder_box")
+                if not meter.take_msda(kind):
+                    return raw_msda(*a)
+                # algorithmic bytes (SURVEY §8d): the value maps a batch element reads + offsets + logits + output, fp32.  Encoder /
+                # decoder box level: one frame's map per element; temporal: the L frames of the clip.
+                frames = L if kind == "decoder_temporal" else 1
+                nbytes = 4.0 * B * (frames * v_brows * M * D + Q * M * L * P * 3 + Q * M * D)
+                return timed(raw_msda, a, meter.msda[kind], nbytes)
         ops.lib = Wrapped()
 
     def summary(self):
@@ -110,7 +154,17 @@ class GemmMeter:
             return None
         ms = sum(a.elapsed_time(b) for a, b, _ in self.rec)
         fl = sum(f for _, _, f in self.rec)
-        return dict(launches=len(self.rec), avg_us=1e3 * ms / len(self.rec), tflops=fl / ms / 1e9)
+        return dict(launches_timed=len(self.rec), launches_total=self.total, avg_us=1e3 * ms / len(self.rec), tflops=fl / ms / 1e9)
+
+    def msda_summary(self):
+        out = {}
+        for kind, rec in self.msda.items():
+            if rec:
+                ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+                by = sum(w for _, _, w in rec)
+                out[kind] = dict(launches_timed=len(rec), launches_total=self.msda_count[kind], avg_us=1e3 * ms / len(rec),
+                                 avg_mbytes=by / len(rec) / 1e6, tbps=by / ms / 1e9)
+        return out
 
 
 def synth_video(f0, f1, seed, h=360, w=640, n_obj=10):
@@ -271,15 +325,13 @@ def cpu_baseline(cfg, sd, frames4):
                                      "passes instead of 120" % t_re}}
 
 
-def spawn_ranks(n, rehearsal):
+def spawn_ranks(n):
     """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same args>` as a child and return its
-    exit code.  Called before this process has made any GPU call.  Without a rehearsal hook the box must show n GPUs."""
+    exit code.  This process makes NO GPU call of any kind (not even a device count): the ranks themselves refuse to run on a box
+    with fewer GPUs than ranks (exit 2), and torch.distributed.run ends the other ranks and exits non-zero as soon as one rank fails --
+    the failing rank's stderr is this process's stderr."""
     import socket
     import subprocess
-    if not rehearsal and torch.cuda.device_count() < n:
-        print("bench.py: --gpus %d but only %d GPU(s) visible (MDQE_BENCH_BACKEND=gloo MDQE_BENCH_ONE_DEVICE=1 rehearses %d ranks on one)"
-              % (n, torch.cuda.device_count(), n), file=sys.stderr)
-        return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -289,6 +341,64 @@ def spawn_ranks(n, rehearsal):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
+
+
+class Deadline:
+    """A soft watchdog around an OPTIONAL measurement (the halo-exchange A/B at N > 1, which has never run over RCCL with more than
+    one rank): if the guarded region has not finished after `seconds`, `on_expire()` runs on a timer thread (rank 0 prints the line it
+    already has) and the process leaves with exit code 0 -- before the process group's own timeout (COLLECTIVE_TIMEOUT_S) would abort
+    it and lose the headline.  Every rank arms the same deadline at the same barrier."""
+
+    def __init__(self, seconds, on_expire=None):
+        import threading
+        self.expired = False
+
+        def fire():
+            self.expired = True
+            try:
+                if on_expire is not None:
+                    on_expire()
+            finally:
+                sys.stderr.flush()
+                os._exit(0)
+        self.t = threading.Timer(seconds, fire)
+        self.t.daemon = True
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def same_output(a, b):
+    """Bit-for-bit comparison of two `MDQE.forward` results (labels, scores, masks); returns (ok, what differs)."""
+    if a is None or b is None:
+        return False, "missing result"
+    if a["pred_labels"] != b["pred_labels"]:
+        return False, "labels %s vs %s" % (a["pred_labels"][:8], b["pred_labels"][:8])
+    if a["pred_scores"] != b["pred_scores"]:
+        return False, "scores %s vs %s" % (a["pred_scores"][:4], b["pred_scores"][:4])
+    if len(a["pred_masks"]) != len(b["pred_masks"]):
+        return False, "mask count"
+    for i, (x, y) in enumerate(zip(a["pred_masks"], b["pred_masks"])):
+        if x.shape != y.shape or not torch.equal(x, y):
+            return False, "mask %d" % i
+    return True, ""
+
+
+def fail_hook(where, rank):
+    """Test hooks for the failure paths of a multi-rank run: MDQE_BENCH_FAIL_RANK=r MDQE_BENCH_FAIL_AT=init|run makes rank r raise there,
+    MDQE_BENCH_HANG_RANK=r makes it sleep instead (the others must time out, not wait for ever)."""
+    if os.environ.get("MDQE_BENCH_FAIL_AT", "init") != where:
+        return
+    if os.environ.get("MDQE_BENCH_FAIL_RANK") == str(rank):
+        raise RuntimeError("bench.py: rank %d fails on purpose at '%s' (MDQE_BENCH_FAIL_RANK)" % (rank, where))
+    if os.environ.get("MDQE_BENCH_HANG_RANK") == str(rank):
+        print("bench.py: rank %d hangs on purpose at '%s' (MDQE_BENCH_HANG_RANK)" % (rank, where), file=sys.stderr, flush=True)
+        time.sleep(3600)
 
 
 def main():
@@ -334,10 +444,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` starts its own N ranks, as the reference's CLI does from --num-gpus (train_net.py:264-271,
-        # detectron2 `launch`).  Nothing in THIS process has touched the GPU (device_count() does not initialise HIP on this image):
-        # the ranks are a CHILD process tree (torch.distributed.run), whose stdout/stderr are this process's and whose exit code
-        # is passed on.
-        sys.exit(spawn_ranks(args.gpus, one_dev or probe))
+        # detectron2 `launch`).  THIS process never touches the GPU runtime -- no torch.cuda call at all; the ranks refuse a box with
+        # too few GPUs themselves: the ranks are a CHILD process tree (torch.distributed.run), whose stdout/stderr are this
+        # process's and whose exit code is passed on.
+        sys.exit(spawn_ranks(args.gpus))
 
     # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints a five-line version banner
     # there when a communicator is created, gloo its connection messages) are sent to stderr for the rest of the run
@@ -373,10 +483,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("MDQE_COLLECTIVE_TIMEOUT_S", "120")))
+        # a finite timeout on every collective: a rank that dies (or never arrives) makes the others raise after `tmo` instead of
+        # waiting for the driver's kill with an empty stdout; under torch.distributed.run the agent ends the other ranks at once
         if backend == "nccl" and not probe:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         else:
-            dist.init_process_group("gloo" if probe else backend)
+            dist.init_process_group("gloo" if probe else backend, timeout=tmo)
+        fail_hook("init", rank)
         # every rank adds a 1: the communicator really spans --gpus processes
         one = torch.ones(1, dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(one)
@@ -403,23 +518,27 @@ def main():
     model = MDQE(cfg, state_dict=sd).eval()
     model.rle_output = bool(args.rle_output)
     bias_shift = calibrate_synthetic_scores(model, sd, cfg, fh, fw) if args.init == "workload" else 0.0
-    meter = GemmMeter()
+    meter = Meter()
     meter.install()
 
     # The video starts in PINNED HOST memory, one tensor per frame as the mapper hands them over (mdqe/data/dataset_mapper.py:
     # 228-263); the host->device copy of a1 (mdqe/mdqe.py:480) is part of every timed step.
     L = args.frames * world
     T = cfg.n_frames_test
+    like = torch.zeros(0, 3, fh, fw, device="cuda")
+    shards = {}                                            # halo_exchange (bool) -> (plan, {chunk: pinned frames})
     if not sharded:
         video = synth_video(0, L, seed=0, h=fh, w=fw).pin_memory()
         host_frames = list(video)                          # L views [3,h,w] of the pinned block
-        chunk_frames = plan = chunk = None
+        chunk = None
     else:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
         chunk = sharding.round_sizes(args.frames, T) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
-        plan = sharding.chunk_plan(L, T, cfg.clip_stride, chunk, halo_exchange=args.halo_exchange, world=world)
-        chunk_frames = {g: synth_video(plan[g][1], plan[g][2], seed=0, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(plan, world, rank)}
-    like = torch.zeros(0, 3, fh, fw, device="cuda")
+
+        def shard(halo, n_frames=L, chunk_=None, seed=0):
+            pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk if chunk_ is None else chunk_, halo_exchange=halo, world=world)
+            return pl, {g: synth_video(pl[g][1], pl[g][2], seed=seed, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(pl, world, rank)}
+        shards[args.halo_exchange] = shard(args.halo_exchange)
     torch.cuda.synchronize()
 
     def sync():
@@ -429,7 +548,7 @@ def main():
 
     from mdqe_cvpr2023_amd import ops
 
-    def run(k, stream, mdl=model, resident=None):
+    def run(k, stream, mdl=model, resident=None, halo=args.halo_exchange, stats=None):
         """k steps (videos).  stream=False: one `model(inputs)` per video -- the metric as SURVEY §8(d) defines it (the
         reference's evaluator calls the model once per video, train_net.py:207).  stream=True: MDQE.forward_stream /
         sharding.run_round_robin_stream -- the next video's first pass (round) is queued under the current video's tracker tail."""
@@ -442,20 +561,22 @@ def main():
             else:
                 for o in mdl.forward_stream(inp for _ in range(k)):
                     pass
-        elif not stream:
+            return o
+        plan, chunk_frames = shards[halo]
+        if not stream:
             for _ in range(k):
                 o = sharding.run_round_robin(mdl, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), root_only=True,
-                                             halo_exchange=args.halo_exchange, like=like)
+                                             halo_exchange=halo, like=like, stats=stats)
         else:
             for o in sharding.run_round_robin_stream(mdl, ((chunk_frames, plan, like) for _ in range(k)), rank, world, dist,
-                                                     out_size=(fh, fw), root_only=True, halo_exchange=args.halo_exchange):
+                                                     out_size=(fh, fw), root_only=True, halo_exchange=halo, stats=stats):
                 pass
         return o
 
     def timed(precision, meter_on, stream=False, **kw):
         ops.set_gemm_precision(precision)
         with torch.no_grad():
-            run(args.warmup, stream, **kw)
+            run(args.warmup, stream, **dict(kw, stats=None))
             sync()
             meter.enabled = meter_on
             t0 = time.perf_counter()
@@ -472,22 +593,82 @@ def main():
     def rate(d):
         return {"value": L * args.steps / d, "unit": "frames/s", "ms_per_step": 1e3 * d / args.steps}
 
-    dt, out = timed(args.precision, True)
-    g_timed = meter.summary()
+    def verify_sharded(halo):
+        """Before anything is timed at N > 1: a short video (>= 2 tracker windows, two rounds of chunks) through the sharded schedule
+        and, on rank 0, through one plain `model(inputs)` call -- labels, scores and masks must agree bit for bit.  Every rank learns
+        the verdict (broadcast); a mismatch ends the run with exit code 3 on all ranks."""
+        Lv = max(2 * cfg.n_frames_window_test, 12 * world)
+        cv = max(T + 2, Lv // (2 * world))
+        shards["verify"] = shard(halo, Lv, cv, seed=1)
+        with torch.no_grad():
+            o = sharding.run_round_robin(model, shards["verify"][1], shards["verify"][0], rank, world, dist, out_size=(fh, fw), root_only=True,
+                                         halo_exchange=halo, like=like)
+            ok, why = 1, ""
+            if rank == 0:
+                full = synth_video(0, Lv, seed=1, h=fh, w=fw).pin_memory()
+                ref = model([{"image": list(full), "height": fh, "width": fw}])
+                good, why = same_output(o, ref)
+                ok = int(good)
+                if not good:
+                    print("bench.py: sharded result differs from the single-GPU result (%s; halo_exchange=%s, %d frames, %d-frame chunks, "
+                          "%d ranks)" % (why, halo, Lv, cv, world), file=sys.stderr, flush=True)
+        del shards["verify"]
+        flag = torch.tensor([ok], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.broadcast(flag, 0)
+        sync()
+        return bool(int(flag.item())), {"frames": Lv, "chunk_frames": cv, "rounds": -(-len(sharding.chunk_plan(Lv, T, cfg.clip_stride, cv, halo, world)) // world)}
+
+    def rank_stats(stats):
+        """This rank's mean host milliseconds per video over the timed steps, gathered from all ranks -> {key: [rank 0, rank 1, ...]}."""
+        keys = ("compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed")
+        mine = {k: (sum(v[k] for v in stats) / max(len(stats), 1)) for k in keys}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        return {k: [round(r[k], 2) for r in allr] for k in keys}
+
+    verified = None
+    if sharded:
+        fail_hook("run", rank)
+        ok, vinfo = verify_sharded(args.halo_exchange)
+        if not ok:
+            dist.destroy_process_group()
+            sys.exit(3)
+        verified = dict(vinfo, ok=True, what="the sharded schedule and one plain model(inputs) call on rank 0 agree bit for bit (labels, scores, masks)")
+
+    st_main = [] if sharded else None
+    dt, out = timed(args.precision, True, **({"stats": st_main} if sharded else {}))
+    g_timed, m_timed = meter.summary(), meter.msda_summary()
+    breakdown = None
+    if sharded:
+        breakdown = {"per_rank_ms": rank_stats(st_main), "halo_frac": round(sharding.halo_recompute_frac(shards[args.halo_exchange][0], L), 4),
+                     "rounds": len(chunk) if isinstance(chunk, list) else -(-len(shards[args.halo_exchange][0]) // world),
+                     "what": "mean host ms per video (step) on every rank: compute = queueing a round's frame passes + consuming its clip results "
+                             "(ends with the sync behind the round's last clip kernel); gather_wait = size all-gather = waiting for the slowest "
+                             "rank; gather_payload = the three padded gathers + one D2H of the clip tables; feed = hand-over to the replay thread; "
+                             "replay_exposed = rank 0 joining the tracker replay + video merge after the LAST gather (nothing hides it); halo_frac = "
+                             "per-frame work done twice"}
+        pr = breakdown["per_rank_ms"]
+        breakdown["replay_exposed_ms"] = pr["replay_exposed"][0]
+        breakdown["gather_ms"] = round(max(a + b for a, b in zip(pr["gather_wait"], pr["gather_payload"])), 2)
     # The same launches with the streams serialized (one extra UNTIMED step): in the timed region the dominant GEMM shares
     # the chip with the clip-stream / tracker-stream kernels, which stretches its per-launch duration without being a
     # property of the kernel; both figures are reported.
-    g_iso = None
+    g_iso = m_iso = clip_stage = None
     if not sharded:
-        meter.rec = []
+        meter.reset()
         model.overlap_streams = False
+        strides = meter.stride, meter.msda_stride
+        meter.stride, meter.msda_stride = 1, 1             # (untimed: every launch gets its pair)
         with torch.no_grad():
             meter.enabled = True
             run(1, False)
             sync()
             meter.enabled = False
+        meter.stride, meter.msda_stride = strides
         model.overlap_streams = True
-        g_iso = meter.summary()
+        g_iso, m_iso = meter.summary(), meter.msda_summary()
+        if not args.no_fast_mode:
+            clip_stage = clip_stage_alone(model, cfg, torch.stack(host_frames).cuda(), meter, L, T)
     extra = {}
     if not args.no_fast_mode:
         d, _ = timed(args.precision, False, stream=True)
@@ -521,6 +702,7 @@ def main():
         with torch.no_grad():
             print(json.dumps({"stages_ms": profiling.stage_breakdown(model, torch.stack(host_frames).cuda())}), file=sys.stderr)
 
+    line = None
     if rank == 0:
         g = g_timed
         line = {
@@ -549,6 +731,11 @@ def main():
                                           "halo exchange (T-1 frames of encoder tokens + mask features by send/recv)" if args.halo_exchange
                                           else "a chunk's T-1 frame halo is computed by its owner again")) if sharded else "single GPU"},
         }
+        if verified is not None:
+            line["verified"] = True
+            line["verification"] = verified
+        if breakdown is not None:
+            line["scaling_breakdown"] = breakdown
         if g:
             pk = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3
             kname = ("gemm_nt_f32_k16_kernel (fp32 MFMA GEMM / implicit-GEMM conv incl. its LayerNorm-epilogue form; every launch worth >= 192 tiles of "
@@ -558,21 +745,119 @@ def main():
                                 # HBM bytes need rocprofv3 --pmc passes, which cannot run inside this process: not a live figure -> null;
                                 # the per-launch counters of the dominant launch shape are in the file named below
                                 "traffic": None,
-                                "traffic_ref": "profiles/r03_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: 2 x FETCH_SIZE + WRITE_SIZE = 346 + 836 = 1182 MB per launch vs 1046 MB algorithmic = 1.13x; MFMA pipe busy 0.71 of the kernel's cycles, 0 LDS bank conflicts: r03_pmc_gemm_ffn1_SQ_BUSY_CYCLES.csv)",
-                                "launches": g["launches"], "avg_launch_us": g["avg_us"],
-                                "sampled": "an event pair around every %d-th qualifying launch of the timed region (a pair per launch costs the region 1.2 %%)" % meter.stride,
+                                "traffic_ref": TRAFFIC_REF_GEMM,
+                                "launches": g["launches_timed"], "launches_timed": g["launches_timed"], "launches_total": g["launches_total"],
+                                "avg_launch_us": g["avg_us"],
+                                "sampled": "an event pair around every %d-th qualifying launch of the timed region (a pair per launch costs the region 1.2 %%): "
+                                           "launches_timed of launches_total" % meter.stride,
                                 "note": "timed region: launches overlap with the clip-stream and tracker-stream kernels"}
             if g_iso:
                 line["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": g_iso["tflops"], "peak": pk,
-                                             "unit": "TFLOP/s", "frac": g_iso["tflops"] / pk, "launches": g_iso["launches"],
+                                             "unit": "TFLOP/s", "frac": g_iso["tflops"] / pk, "launches": g_iso["launches_timed"],
                                              "avg_launch_us": g_iso["avg_us"],
                                              "note": "same launches, one extra untimed step with all stages on one stream"}
+        if m_timed:
+            def entry(kind, kernel, m, iso):
+                e = {"bound": "hbm", "kernel": kernel, "achieved": m["tbps"], "achieved_TBps": m["tbps"], "peak": HBM_PEAK_TBPS, "unit": "TB/s",
+                     "frac": m["tbps"] / HBM_PEAK_TBPS, "avg_launch_us": m["avg_us"], "algorithmic_MB_per_launch": m["avg_mbytes"],
+                     "launches_timed": m["launches_timed"], "launches_total": m["launches_total"]}
+                if iso:
+                    e.update(frac_isolated=iso["tbps"] / HBM_PEAK_TBPS, achieved_isolated_TBps=iso["tbps"], avg_launch_us_isolated=iso["avg_us"])
+                return e
+            iso = m_iso or {}
+            if "encoder" in m_timed:
+                rm = entry("encoder", "msda_fused_v3_kernel (mdqe_msda_fused_f32 mode 0: the encoder's multi-scale deformable gather, offsets + softmax + "
+                                      "bilinear gather fused, the coarse levels staged in LDS)", m_timed["encoder"], iso.get("encoder"))
+                rm["traffic"] = None
+                rm["traffic_ref"] = TRAFFIC_REF_MSDA
+                rm["bytes"] = ("algorithmic = SURVEY §8(d): value + sampling offsets + attention logits + output, fp32 = 18.3 MB per frame and layer "
+                               "at 360p, x the frames of the launch")
+                rm["sampled"] = "an event pair around every %d-th launch of the timed region" % meter.msda_stride
+                for k2, kn in (("decoder_box", "msda_fused_v3_kernel<832> (mode 1: the decoder's box-level launch, a clip-frame's map per batch element)"),
+                               ("decoder_temporal", "msda_fused_tp_kernel (the decoder's instance-level launch: 4 frames x 4 levels per clip)")):
+                    if k2 in m_timed:
+                        rm[k2] = entry(k2, kn, m_timed[k2], iso.get(k2))
+                        rm[k2]["bytes"] = ("SURVEY §8(d)'s per-clip figure: every clip(-frame) counts its frames' whole value maps, though overlapping "
+                                           "stride-1 clips share them (a frame belongs to 4 clips: unique bytes are ~4x fewer)")
+                line["roofline_msda"] = rm
+        if clip_stage:
+            line["clip_stage"] = clip_stage
         line.update(extra)
         if not sharded and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
+
+    # N > 1: the halo-exchange form of the same job as an extra key of the same line, so that one multi-GPU run decides the default.
+    # It has never run over RCCL with more than one rank, so it runs LAST and under a soft deadline: if it has not finished in time,
+    # rank 0 prints the line it already has (with the reason) and every rank leaves with exit code 0.
+    if sharded and world > 1 and not args.halo_exchange and os.environ.get("MDQE_BENCH_HALO_AB", "1") != "0" and not args.no_fast_mode:
+        budget = float(os.environ.get("MDQE_BENCH_HALO_AB_S", "75"))
+
+        def give_up():
+            if rank == 0:
+                line["halo_exchange"] = {"error": "did not finish within %.0f s (soft deadline); the headline above is unaffected" % budget}
+                emit(json.dumps(line))
+        sync()
+        with Deadline(budget, give_up):
+            shards[True] = shard(True)
+            ok, vinfo = verify_sharded(True)
+            res = {"verified": bool(ok)}
+            if ok:
+                st_h = []
+                d, _ = timed(args.precision, False, halo=True, stats=st_h)
+                res.update(rate(d), per_rank_ms=rank_stats(st_h), halo_frac=round(sharding.halo_recompute_frac(shards[True][0], L), 4),
+                           what="the same steps with the halo exchange: chunks partition the frames, a chunk's first T-1 clips read the left "
+                                "neighbour's last T-1 frames from shipped encoder tokens + mask features (one grouped send/recv per rank and round)")
+        if rank == 0:
+            line["halo_exchange"] = res
+    if rank == 0:
         emit(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+TRAFFIC_REF_GEMM = ("profiles/r03_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: "
+                    "2 x FETCH_SIZE + WRITE_SIZE = 346 + 836 = 1182 MB per launch vs 1046 MB algorithmic = 1.13x; MFMA pipe busy 0.71 of the kernel's "
+                    "cycles, 0 LDS bank conflicts: r03_pmc_gemm_ffn1_SQ_BUSY_CYCLES.csv)")
+TRAFFIC_REF_MSDA = ("profiles/r02_pmc_msda_v3_p{1..8}.csv + r02_pmc_msda_v3_summary.txt (the 40-frame 360p encoder launch: 2 x FETCH_SIZE + WRITE_SIZE = "
+                    "2 x 399 + 209 MB fetched + written vs 732 MB algorithmic = 1.38x; TA busy 0.67 of the kernel's cycles)")
+
+
+def clip_stage_alone(model, cfg, video_dev, meter, L, T):
+    """The per-clip stage (decoder + inference_clip over cached frames) ALONE, untimed extra (tools/stream_split.py's method): three
+    caches of 40 (+T-1) frames, every clip of the video decoded in three batches; GEMM FLOPs counted by the meter as launched."""
+    eng = model.engine
+    h, w = int(video_dev.shape[-2]), int(video_dev.shape[-1])
+    with torch.no_grad():
+        geo = eng.geometry(h, w)
+        fb = max(8, min(40, 306000 // max(geo.N, 1)))
+        caches = [model._frame_cache(video_dev[a:min(L, a + fb + T - 1)], geo) for a in range(0, L - T + 1, fb)]
+
+        def clips_only():
+            for c in caches:
+                n = c["mf"].shape[0] - (T - 1)
+                if n > 0:
+                    outs = eng.decode_clips(c, list(range(n)), T, geo)
+                    eng.inference_clips(outs, c["mf"], list(range(n)), T)
+        clips_only()
+        torch.cuda.synchronize()
+        meter.flops, meter.counting = 0.0, True
+        clips_only()
+        meter.counting = False
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            clips_only()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+    n_clips = sum(max(c["mf"].shape[0] - (T - 1), 0) for c in caches)
+    del caches
+    torch.cuda.empty_cache()
+    tf = meter.flops / ms / 1e9
+    return {"ms_per_step": ms, "clips": n_clips, "tflops": tf, "peak": F32_MFMA_PEAK_TFLOPS, "frac": tf / F32_MFMA_PEAK_TFLOPS,
+            "gemm_gflop_per_clip": meter.flops / max(n_clips, 1) / 1e9,
+            "what": "decoder + inference_clip of every clip of the step's video over cached frames, nothing else on the chip (batches of %d clips); "
+                    "FLOPs = 2MNK of every GEMM-type launch as issued (no tile padding)" % fb}
 
 
 if __name__ == "__main__":

@@ -8,8 +8,15 @@ padded to the global maximum instance count; every rank then replays the tracker
 order, which is bit-identical to the single-GPU schedule.
 """
 import contextlib
+import datetime
+import os
+import time
 
 import torch
+
+# Every process group this module creates gets a finite timeout: a rank that dies before a collective must not leave the others waiting
+# for the driver's kill (bench.py gives the default group the same one).
+COLLECTIVE_TIMEOUT_S = float(os.environ.get("MDQE_COLLECTIVE_TIMEOUT_S", "120"))
 
 FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
 
@@ -58,54 +65,76 @@ def pack(results, T, device, proto_shapes):
     return meta, vec.contiguous(), msk.contiguous()
 
 
-def all_gather_clips(local, T, dist, world, device, proto_shapes, root=None, rank=0):
+def all_gather_clips(local, T, dist, world, device, proto_shapes, root=None, rank=0, timing=None):
     """Variable-length gather: sizes first (all-gather, 16 B per rank), then three payloads -- clip table, per-instance vectors,
     per-instance mask logits -- padded to the global maxima of clips and of INSTANCES per rank (not clips x max instances).
     root=None: all-gather, every rank gets the merged list.  root=r: payloads go to rank r only (`dist.gather`; the other
-    ranks return None) -- 1/world of the all-gather's traffic into every non-root rank."""
+    ranks return None) -- 1/world of the all-gather's traffic into every non-root rank.
+    timing: a dict that accumulates host seconds -- "pack" (the two concatenations), "wait" (the size all-gather + its host sync: the
+    time this rank waits for the slowest rank of the round), "payload" (issuing the three gathers + reading the clip table and the
+    per-instance vectors back, ONE device->host copy and sync for the whole round)."""
+    t_in = time.perf_counter()
     meta_l, vec_l, msk_l = pack(local, T, device, proto_shapes)
     K = proto_shapes["cls_probs"][0][0]
     sizes = torch.tensor([len(local), vec_l.shape[0]], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    t_pack = time.perf_counter()
     dist.all_gather(all_sizes, sizes)
     sizes_h = torch.stack(all_sizes).cpu().tolist()               # one sync
+    t_sizes = time.perf_counter()
     cmax = max(1, max(s_[0] for s_ in sizes_h))                   # never hand RCCL a zero-size buffer
     imax = max(1, max(s_[1] for s_ in sizes_h))
     mine = root is None or rank == root
 
     def exchange(part, rows):
+        """-> [world, rows, ...] (one allocation; its `world` slices are the collective's output list)."""
         buf = part
         if part.shape[0] != rows:
             buf = torch.zeros((rows,) + tuple(part.shape[1:]), dtype=part.dtype, device=device)
             buf[:part.shape[0]] = part
-        outs = [torch.empty_like(buf) for _ in range(world)] if mine else None
+        whole = torch.empty((world, rows) + tuple(part.shape[1:]), dtype=part.dtype, device=device) if mine else None
+        outs = list(whole.unbind(0)) if mine else None
         if root is None:
             dist.all_gather(outs, buf)
         else:
             dist.gather(buf, outs, dst=root)
-        return outs
+        return whole
 
     g_meta = exchange(meta_l, cmax)
     g_vec = exchange(vec_l, imax)
     g_msk = exchange(msk_l, imax)
+    if timing is not None:
+        timing["pack"] = timing.get("pack", 0.0) + t_pack - t_in
+        timing["wait"] = timing.get("wait", 0.0) + t_sizes - t_pack
     if not mine:
+        if timing is not None:
+            timing["payload"] = timing.get("payload", 0.0) + time.perf_counter() - t_sizes
         return None
     ready = None
     if device.type == "cuda":
         ready = torch.cuda.Event()
         ready.record()                                 # the gathered payloads are complete once this event fires
+        # the clip tables and the per-instance vectors of ALL ranks in one device->host transfer each and ONE sync (round 3: two
+        # blocking copies per rank -- 2N host syncs per round on rank 0's main thread)
+        meta_h = torch.empty(g_meta.shape, dtype=g_meta.dtype, pin_memory=True)
+        vec_h = torch.empty(g_vec.shape, dtype=g_vec.dtype, pin_memory=True)
+        meta_h.copy_(g_meta, non_blocking=True)
+        vec_h.copy_(g_vec, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+    else:
+        meta_h, vec_h = g_meta, g_vec
+    meta_l_, host_all = meta_h.tolist(), vec_h.numpy()
     merged = []
     for r in range(world):
         nclips, ninst = sizes_h[r]
         if nclips == 0:
             continue
-        m = g_meta[r][:nclips].cpu().tolist()
         vec = g_vec[r][:ninst]
-        host = vec.cpu().numpy()                       # one copy per rank (root of N ranks walks N x clips below: keep the per-clip work small)
+        host = host_all[r]
         classes = vec[:, 1].long()
         msk = g_msk[r]
         o = 0
-        for s, e, l, n in m:
+        for s, e, l, n in meta_l_[r][:nclips]:
             pm = msk[o:o + n]
             if e - s != T:
                 pm = pm[:, :e - s].contiguous()        # the short last clip was padded in time
@@ -115,6 +144,8 @@ def all_gather_clips(local, T, dist, world, device, proto_shapes, root=None, ran
                                            "host": {"scores": h[:, 0], "cls_probs": h[:, 2:2 + K], "query_embeds": h[:, 2 + K:]}}))
             o += n
     merged.sort(key=lambda c: c[0])
+    if timing is not None:
+        timing["payload"] = timing.get("payload", 0.0) + time.perf_counter() - t_sizes
     return merged
 
 
@@ -231,7 +262,8 @@ def owned_chunks(plan, world, rank):
     return [g for g in range(len(plan)) if g % world == rank]
 
 
-def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, like=None):
+def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, like=None,
+                    stats=None):
     """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
     Default: every rank all-gathers each round and replays the tracker (all ranks return the video result;
     emit_masks=False skips the mask production on ranks that only keep the tracker in step).
@@ -239,7 +271,7 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
     its main thread goes on with the next round; the other ranks only compute and send, and return None.
     `like`: any [.., h, w] tensor on the frames' device -- needed by a rank that owns NO chunk of this video (more ranks than chunks)."""
     return next(run_round_robin_stream(model, [(chunk_frames, plan, like) if like is not None else (chunk_frames, plan)], rank, world, dist, out_size,
-                                       emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange))
+                                       emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange, stats=stats))
 
 
 _HALO_GROUPS = {}
@@ -256,7 +288,11 @@ def halo_group(dist, world):
     default = getattr(getattr(dist, "group", None), "WORLD", None)     # a re-initialised process group is a new object: no stale handle
     hit = _HALO_GROUPS.get(world)
     if hit is None or hit[0] is not default:
-        hit = _HALO_GROUPS[world] = (default, dist.new_group(ranks=list(range(world))))
+        try:
+            pg = dist.new_group(ranks=list(range(world)), timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+        except TypeError:                              # (a stand-in `dist` of the CPU tests)
+            pg = dist.new_group(ranks=list(range(world)))
+        hit = _HALO_GROUPS[world] = (default, pg)
     return hit[1]
 
 
@@ -352,6 +388,7 @@ class _Job:
             if root_only:
                 self.replay = ReplayThread(self.merger, self.device)
         self.rounds = (len(plan) + world - 1) // world
+        self.tm = {"compute": 0.0, "pack": 0.0, "gather_wait": 0.0, "gather_payload": 0.0, "feed": 0.0, "replay_exposed": 0.0}
 
     def start(self, q):
         """Queue the per-frame work of this rank's chunk of round q (async); the returned generator yields its clip results."""
@@ -412,13 +449,23 @@ class _Job:
             self.replay = None
 
 
-def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False):
+def halo_recompute_frac(plan, L):
+    """Share of the per-frame work that is done twice: frames held by the chunks of a plan / frames of the video - 1 (0 with the halo
+    exchange, whose chunks partition the frames)."""
+    return sum(f1 - f0 for _, f0, f1 in plan) / float(max(L, 1)) - 1.0
+
+
+def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, stats=None):
     """Videos as a stream through the round-robin schedule.  jobs: iterable of (chunk_frames, plan[, like]) as for
     run_round_robin (`like`: any [.., h, w] tensor on the device, for a rank that owns no chunk of a short video); yields each video's result in order (None on the ranks that do not replay).  Within a video the next round's per-frame
     work is queued before this round's clip work; ACROSS videos the first round of video k+1 is queued before the last round's
     clip work of video k, and video k's result is handed out only after that first round has been gathered -- so the replay of
     video k's last round (N x clips of a chunk on rank 0, which has no next round of its own to hide under) and its mask
-    read-back run under video k+1's compute.  Every rank walks the same sequence of collectives."""
+    read-back run under video k+1's compute.  Every rank walks the same sequence of collectives.
+    stats: a list; one dict of host milliseconds per video is appended on every rank -- `compute` (queueing a round's per-frame work +
+    consuming its clip results: ends with the host sync behind the round's last clip kernel), `pack` / `gather_wait` / `gather_payload`
+    (all_gather_clips: `gather_wait` is the wait for the slowest rank of a round), `feed` (handing the round to the tracker or its
+    replay thread), `replay_exposed` (joining the replay + the video merge after the last gather: what no later round hides), `rounds`."""
     it = iter(jobs)
     ws = getattr(model, "work_stream", contextlib.nullcontext)      # the model's high-priority stream (no context is held across a yield)
 
@@ -428,8 +475,13 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
                                            like=j[2] if len(j) > 2 else None, dist=dist, halo_exchange=halo_exchange)
 
     def finish(j):
+        t0 = time.perf_counter()
         with ws():
-            return j.finish()
+            out = j.finish()
+        if stats is not None:
+            j.tm["replay_exposed"] = time.perf_counter() - t0
+            stats.append({k: 1e3 * v for k, v in j.tm.items() if k != "rounds"} | {"rounds": j.rounds})
+        return out
 
     job = pending = nxt_job = None                 # pending: the previous video, all rounds fed, result not yet collected
     try:
@@ -439,6 +491,7 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
         while job is not None:
             nxt_job = None
             for q in range(job.rounds):
+                t_r = time.perf_counter()
                 with ws():
                     if q + 1 < job.rounds:
                         nxt_gen = job.start(q + 1)     # the next round's per-frame work goes to the frame stream first ...
@@ -446,8 +499,15 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
                         nxt_job = open_next()          # ... or the first round of the next video
                         nxt_gen = nxt_job.start(0) if nxt_job is not None else None
                     local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
-                    merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank)
+                    t_c = time.perf_counter()
+                    tg = {}
+                    merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank, timing=tg)
+                    t_g = time.perf_counter()
                     job.feed(merged)
+                    tm = job.tm
+                    tm["compute"] += t_c - t_r
+                    tm["pack"] += tg.get("pack", 0.0); tm["gather_wait"] += tg.get("wait", 0.0); tm["gather_payload"] += tg.get("payload", 0.0)
+                    tm["feed"] += time.perf_counter() - t_g
                 if q == 0 and pending is not None:     # the previous video's tail has had this whole round to finish
                     p, pending = pending, None
                     yield finish(p)

@@ -91,3 +91,52 @@ def test_cpu_baseline_runs_and_reports_cores_and_model():
     assert r["kind"] == "port" and r["unit"] == "frames/s" and r["value"] > 0 and 1 <= r["cores"] <= r["physical_cores"] <= r["logical_cpus"]
     assert r["cpu_model"] and len(r["threads_tried"]) >= 1 and abs(max(r["threads_tried"].values()) - r["value"]) < 1e-3
     assert 0 < r["as_reference"]["value"] < r["value"]           # the reference's window recompute costs three more frame passes
+
+
+def test_a_failing_rank_ends_the_whole_run_quickly_and_loudly():
+    """gloo rehearsal of the failure path of the first real multi-GPU run (no GPU needed: MDQE_BENCH_RANK_PROBE): rank 1 raises before
+    its first collective -> the parent exits non-zero within seconds (torch.distributed.run ends the other ranks), with the failing
+    rank's message on stderr and no JSON line on stdout."""
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "2"], {"MDQE_BENCH_RANK_PROBE": "1", "MDQE_BENCH_FAIL_RANK": "1", "MDQE_BENCH_COLLECTIVE_TIMEOUT_S": "30",
+                                 "MDQE_COLLECTIVE_TIMEOUT_S": "30"}, timeout=240)
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert "rank 1 fails on purpose" in r.stderr
+    assert time.time() - t0 < 120
+
+
+def test_a_hung_rank_times_the_collective_out():
+    """A rank that never arrives (sleeps before its first collective): the others raise after the process group's timeout instead of
+    waiting for the driver's kill; the parent exits non-zero."""
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "2"], {"MDQE_BENCH_RANK_PROBE": "1", "MDQE_BENCH_HANG_RANK": "1", "MDQE_COLLECTIVE_TIMEOUT_S": "8"}, timeout=240)
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert "hangs on purpose" in r.stderr
+    assert time.time() - t0 < 150
+
+
+def test_the_launching_parent_never_touches_the_gpu_runtime():
+    """`python bench.py --gpus N` is a parent that only starts a child process tree: no torch.cuda call of any kind before that
+    (let the ranks refuse)."""
+    import ast
+    import inspect
+    import bench
+    src = inspect.getsource(bench.spawn_ranks)
+    assert "torch.cuda" not in src and "device_count" not in src.replace("not even a device count", "")
+    main_src = inspect.getsource(bench.main)
+    head = main_src[:main_src.index("sys.exit(spawn_ranks(")]
+    assert "torch.cuda" not in "\n".join(l for l in head.splitlines() if not l.strip().startswith("#"))
+    ast.parse(main_src.lstrip())
+
+
+def test_same_output_compares_bit_for_bit():
+    from bench import same_output
+    a = {"pred_labels": [1, 2], "pred_scores": [0.5, 0.25], "pred_masks": [torch.zeros(2, 4, 4, dtype=torch.bool), torch.ones(2, 4, 4, dtype=torch.bool)]}
+    b = {k: ([m.clone() for m in v] if k == "pred_masks" else list(v)) for k, v in a.items()}
+    assert same_output(a, b) == (True, "")
+    b["pred_masks"][1][0, 0, 0] = False
+    assert same_output(a, b)[0] is False and same_output(a, None)[0] is False
+    b = dict(a, pred_scores=[0.5, 0.2500001])
+    assert same_output(a, b)[0] is False

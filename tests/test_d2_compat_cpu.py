@@ -226,3 +226,41 @@ def test_a_broken_detectron2_is_not_swallowed():
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and "LOUD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_a_detectron2_that_fails_to_import_is_a_warning_not_a_crash():
+    """detectron2 installed but `detectron2.modeling` raising ImportError / OSError (its compiled `_C` missing on a ROCm box): the
+    detectron2-free entry point must survive -- a logged warning + `registration_state()`; `MDQE_MI355X_REGISTER=strict` raises."""
+    script = textwrap.dedent('''
+        import importlib.abc, importlib.machinery, logging, os, sys, types
+        d2 = types.ModuleType("detectron2"); d2.__path__ = []
+        sys.modules["detectron2"] = d2
+        class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+            def find_spec(self, name, path, target=None):
+                return importlib.machinery.ModuleSpec(name, self) if name == "detectron2.modeling" else None
+            def create_module(self, spec): return None
+            def exec_module(self, module):
+                raise (OSError if os.environ.get("KIND") == "os" else ImportError)("libtorch_hip.so: undefined symbol (detectron2._C)")
+        sys.meta_path.insert(0, Finder())
+        records = []
+        class H(logging.Handler):
+            def emit(self, r): records.append(r.getMessage())
+        logging.getLogger("mdqe_cvpr2023_amd").addHandler(H())
+        try:
+            import mdqe_cvpr2023_amd.meta_arch as ours
+        except (ImportError, OSError) as e:
+            print("RAISED", type(e).__name__); raise SystemExit(0)
+        st = ours.registration_state()
+        assert st["state"] == "detectron2 import failed" and "_C" in st["error"], st
+        assert any("does not import" in r for r in records), records
+        from mdqe_cvpr2023_amd import MDQE          # the d2-free surface is intact
+        print("WARNED_OK")
+    ''')
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("MDQE_MI355X_REGISTER", None)
+    for kind in ("import", "os"):
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(env, KIND=kind), cwd=ROOT, timeout=600)
+        assert r.returncode == 0 and "WARNED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(env, MDQE_MI355X_REGISTER="strict"), cwd=ROOT,
+                       timeout=600)
+    assert r.returncode == 0 and "RAISED ImportError" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -130,6 +130,13 @@ def test_halo_exchange_plan_partitions_frames_and_clips():
             assert any(s >= f0 and e - s == min(T, L_) for s, e, _ in cl)
 
 
+def test_halo_recompute_fraction():
+    T = 4
+    plan = sharding.chunk_plan(120, T, 1, 30)
+    assert abs(sharding.halo_recompute_frac(plan, 120) - 9 / 120) < 1e-9           # three interior chunk edges x (T-1) frames
+    assert sharding.halo_recompute_frac(sharding.chunk_plan(120, T, 1, 30, halo_exchange=True), 120) == 0.0
+
+
 def test_decreasing_rounds_plan():
     """round_sizes: per-rank frames split into rounds of decreasing chunks (the last round's replay is the one nobody hides);
     chunk_plan with per-round sizes: round q = chunks q*world .. q*world+world-1 of that size; all clips once, in order, both forms."""
@@ -235,10 +242,16 @@ def stream_worker(rank, world, port, outdir, root_only, lengths=None):
         plan = sharding.chunk_plan(Lv, CFG.n_frames_test, 1, 4)
         frames = {g: torch.zeros(plan[g][2] - plan[g][1], 3, HW[0] * 4, HW[1] * 4) for g in sharding.owned_chunks(plan, world, rank)}
         jobs.append((frames, plan, torch.zeros(0, 3, HW[0] * 4, HW[1] * 4)))
-    outs, order = [], []
-    for k, out in enumerate(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (HW[0] * 4, HW[1] * 4), root_only=root_only)):
+    outs, order, stats = [], [], []
+    for k, out in enumerate(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (HW[0] * 4, HW[1] * 4), root_only=root_only,
+                                                            stats=stats)):
         outs.append(out)
         order.append((k, len(log)))               # how much per-frame work had been queued when video k's result came out
+    # the per-video timing breakdown bench.py gathers into `scaling_breakdown`: one entry per video on EVERY rank
+    assert len(stats) == len(jobs)
+    for st, (_, plan, _) in zip(stats, jobs):
+        assert set(st) == {"compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed", "rounds"}
+        assert st["rounds"] == -(-len(plan) // world) and all(v >= 0 for v in st.values())
     torch.save((outs, order, log), os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
