@@ -789,7 +789,8 @@ def main():
     # N > 1: the halo-exchange form of the same job as an extra key of the same line, so that one multi-GPU run decides the default.
     # It has never run over RCCL with more than one rank, so it runs LAST and under a soft deadline: if it has not finished in time,
     # rank 0 prints the line it already has (with the reason) and every rank leaves with exit code 0.
-    if sharded and world > 1 and not args.halo_exchange and os.environ.get("MDQE_BENCH_HALO_AB", "1") != "0" and not args.no_fast_mode:
+    halo_ab = os.environ.get("MDQE_BENCH_HALO_AB", "")             # "1": always, "0": never, unset: with the other extras of the line
+    if sharded and world > 1 and not args.halo_exchange and (halo_ab == "1" or (halo_ab != "0" and not args.no_fast_mode)):
         budget = float(os.environ.get("MDQE_BENCH_HALO_AB_S", "75"))
 
         def give_up():

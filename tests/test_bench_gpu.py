@@ -28,6 +28,15 @@ def test_bench_line_contract():
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["traffic"] is None
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] < 1.0 and rf["peak"] == 157.3
     assert d["config"]["clips_per_step"] == 24 - 2 and d["config"]["instances_out"] >= 1
+    assert rf["launches_timed"] <= rf["launches_total"] and rf["launches_total"] >= 1
+    # the deformable gather's HBM figure is in the same line (north star: "rocprof HBM GB/s on the deformable gather")
+    rm = d["roofline_msda"]
+    assert rm["bound"] == "hbm" and rm["peak"] == 8.0 and rm["unit"] == "TB/s" and 0.0 < rm["frac"] < 1.0 and 0.0 < rm["frac_isolated"] < 1.0
+    assert abs(rm["frac"] - rm["achieved"] / rm["peak"]) < 1e-9 and rm["traffic"] is None and "profiles/" in rm["traffic_ref"]
+    # 24 frames = one pass: 18.3 MB of algorithmic bytes per frame and layer at 360p
+    assert abs(rm["algorithmic_MB_per_launch"] / 24 - 18.28) < 0.1
+    for k in ("decoder_box", "decoder_temporal"):
+        assert 0.0 < rm[k]["frac"] < 1.0 and rm[k]["launches_timed"] >= 1
 
 
 def test_bench_gpus_2_runs_two_ranks_without_torchrun():
@@ -37,8 +46,10 @@ def test_bench_gpus_2_runs_two_ranks_without_torchrun():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     # (--halo-exchange: the rehearsal also takes the neighbour send/recv of the partitioned chunks through bench.py itself, on its own
     # process group; the recompute form of the same schedule is held to the single-GPU result in tests/test_sharded_gpu.py)
-    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "24", "--no-cpu-baseline", "--no-fast-mode",
-            "--halo-exchange"]
+    # MDQE_BENCH_HALO_AB=1: the halo-exchange form runs as the extra key `halo_exchange` of the same line (its own process group, its own
+    # bit-exact verification); the recompute form is the headline
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "24", "--no-cpu-baseline", "--no-fast-mode"]
+    env["MDQE_BENCH_HALO_AB"] = "1"
     if torch.cuda.device_count() < 2:
         r = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
         assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -51,3 +62,11 @@ def test_bench_gpus_2_runs_two_ranks_without_torchrun():
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["frames_per_gpu"] == 24 and d["scaling"] == "weak"
     assert abs(d["value"] - 48 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]              # whole-job frames / max-over-ranks time
     assert d["config"]["instances_out"] >= 1
+    # self-verification + the per-rank breakdown of the sharded schedule (what makes the first real 8-GPU run diagnosable)
+    assert d["verified"] is True and d["verification"]["ok"] is True and d["verification"]["frames"] >= 60
+    sb = d["scaling_breakdown"]
+    for k in ("compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed"):
+        assert len(sb["per_rank_ms"][k]) == 2 and all(v >= 0 for v in sb["per_rank_ms"][k])
+    assert sb["per_rank_ms"]["compute"][0] > 0 and sb["replay_exposed_ms"] >= 0 and sb["gather_ms"] >= 0 and 0 <= sb["halo_frac"] < 0.5
+    he = d["halo_exchange"]
+    assert he["verified"] is True and he["value"] > 0 and he["halo_frac"] == 0.0 and len(he["per_rank_ms"]["compute"]) == 2
