@@ -42,8 +42,8 @@ clip_assoc_kernel(const float* __restrict__ emb, const int* __restrict__ fidx, i
   // ulp to one ulp of the quotient apart and can round to the same float (numerators from 1 - 2^-23 down are >= 1 ulp away and
   // cannot).  Pass 1 finds the maximum (first index among exact ties) and the largest value strictly below it.  Only when that
   // runner-up lies within 2^-23 of the maximum -- possible only for |max| < 1, where fp32 similarities are spaced that finely --
-  // the slow path evaluates what the reference evaluates: sum = sum over the admissible cells of expf(s - max) (index order),
-  // p(q) = expf(s_q - max) / sum in fp32, and the first admissible q < argmax with p(q) == 1.0f / sum wins.
+  // the slow path evaluates what the reference evaluates: sum = sum over the admissible cells of exp(s - max) (index order),
+  // p(q) = exp(s_q - max) / sum in fp32 (exp correctly rounded), and the first admissible q < argmax with p(q) == 1.0f / sum wins.
   // What stays open: torch's vectorised exp and its summation order (lanes of 8 / 16 partial sums) differ from expf and this
   // loop by an ulp, as does the 64-term dot product itself (torch's GEMM vs this loop), so a near-tie of an ulp or two can still
   // resolve differently; a NaN similarity makes the reference's whole column NaN (argmax -> index 0) while this loop keeps the
@@ -72,14 +72,16 @@ clip_assoc_kernel(const float* __restrict__ emb, const int* __restrict__ fidx, i
     else if (s < best && s > second) second = s;
   }
   if (have && second - best > BAND) {                                   // rare: an earlier cell may tie with the maximum in fp32 softmax
+    // (exp through double: the hardware expf is an ulp or two off, and whether exp(-3.7e-8) rounds to 1 or to 1 - 2^-24 is the question)
+    auto exp32 = [](float d) { return (float)exp((double)d); };
     float sum = 0.f;
     for (int q = 0; q < Q; ++q)
-      if (admissible(q)) sum += expf(sim(q) - best);
+      if (admissible(q)) sum += exp32(sim(q) - best);
     const float top = 1.0f / sum;
     for (int q = 0; q < bi; ++q) {
       if (!admissible(q)) continue;
       const float d = sim(q) - best;
-      if (d > BAND && expf(d) / sum == top) { bi = q; break; }
+      if (d > BAND && exp32(d) / sum == top) { bi = q; break; }
     }
   }
   idx[((long)b * T + t) * Q + k] = bi;
