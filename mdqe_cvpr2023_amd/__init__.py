@@ -12,8 +12,11 @@ def __getattr__(name):                 # `from mdqe_cvpr2023_amd import MDQE` wi
     if name in ("MDQE", "MDQE_MI355X", "register_with_detectron2"):
         from . import meta_arch
         return getattr(meta_arch, name)
+    if name in ("build_swinv2_backbone", "SwinTransformerV2"):
+        from . import backbone
+        return getattr(backbone, name)
     raise AttributeError(name)
 
 
 __all__ = ["lib", "load_library", "LibraryMissing", "MDQE", "MDQE_MI355X", "register_with_detectron2", "add_mdqe_config", "add_swinl_config", "add_swinb_config",
-           "add_swins_config", "add_swint_config"]
+           "add_swins_config", "add_swint_config", "build_swinv2_backbone", "SwinTransformerV2"]

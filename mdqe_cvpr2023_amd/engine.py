@@ -79,7 +79,7 @@ def _swin_shift_mask(H, W, ws):
 class Packed:
     """Device-resident weights in kernel layouts, built from a reference-named state dict."""
 
-    def __init__(self, sd, cfg: MDQEConfig, device):
+    def __init__(self, sd, cfg: MDQEConfig, device, only_backbone=False):
         self.cfg = cfg
         dev = torch.device(device)
         sd = {k: v.detach().float().cpu() for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
@@ -161,6 +161,10 @@ class Packed:
                     stg.out_norm = (up(sd[f"{bp}.norm{i}.weight"]), up(sd[f"{bp}.norm{i}.bias"]))
                 sw.stages.append(stg)
             self.swin = sw
+
+        if only_backbone:                        # a backbone on its own (backbone.SwinTransformerV2 behind detectron2's build_backbone)
+            self.level_embed, self.enc, self.inproj, self.dec = None, [], [], []
+            return
 
         # ---- input_proj (a6) ---------------------------------------------------------------------
         self.inproj = []
@@ -311,17 +315,18 @@ class Geometry:
         self.mask_flat = torch.cat([m.flatten() for m in masks]).to(dev)             # [N] bool
         self.any_pad = bool(self.mask_flat.any())
         npf = cfg.hidden_dim // 2
-        pos = torch.cat([_pos_sine(m, npf) + P.level_embed[l].view(1, -1) for l, m in enumerate(masks)], 0)   # [N,C]
-        ref = torch.cat([self._ref_points(H, W) for H, W in shapes], 0)              # transformer_enc.py:48-49
-        self.ref = ref.contiguous().to(dev)
-        pos_d = pos.contiguous().to(dev)
-        nq = P.enc[0].wq.shape[0] if P.enc else 0
-        C = cfg.hidden_dim
         self.pos_tables = []
-        for lyr in P.enc:                                                # (pos+lvl) @ [Woff;Wattn]^T, constant per resolution
-            t = torch.zeros(self.N, C + nq, device=dev)
-            ops.linear(pos_d, lyr.wq, None, out=t[:, C:], ldc=C + nq)
-            self.pos_tables.append(t)
+        if P.level_embed is not None:            # (None: a backbone-only engine needs no encoder constants)
+            pos = torch.cat([_pos_sine(m, npf) + P.level_embed[l].view(1, -1) for l, m in enumerate(masks)], 0)   # [N,C]
+            ref = torch.cat([self._ref_points(H, W) for H, W in shapes], 0)              # transformer_enc.py:48-49
+            self.ref = ref.contiguous().to(dev)
+            pos_d = pos.contiguous().to(dev)
+            nq = P.enc[0].wq.shape[0] if P.enc else 0
+            C = cfg.hidden_dim
+            for lyr in P.enc:                                                # (pos+lvl) @ [Woff;Wattn]^T, constant per resolution
+                t = torch.zeros(self.N, C + nq, device=dev)
+                ops.linear(pos_d, lyr.wq, None, out=t[:, C:], ldc=C + nq)
+                self.pos_tables.append(t)
         self._masks_rep = {}
         self.swin_masks = None
         if P.swin is not None:
@@ -367,9 +372,9 @@ DEC_FUSED = os.environ.get("MDQE_DEC_FUSED", "1") != "0"   # 0: position embeddi
 
 
 class Engine:
-    def __init__(self, cfg: MDQEConfig, state_dict, device="cuda", backbone_fn=None):
+    def __init__(self, cfg: MDQEConfig, state_dict, device="cuda", backbone_fn=None, only_backbone=False):
         self.cfg = cfg
-        self.P = Packed(state_dict, cfg, device)
+        self.P = Packed(state_dict, cfg, device, only_backbone=only_backbone)
         self.dev = self.P.dev
         self.backbone_fn = backbone_fn           # optional callable(frames [NI,3,h,w], geo) -> list of NHWC feats
         self._geo = {}

@@ -950,7 +950,7 @@ def register_with_detectron2(registry=None, takeover=None):
     """Put this implementation into detectron2's `META_ARCH_REGISTRY` BESIDE the reference's `mdqe` package.
 
     The reference registers its own torch model under the name "MDQE" the moment `mdqe` is imported (`mdqe/__init__.py:3` ->
-    `@META_ARCH_REGISTRY.register()` at `mdqe/mdqe.py:60-61`), and `train_net.py:39` / `demo/demo.py:16` import `mdqe` for
+    `@META_ARCH_REGISTRY.register()` at `mdqe/mdqe.py:60-61`), and `train_net.py:40-43` / `demo/demo.py:16` import `mdqe` for
     `add_mdqe_config` and the data loaders; fvcore's `Registry` asserts on a second registration of a name.  So:
 
     * the alias `MDQE_MI355X` is always registered (no collision possible);
@@ -1025,4 +1025,16 @@ def registration_state():
     return dict(_REGISTRATION)
 
 
+def _register_backbone():
+    """The Swin builder goes into BACKBONE_REGISTRY whenever the meta-architecture went into META_ARCH_REGISTRY (same policy)."""
+    if _REGISTRATION.get("state") in ("MDQE taken over", "alias only"):
+        from .backbone import register_backbone_with_detectron2
+        try:
+            from detectron2.modeling import BACKBONE_REGISTRY  # noqa: F401
+        except (ImportError, OSError, AttributeError):
+            return                                   # (a stand-in detectron2 without a backbone registry)
+        register_backbone_with_detectron2()
+
+
 register_with_detectron2()                        # silent without detectron2, a warning if it is there but does not import, loud otherwise
+_register_backbone()

@@ -89,7 +89,7 @@ def test_d2_registration_and_config_functions_execute():
 
 # ---- coexistence with the reference's own `mdqe` package ---------------------------------------------------------
 # fvcore's Registry refuses a second registration of a name (`assert name not in self._obj_map`); the reference registers ITS model as
-# "MDQE" when `mdqe` is imported (mdqe/__init__.py:3, mdqe/mdqe.py:60-61) and train_net.py:39 / demo/demo.py:16 import `mdqe`.  The
+# "MDQE" when `mdqe` is imported (mdqe/__init__.py:3, mdqe/mdqe.py:60-61) and train_net.py:40-43 / demo/demo.py:16 import `mdqe`.  The
 # stand-ins below keep exactly those two behaviours: a registry that asserts on duplicates, and an `mdqe` package whose import registers
 # a class named MDQE.  Both import orders must end with `build_model(cfg)` constructing THIS package's class.
 COEXIST = textwrap.dedent('''
@@ -124,7 +124,7 @@ COEXIST = textwrap.dedent('''
     mod.build_model = build_model
     sys.modules.update({"detectron2": d2, "detectron2.config": cfgm, "detectron2.modeling": mod})
 
-    def import_reference():                           # what `from mdqe import add_mdqe_config, ...` triggers (train_net.py:39)
+    def import_reference():                           # what `from mdqe import add_mdqe_config, ...` triggers (train_net.py:40)
         ref = types.ModuleType("mdqe"); ref.__path__ = []
         sub = types.ModuleType("mdqe.mdqe")
         @REG.register()

@@ -169,6 +169,33 @@ def test_swinv2_backbone_vs_reference():
         assert maxdiff(o, ref) < 2e-4, name
 
 
+def test_build_swinv2_backbone_surface_vs_reference():
+    """The detectron2-facing builder (`build_swinv2_backbone(cfg, input_shape)`, swin_transformer_v2.py:675-702): reference parameter
+    names through `load_state_dict`, `forward(x)` -> {"stage3","stage4","stage5"} NCHW equal to the reference run (fixture swin_small),
+    `output_shape()` as the meta-architecture reads it (mdqe/mdqe.py:28-30)."""
+    from types import SimpleNamespace as NS
+    from mdqe_cvpr2023_amd import build_swinv2_backbone
+    fx = Fixture("swin_small")
+    cfg = NS(MODEL=NS(DEVICE="cuda", SWIN=NS(EMBED_DIM=32, DEPTHS=[2, 2, 2, 2], NUM_HEADS=[2, 4, 8, 16], WINDOW_SIZE=4, MLP_RATIO=4,
+                                             OUT_FEATURES=["stage3", "stage4", "stage5"])))
+    bb = build_swinv2_backbone(cfg, NS(channels=3)).eval()
+    sd = {k.replace("bb.", "", 1): v for k, v in fx.state().items()}
+    for k in fx.z.files:
+        if k.startswith("ls::"):
+            sd[k[4:]] = fx.t(k)
+    missing, unexpected = bb.load_state_dict(sd, strict=False)
+    assert not missing, missing[:5]
+    outs = bb(fx.t("x").cuda())
+    assert list(outs) == ["stage3", "stage4", "stage5"]
+    shp = bb.output_shape()
+    for name, stride, ch in (("stage3", 8, 64), ("stage4", 16, 128), ("stage5", 32, 256)):
+        ref = fx.t(name)
+        assert outs[name].shape == ref.shape and shp[name].stride == stride and shp[name].channels == ch
+        assert maxdiff(outs[name].cpu(), ref) < 2e-4, name
+    with pytest.raises(RuntimeError):
+        bb(torch.zeros(1, 3, 60, 96, device="cuda"))                     # not padded to 32: loud
+
+
 def test_swinl_ovis_runs_end_to_end():
     """swinl_ovis (config 4) at a reduced frame size: Swin-L backbone (195 M params, window 12/6), hidden 192 (head dim 24,
     mask dim 24, GroupNorm 24), 2-frame clips.  Encoder output vs the CPU oracle; whole video well-formed."""
