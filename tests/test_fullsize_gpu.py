@@ -22,7 +22,7 @@ import pytest
 import torch
 
 import mdqe_oracle as O
-from _golden import maxdiff
+from _golden import maxdiff, record_margin
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -105,6 +105,16 @@ def _workload(name, fh, fw, n_frames, window, max_inst=120):
     return ref
 
 
+GROUP = {"name": "?"}          # the parity-margin group of the running test: "<config> <frames> frames, <gemm mode>, <direct|chained>"
+
+
+def _m(stage, got, want, tol, scale=1.0):
+    """max |got - want| recorded under the running group + asserted against tol * scale."""
+    d = record_margin(GROUP["name"], stage, maxdiff(got, want), scale, tol)
+    assert d < tol * scale, (GROUP["name"], stage, d, tol * scale)
+    return d
+
+
 def _model(ref):
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     return MDQE(ref["cfg"], state_dict=ref["sd"]).eval()
@@ -112,19 +122,21 @@ def _model(ref):
 
 def _check_video(out, ref_video, tol=1e-3):
     assert out["pred_labels"] == ref_video["pred_labels"]
-    assert np.allclose(out["pred_scores"], ref_video["pred_scores"], atol=1e-3)
+    _m("video scores", torch.tensor(out["pred_scores"]), torch.tensor(ref_video["pred_scores"]), 1e-3)
     got, want = torch.stack(out["pred_masks"]), torch.stack(ref_video["pred_masks"])
     assert got.shape == want.shape and got.dtype == torch.bool
-    assert float((got != want).float().mean()) < tol
+    mis = record_margin(GROUP["name"], "final masks: mismatching pixel fraction", float((got != want).float().mean()), 1.0, tol)
+    assert mis < tol
 
 
-def _check_clip(res, rc, scale=1.0):
+def _check_clip(res, rc, scale=1.0, tag="clip"):
     assert res["pred_masks"].shape == rc["pred_masks"].shape, (res["pred_masks"].shape, rc["pred_masks"].shape)
     assert res["pred_classes"].tolist() == rc["pred_classes"].tolist()
-    assert maxdiff(res["pred_masks"].cpu(), rc["pred_masks"]) < 1e-3 * scale
-    assert maxdiff(res["scores"].cpu(), rc["scores"]) < 1e-3
-    assert maxdiff(res["cls_probs"].cpu(), rc["cls_probs"]) < 1e-3
-    assert maxdiff(res["query_embeds"].cpu(), rc["query_embeds"]) < 1e-3 * max(1.0, float(rc["query_embeds"].abs().max()))
+    if rc["pred_masks"].numel():
+        _m(tag + " mask logits", res["pred_masks"].cpu(), rc["pred_masks"], 1e-3, scale)
+        _m(tag + " scores", res["scores"].cpu(), rc["scores"], 1e-3)
+        _m(tag + " cls_probs", res["cls_probs"].cpu(), rc["cls_probs"], 1e-3)
+        _m(tag + " query_embeds", res["query_embeds"].cpu(), rc["query_embeds"], 1e-3, max(1.0, float(rc["query_embeds"].abs().max())))
 
 
 def _chain(ref, model, fh, fw):
@@ -139,8 +151,8 @@ def _chain(ref, model, fh, fw):
         fd = torch.stack(ref["frames"]).cuda()
         enc = eng.encode(eng.backbone(fd, geo), geo)
         mf = eng.mask_features(enc, geo)
-        assert maxdiff(enc.cpu(), enc_r) < 1e-3 * float(enc_r.abs().max())
-        assert maxdiff(mf.cpu(), mf_r.permute(1, 2, 3, 0)) < 1e-3 * max(1.0, float(mf_r.abs().max()))
+        _m("a1-a8 encoder tokens", enc.cpu(), enc_r, 1e-3, float(enc_r.abs().max()))
+        _m("a10 mask features", mf.cpu(), mf_r.permute(1, 2, 3, 0), 1e-3, max(1.0, float(mf_r.abs().max())))
         del enc, mf
         enc_d = enc_r.cuda().contiguous()
         mf_d = mf_r.permute(1, 2, 3, 0).contiguous().cuda()                  # [frames, Hm, Wm, M] channels-last, as the engine keeps it
@@ -154,15 +166,14 @@ def _chain(ref, model, fh, fw):
             # a11-a14: decoder of this clip on the oracle's encoder tokens
             out = eng.decode_clips(cache, [s], e - s, geo)
             for k in ("cls", "mask_coeff", "query_embed"):
-                d = maxdiff(out[k][0].cpu(), c["out"][k][0])
-                assert d < 1e-3 * max(1.0, float(c["out"][k].abs().max())), (s, k, d)
+                _m("a11-a14 decoder " + k, out[k][0].cpu(), c["out"][k][0], 1e-3, max(1.0, float(c["out"][k].abs().max())))
             # a15: inference_clip on the ORACLE's decoder heads
             outs_r = {k: c["out"][k].cuda().contiguous() for k in ("cls", "mask_coeff", "query_embed")}
             res = eng.inference_clips(outs_r, [mf_d[s:e]])[0]
-            _check_clip(res, c["clip"], lscale)
+            _check_clip(res, c["clip"], lscale, "a15 inference_clip (oracle heads)")
             # ... and end to end within the clip stage (decoder -> inference_clip on product values)
             res2 = eng.inference_clips(out, [mf_d[s:e]])[0]
-            _check_clip(res2, c["clip"], lscale)
+            _check_clip(res2, c["clip"], lscale, "a11-a15 decoder + inference_clip")
             rc = c["clip"]
             items.append((s, e, c["last"], {"scores": rc["scores"].cuda(), "pred_classes": rc["pred_classes"].cuda(),
                                             "cls_probs": rc["cls_probs"].cuda(), "query_embeds": rc["query_embeds"].cuda(),
@@ -176,7 +187,7 @@ def _chain(ref, model, fh, fw):
             m.feed_many([(s, e, l, dict(r)) for s, e, l, r in items])
             assert len(m.cls_clips) == len(ref["cls_w"])
             for a, b in zip(m.cls_clips, ref["cls_w"]):
-                assert maxdiff(a, b) < 1e-5
+                _m("a16 tracker window cls", a, b, 1e-5)
             _check_video(m.finish(), ref["video"])
         model.merge_on_cpu, model.early_masks = None, True
 
@@ -188,7 +199,7 @@ def _direct(ref, model, fh, fw):
     assert len(trace) == len(ref["clips"])
     lscale = max(1.0, max(float(c["clip"]["pred_masks"].abs().max()) for c in ref["clips"] if c["clip"]["pred_masks"].numel()))
     for res, c in zip(trace, ref["clips"]):
-        _check_clip(res, c["clip"], lscale)
+        _check_clip(res, c["clip"], lscale, "a1-a15 frames -> clip")
     _check_video(out, ref["video"])
     assert out["pred_masks"][0].shape == (len(ref["frames"]), fh, fw)
     return out
@@ -199,7 +210,9 @@ def test_r50_ovis_360_full_size_end_to_end(gemm_precision):
     ref = _workload("R50_ovis_360", 360, 640, 6, 4)
     assert sum(int(c["clip"]["scores"].numel()) for c in ref["clips"]) > len(ref["clips"])      # the workload keeps >1 instance per clip
     model = _model(ref)
+    GROUP["name"] = "R50_ovis_360 6x360x640 %s chained" % gemm_precision
     _chain(ref, model, 360, 640)
+    GROUP["name"] = "R50_ovis_360 6x360x640 %s direct" % gemm_precision
     _direct(ref, model, 360, 640)
 
 
@@ -210,7 +223,9 @@ def test_r50_ovis_720_geometry_full_size(gemm_precision):
     model = _model(ref)
     geo = model.engine.geometry(640, 1138)
     assert (geo.Hp, geo.Wp, geo.N) == (640, 1152, 15300) and geo.shapes == [(80, 144), (40, 72), (20, 36), (10, 18)]
+    GROUP["name"] = "R50_ovis_720 3x640x1138 %s chained" % gemm_precision
     _chain(ref, model, 640, 1138)
+    GROUP["name"] = "R50_ovis_720 3x640x1138 %s direct" % gemm_precision
     _direct(ref, model, 640, 1138)
 
 
@@ -246,7 +261,9 @@ def test_swinl_ovis_480p_full_size(gemm_precision):
     model = _model(ref)
     geo = model.engine.geometry(480, 853)
     assert (geo.Hp, geo.Wp, geo.N) == (480, 864, 8617) and geo.shapes == [(60, 108), (30, 54), (15, 27), (8, 14)]
+    GROUP["name"] = "swinl_ovis 3x480x853 %s chained" % gemm_precision
     _chain(ref, model, 480, 853)
+    GROUP["name"] = "swinl_ovis 3x480x853 %s direct" % gemm_precision
     _direct(ref, model, 480, 853)
 
 
