@@ -367,6 +367,8 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 
 static int g_k16_stagger = 0;      // tools/ A/B: first-round start offset between the blocks of a CU, in 10-ns ticks
 extern "C" int mdqe_debug_gemm_stagger(int v) { g_k16_stagger = v; return MDQE_OK; }
+static int g_k16_lds_pad = 0;      // tools/ A/B: extra dynamic LDS bytes per block (caps the blocks per CU: occupancy experiments)
+extern "C" int mdqe_debug_gemm_lds_pad(int v) { g_k16_lds_pad = v > 0 ? v : 0; return MDQE_OK; }
 static int g_k16_stages = 0;       // tools/ A/B: 0 = by grid size, 2 / 4 = forced
 extern "C" int mdqe_debug_gemm_stages(int v) { g_k16_stages = v; return MDQE_OK; }
 
@@ -378,6 +380,10 @@ static int launch_k16_ns_(const GemmParams& p_in, hipStream_t st) {
   size_t smem = (size_t)NS * (BM + BN) * 16 * sizeof(float);
   if (smem < (size_t)WM * WN * 4096) smem = (size_t)WM * WN * 4096;        // per-wave epilogue slices
   auto kern = gemm_nt_f32_k16_kernel<BM, BN, WM, WN, CONV, LN, NS, CAT>;
+  if (g_k16_lds_pad > 0) {                                                 // tools/ only
+    smem += (size_t)g_k16_lds_pad;
+    if (smem > 64 * 1024 && mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) return MDQE_ELAUNCH;
+  }
   hipLaunchKernelGGL(kern, dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(64 * WM * WN), smem, st, p);
   return mdqe_launch_status();
 }

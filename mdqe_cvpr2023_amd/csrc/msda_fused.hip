@@ -263,8 +263,12 @@ msda_fused_v2_kernel(const float* __restrict__ value, long value_bytes, long ldv
 // corners with ds_read_b128 instead of going through the texture path, which is what bounds v2 (TA busy 0.62-0.71, L1 hit 65 %).
 // A corner outside the map points at a zero row behind the staged levels (v2: an out-of-range buffer offset that reads as 0).
 // The sample descriptors take half of v2's LDS: the 16 samples go in two halves of 8 (same order).
-template <int L, int P, int DD, int NT>
-__global__ void __launch_bounds__(NT)
+// WPE: waves per SIMD the register allocation must allow (0: no constraint).  The natural allocation is 68 VGPRs = 7 waves per SIMD,
+// ONE wave short of what two 1024-thread blocks per CU need (2 x 16 waves = 8 per SIMD): with WPE = 8 the same code takes 64 VGPRs
+// (no spill) and the second block of a CU -- which the 38 + 37 KB of LDS per block always allowed -- becomes resident, so one block
+// stages / sets up while the other gathers.
+template <int L, int P, int DD, int NT, int WPE = 0>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, WPE > 0 ? WPE : 8)))
 msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode, const float* __restrict__ grid, MsdaLevels lv,
@@ -642,7 +646,10 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
           hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
                              ref, ref_bstride, ref_dim, mode, grid, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
         };
-        if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
+        // two blocks of 1024 threads per CU need the 8-waves-per-SIMD build (variant bit 256 of the tools/ sweep turns it off)
+        const bool wpe8 = !(g_msda_variant >= 0 && (g_msda_variant & 256)) && 2 * smem + 1024 <= 160 * 1024;
+        if (nt == 1024 && wpe8) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8>); }
+        else if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
         else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
         else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
         if (!lds_ok) { (void)hipGetLastError(); return MDQE_ELAUNCH; }     // `out` was never written: not MDQE_OK (as msda.hip does)

@@ -71,6 +71,7 @@ def worker(rank, world, port, outdir, modes, backend, p2p_self):
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(max(1, min(4, (os.cpu_count() or 4) // max(world, 1))))     # `world` ranks share the box's cores: no oversubscription
     backend = backend or os.environ.get("MDQE_TEST_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
     dev = rank if (backend == "nccl" and world > 1) else 0
     torch.cuda.set_device(dev)
