@@ -12,6 +12,7 @@
 // Thread mapping as in msda.hip: a lane owns 4 channels of one (query, head); a wave64 = one query
 // when M*D/4 = 64.  Level geometry comes in by value (no device table reads).
 #include "common.h"
+#include <type_traits>
 
 struct MsdaLevels { int H[16]; int W[16]; int start[16]; };
 
@@ -267,13 +268,20 @@ msda_fused_v2_kernel(const float* __restrict__ value, long value_bytes, long ldv
 // ONE wave short of what two 1024-thread blocks per CU need (2 x 16 waves = 8 per SIMD): with WPE = 8 the same code takes 64 VGPRs
 // (no spill) and the second block of a CU -- which the 38 + 37 KB of LDS per block always allowed -- becomes resident, so one block
 // stages / sets up while the other gathers.
-template <int L, int P, int DD, int NT, int WPE = 0>
+// LSC: the first staged level as a COMPILE-TIME constant (-1: the runtime argument).  With a runtime LS every sample's `level staged?`
+// test is a (wave-uniform) branch, i.e. a basic-block boundary per sample: the compiler drains `vmcnt` at each one and a wave never has
+// more than the 4 corner loads of ONE sample in flight -- in places one (round 4, from the ISA: `buffer_load; s_waitcnt vmcnt(0)` four
+// times in a row).  With LSC the 8 samples of a half are straight-line code and the loads of several samples are in flight together.
+// GS: samples whose corner loads are in flight together in the LSC form (4 = a whole level: 64 VGPRs of data, one 1024-thread block
+// per CU; 2: 32 VGPRs, fits the 8-waves-per-SIMD build).
+template <int L, int P, int DD, int NT, int WPE = 0, int LSC = -1, int GS = 4>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, WPE > 0 ? WPE : 8)))
 msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode, const float* __restrict__ grid, MsdaLevels lv,
-                     int B, int M, int Q, int LS, int stage_px, int chunk, int nchunk, float scale,
+                     int B, int M, int Q, int LS_rt, int stage_px, int chunk, int nchunk, float scale,
                      float* __restrict__ out, long ldout, int xcd_order) {
+  const int LS = LSC >= 0 ? LSC : LS_rt;
   constexpr int LP = L * P;                    // 16
   constexpr int D = DD, HS = LP / 2;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -388,23 +396,57 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if constexpr (LSC >= 0) {
+        // One LEVEL at a time (P == 4: samples 4g .. 4g+3 of the half): its 4 descriptors, then all 16 corner loads in flight together,
+        // then the 16 multiply-adds in v2's order (sample by sample, corner by corner: the same bits).  The scheduling fences keep the
+        // compiler from hoisting the next level's loads over this one's (128 live VGPRs of data and spills, as it does unfenced).
 #pragma unroll
-      for (int s = 0; s < HS; ++s) {
-        const int l = (half * HS + s) / P;        // compile-time
-        const u32x4 o = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + s) * 4);
-        const f32x4 w = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + s) * 4);
-        if (l >= LS) {
+        for (int gq = 0; gq < HS / GS; ++gq) {
+          constexpr int PP = GS;
+          const int l = (half * HS + gq * GS) / P;   // compile-time (GS divides P: a group never straddles two levels)
+          u32x4 o[PP];
+          f32x4 w[PP], v[PP][4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[c] + lane_lds);
-            acc += v * w[c];
+          for (int s = 0; s < PP; ++s) {
+            o[s] = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + gq * PP + s) * 4);
+            w[s] = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + gq * PP + s) * 4);
           }
-        } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
-            acc += v * w[c];
+          for (int s = 0; s < PP; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (l >= LS) v[s][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[s][c] + lane_lds);
+              else v[s][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, chan ? o[s][c] + lane_off : MSDA_OOB, 0, 0));
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < PP; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc += v[s][c] * w[s][c];
+          // (pin the chain here: `acc` is only stored under `chan && live`, and LLVM otherwise SINKS all 64 multiply-adds into that
+          // block, keeping every loaded value alive -- and spilled -- until the end of the query)
+          asm volatile("" : "+v"(acc));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          const int l = (half * HS + s) / P;        // compile-time
+          const u32x4 o = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + s) * 4);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + s) * 4);
+          if (l >= LS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[c] + lane_lds);
+              acc += v * w[c];
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
+              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
+              acc += v * w[c];
+            }
           }
         }
       }
@@ -421,13 +463,14 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
 // stays in registers, 2 barriers per frame.  Lane mapping of the set-up as v2 / v3 (lane j of a (query, head) group prepares look-ups
 // 2j and 2j+1 of the phase: level (2j+k) / P, point (2j+k) % P).  Sum order: frame-major (v2: level-major) -- the same value up to fp32
 // reassociation, held to v2 at 1e-5 (tests/test_kernels_gpu.py) and to the reference through the decoder goldens.
-template <int F, int P, int G, int DD, int NT>
+template <int F, int P, int G, int DD, int NT, int LSC = -1>
 __global__ void __launch_bounds__(NT)
 msda_fused_tp_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, const float* __restrict__ grid, MsdaLevels lv,
-                     int B, int M, int Q, int LS, int stage_px, int chunk, int nchunk, float scale,
+                     int B, int M, int Q, int LS_rt, int stage_px, int chunk, int nchunk, float scale,
                      float* __restrict__ out, long ldout) {
+  const int LS = LSC >= 0 ? LSC : LS_rt;         // compile-time first staged level: straight-line gather, a level's loads in flight together (v3)
   constexpr int FP = F * P;                    // 16 (frame, point) samples share one softmax
   constexpr int GP = G * P;                    // 16 look-ups per frame phase
   constexpr int D = DD, HS = GP / 2;
@@ -535,23 +578,51 @@ msda_fused_tp_kernel(const float* __restrict__ value, long value_bytes, long ldv
           }
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (LSC >= 0) {
 #pragma unroll
-        for (int s = 0; s < HS; ++s) {
-          const int g = (half * HS + s) / P;      // compile-time
-          const u32x4 o = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + s) * 4);
-          const f32x4 w = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + s) * 4);
-          if (g >= LS) {
+          for (int gq = 0; gq < HS / P; ++gq) {     // one level at a time: descriptors, 16 loads in flight, 16 multiply-adds in order
+            const int g = (half * HS) / P + gq;     // compile-time
+            u32x4 o[P];
+            f32x4 w[P], v[P][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[c] + lane_lds);
-              acc += v * w[c];
+            for (int s = 0; s < P; ++s) {
+              o[s] = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + gq * P + s) * 4);
+              w[s] = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + gq * P + s) * 4);
             }
-          } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
-              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
-              acc += v * w[c];
+            for (int s = 0; s < P; ++s)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (g >= LS) v[s][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[s][c] + lane_lds);
+                else v[s][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, chan ? o[s][c] + lane_off : MSDA_OOB, 0, 0));
+              }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < P; ++s)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc += v[s][c] * w[s][c];
+            asm volatile("" : "+v"(acc));           // (see msda_fused_v3_kernel: keeps LLVM from sinking the chain to the store)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < HS; ++s) {
+            const int g = (half * HS + s) / P;      // compile-time
+            const u32x4 o = *reinterpret_cast<const u32x4*>(soff + (grp * (HS + 1) + s) * 4);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(swgt + (grp * (HS + 1) + s) * 4);
+            if (g >= LS) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[c] + lane_lds);
+                acc += v * w[c];
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
+                acc += v * w[c];
+              }
             }
           }
         }
@@ -648,10 +719,30 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         };
         // two blocks of 1024 threads per CU need the 8-waves-per-SIMD build (variant bit 256 of the tools/ sweep turns it off)
         const bool wpe8 = !(g_msda_variant >= 0 && (g_msda_variant & 256)) && 2 * smem + 1024 <= 160 * 1024;
-        if (nt == 1024 && wpe8) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8>); }
-        else if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
-        else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
-        else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
+        // the first staged level as a template constant (2: the two coarsest levels -- every shipped geometry at 360p / Swin-L, the
+        // encoder at 640p --, 3: the coarsest only -- the decoder at 640p); variant bit 512 of the tools/ sweep keeps it a runtime value
+        const int lsc = (g_msda_variant >= 0 && (g_msda_variant & 512)) ? -1 : (LS == 2 || LS == 3) ? LS : -1;
+        // LSC form: GS = 4 (a level's 16 loads in flight, 126 VGPRs: one 1024-thread block per CU) or, variant bit 1024 of the tools/ sweep,
+        // GS = 2 in the 8-waves-per-SIMD build (two blocks per CU).  The runtime-LS form keeps round 3's code.
+        const bool gs2 = g_msda_variant >= 0 && (g_msda_variant & 1024);
+        auto pick = [&](auto lsc_) {
+          constexpr int C = decltype(lsc_)::value;
+          if constexpr (C < 0) {
+            if (nt == 1024 && wpe8) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8>); }
+            else if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
+            else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
+            else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
+          } else {
+            if (nt == 1024 && gs2 && wpe8) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8, C, 2>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8, C, 2>); }
+            else if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 0, C>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 0, C>); }
+            else if (nt == 832 && gs2) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832, 7, C, 2>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832, 7, C, 2>); }
+            else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832, 0, C>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832, 0, C>); }
+            else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512, 0, C>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512, 0, C>); }
+          }
+        };
+        if (lsc == 2) pick(std::integral_constant<int, 2>{});
+        else if (lsc == 3) pick(std::integral_constant<int, 3>{});
+        else pick(std::integral_constant<int, -1>{});
         if (!lds_ok) { (void)hipGetLastError(); return MDQE_ELAUNCH; }     // `out` was never written: not MDQE_OK (as msda.hip does)
         return mdqe_launch_status();
       }
@@ -681,9 +772,16 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
           hipLaunchKernelGGL(kern, dim3((unsigned)nbt), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
                              ref, ref_bstride, grid, lv, B, M, Q, LS, (int)px, chunk, runs, scale, out, ldout);
         };
-        if (nt == 1024) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 1024>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 1024>); }
-        else if (nt == 832) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 832>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 832>); }
-        else { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 512>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 512>); }
+        const int lsc = (g_msda_variant >= 0 && (g_msda_variant & 512)) ? -1 : (LS == 2 || LS == 3) ? LS : -1;
+        auto pick = [&](auto lsc_) {
+          constexpr int C = decltype(lsc_)::value;
+          if (nt == 1024) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 1024, C>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 1024, C>); }
+          else if (nt == 832) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 832, C>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 832, C>); }
+          else { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 512, C>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 512, C>); }
+        };
+        if (lsc == 2) pick(std::integral_constant<int, 2>{});
+        else if (lsc == 3) pick(std::integral_constant<int, 3>{});
+        else pick(std::integral_constant<int, -1>{});
         if (!lds_ok) { (void)hipGetLastError(); return MDQE_ELAUNCH; }
         return mdqe_launch_status();
       }
