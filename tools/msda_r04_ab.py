@@ -7,9 +7,9 @@ import os, runpy, sys, torch
 form = sys.argv[1] if len(sys.argv) > 1 else "enc"
 sys.argv = [sys.argv[0]]
 here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(here))
 from mdqe_cvpr2023_amd._lib import lib
 if form == "dec":
-    sys.path.insert(0, os.path.dirname(here))
     from mdqe_cvpr2023_amd import ops
     g = torch.Generator().manual_seed(0)
     GEO = os.environ.get("MSDA_GEO", "360p")
