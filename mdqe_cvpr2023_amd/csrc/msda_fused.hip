@@ -272,8 +272,8 @@ msda_fused_v2_kernel(const float* __restrict__ value, long value_bytes, long ldv
 // test is a (wave-uniform) branch, i.e. a basic-block boundary per sample: the compiler drains `vmcnt` at each one and a wave never has
 // more than the 4 corner loads of ONE sample in flight -- in places one (round 4, from the ISA: `buffer_load; s_waitcnt vmcnt(0)` four
 // times in a row).  With LSC the 8 samples of a half are straight-line code and the loads of several samples are in flight together.
-// GS: samples whose corner loads are in flight together in the LSC form (4 = a whole level: 64 VGPRs of data, one 1024-thread block
-// per CU; 2: 32 VGPRs, fits the 8-waves-per-SIMD build).
+// GS: samples whose corner loads are in flight together in the LSC form (4 = a whole level: 64 VGPRs of data, 126 in all -- one
+// 1024-thread block per CU; 2 was measured in the 8-waves-per-SIMD build: 25 spilled registers, 737 us against 435, not instantiated).
 template <int L, int P, int DD, int NT, int WPE = 0, int LSC = -1, int GS = 4>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, WPE > 0 ? WPE : 8)))
 msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
@@ -719,23 +719,25 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         };
         // two blocks of 1024 threads per CU need the 8-waves-per-SIMD build (variant bit 256 of the tools/ sweep turns it off)
         const bool wpe8 = !(g_msda_variant >= 0 && (g_msda_variant & 256)) && 2 * smem + 1024 <= 160 * 1024;
-        // the first staged level as a template constant (2: the two coarsest levels -- every shipped geometry at 360p / Swin-L, the
-        // encoder at 640p --, 3: the coarsest only -- the decoder at 640p); variant bit 512 of the tools/ sweep keeps it a runtime value
-        const int lsc = (g_msda_variant >= 0 && (g_msda_variant & 512)) ? -1 : (LS == 2 || LS == 3) ? LS : -1;
-        // LSC form: GS = 4 (a level's 16 loads in flight, 126 VGPRs: one 1024-thread block per CU) or, variant bit 1024 of the tools/ sweep,
-        // GS = 2 in the 8-waves-per-SIMD build (two blocks per CU).  The runtime-LS form keeps round 3's code.
-        const bool gs2 = g_msda_variant >= 0 && (g_msda_variant & 1024);
+        // Which build (round 4, tools/msda_r04_ab.py, profiles/r04_msda_compile_time_level_ab.txt; all forms give the same bits):
+        //  * two 1024-thread blocks fit a CU (the encoder at 360p: 2 x 75 KB): round 3's code in the 8-waves-per-SIMD build -- 435 us
+        //    against 454 (natural allocation, one block per CU) and 458 (compile-time level);
+        //  * otherwise, two staged levels: the compile-time-level form (a level's 16 corner loads in flight) -- decoder box level at
+        //    360p 103 against 108 us, Swin-L encoder 223 against 228, 640p encoder equal;
+        //  * the coarsest level only (decoder at 640p): the runtime form (149 against 152 us).
+        // variant bits of the tools/ sweep: 256 = no 8-waves build, 512 = never the compile-time form, 1024 = always where LS is 2 or 3
+        const bool force_rt = g_msda_variant >= 0 && (g_msda_variant & 512), force_ct = g_msda_variant >= 0 && (g_msda_variant & 1024);
+        const bool two_blocks = nt == 1024 && wpe8;
+        const int lsc = force_rt ? -1 : (force_ct && (LS == 2 || LS == 3)) ? LS : (LS == 2 && !two_blocks) ? 2 : -1;
         auto pick = [&](auto lsc_) {
           constexpr int C = decltype(lsc_)::value;
           if constexpr (C < 0) {
-            if (nt == 1024 && wpe8) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8>); }
+            if (two_blocks) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8>); }
             else if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
             else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
             else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
           } else {
-            if (nt == 1024 && gs2 && wpe8) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8, C, 2>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8, C, 2>); }
-            else if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 0, C>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 0, C>); }
-            else if (nt == 832 && gs2) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832, 7, C, 2>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832, 7, C, 2>); }
+            if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 0, C>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 0, C>); }
             else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832, 0, C>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832, 0, C>); }
             else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512, 0, C>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512, 0, C>); }
           }

@@ -55,8 +55,8 @@ def t_us(n=20):
 
 
 base = 1 | 8 if form != "dec" else 0 | 8
-variants = (("r04 default: compile-time level, 16 loads in flight", base), ("r04: compile-time level, 8 loads in flight, 2 blocks/CU", base | 1024),
-            ("r03 code in the 8-waves/SIMD build", base | 512), ("r03 as shipped (runtime level, natural allocation)", base | 512 | 256))
+variants = (("r04 default (dispatcher's choice)", base), ("compile-time level, a level's 16 loads in flight, 1 block/CU", base | 1024 | 256),
+            ("runtime level (r03 code) in the 8-waves/SIMD build where 2 blocks fit", base | 512), ("r03 as shipped (runtime level, natural allocation)", base | 512 | 256))
 print(what, flush=True)
 ref = None
 for rep in range(3):
