@@ -64,6 +64,7 @@ SIGNATURES = {
     "mdqe_debug_gemm_stagger": [i],
     "mdqe_debug_gemm_stages": [i],
     "mdqe_debug_gemm_lds_pad": [i],
+    "mdqe_debug_msda_dec_stage_kb": [i],
     "mdqe_debug_window_attn_variant": [i],
     "mdqe_debug_mha_variant": [i],
     "mdqe_debug_msda_xcd_order": [i],

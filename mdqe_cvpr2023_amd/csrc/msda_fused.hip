@@ -640,6 +640,7 @@ extern "C" int mdqe_debug_msda_variant(int v) { g_msda_variant = v; return MDQE_
 static int g_msda_stage_kb = 150;  // tools/ A/B: LDS budget (KB) of the levels staged by msda_fused_v3_kernel (how many coarse levels a block takes)
 static int g_msda_dec_stage_kb = 72;   // the decoder's box-level launch: cap of that budget (two blocks per CU)
 extern "C" int mdqe_debug_msda_stage_kb(int v) { g_msda_stage_kb = v > 0 ? v : 150; g_msda_dec_stage_kb = v > 0 ? v : 72; return MDQE_OK; }
+extern "C" int mdqe_debug_msda_dec_stage_kb(int v) { g_msda_dec_stage_kb = v > 0 ? v : 72; return MDQE_OK; }   // the decoder's box-level launch only
 static int g_msda_tp_staged = 1;   // tools/ A/B: 0 = the decoder's temporal launch stays on v2
 extern "C" int mdqe_debug_msda_tp_staged(int v) { g_msda_tp_staged = v; return MDQE_OK; }
 static int g_msda_dec_staged = 1;  // tools/ A/B: 0 = the decoder's box-level launch stays on v2 (the encoder keeps its default)

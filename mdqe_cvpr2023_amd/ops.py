@@ -22,6 +22,13 @@ if os.environ.get("MDQE_GEMM_TILE_RULE"):               # tools/ A/B of the auto
 if os.environ.get("MDQE_GEMM_STAGGER"):                 # tools/ A/B: start stagger between the blocks of a CU (csrc/gemm_k16.hip), 10-ns ticks
     check(lib.mdqe_debug_gemm_stagger(int(os.environ["MDQE_GEMM_STAGGER"])), "gemm_stagger")
 
+if os.environ.get("MDQE_MSDA_DEC_STAGE_KB"):           # tools/ A/B: LDS staging budget (KB) of the decoder's box-level deformable launch
+    check(lib.mdqe_debug_msda_dec_stage_kb(int(os.environ["MDQE_MSDA_DEC_STAGE_KB"])), "msda_dec_stage_kb")
+if os.environ.get("MDQE_MSDA_TP_STAGED"):              # tools/ A/B: 0 = the decoder's temporal launch on the gather form (no LDS staging)
+    check(lib.mdqe_debug_msda_tp_staged(int(os.environ["MDQE_MSDA_TP_STAGED"])), "msda_tp_staged")
+if os.environ.get("MDQE_GEMM_LDS_PAD"):                # tools/ A/B: extra LDS bytes per K-step-16 GEMM block (caps the GEMM blocks per CU)
+    check(lib.mdqe_debug_gemm_lds_pad(int(os.environ["MDQE_GEMM_LDS_PAD"])), "gemm_lds_pad")
+
 _ws = {}
 
 
