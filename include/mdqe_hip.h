@@ -398,6 +398,16 @@ int mdqe_image_final_masks_u8(const float* logits, int n_sel, const int* idx_dev
  * patch_merge_gather: [B,H,W,C] -> [B*ceil(H/2)*ceil(W/2), 4C] in the order x0|x1|x2|x3 of PatchMerging (:311-335). */
 int mdqe_layernorm_post_f32(const float* x, const float* gamma, const float* beta, const float* post, float* y,
                             long rows, int C, float eps, void* stream);
+/* Round 4: the window partition and its reverse without their copies (SwinTransformerBlock.forward, swin_transformer_v2.py:236-288).
+ * mdqe_gemm_nt_swin_f32: C = window_partition(roll(pad(X))) W^T + bias -- the qkv product (WindowAttention.forward :153-155) reads its A
+ *   rows from the NHWC map X [B, H, Wd, lda] through the window order; C [B*Hp*Wp, ldc], Hp / Wp = H / Wd rounded up to multiples of ws;
+ *   padded positions read zeros.  Exact-fp32 mode only (MDQE_EINVAL in the split-precision mode: partition first, then mdqe_gemm_nt_f32).
+ * mdqe_layernorm_swin_scatter_f32: out[b,y,x,:] = shortcut[b,y,x,:] + LN(rows[r,:]) * gamma + beta with r the window-order row of the
+ *   pixel: norm1, window reverse, un-shift, crop and the residual add (:273-287) in one pass; out may alias shortcut. */
+int mdqe_gemm_nt_swin_f32(const float* X, long lda, const float* W, const float* bias, float* C, long ldc, int B, int H, int Wd,
+                          int ws, int shift, int N, int K, void* stream);
+int mdqe_layernorm_swin_scatter_f32(const float* rows, const float* gamma, const float* beta, const float* shortcut, float* out,
+                                    int B, int H, int W, int C, int ws, int shift, float eps, void* stream);
 int mdqe_patch4_im2col_f32(const void* frames, int is_u8, long frame_stride, int NI, int h, int w, int Hp, int Wp,
                            const float* mean3_host, const float* std3_host, float* out, void* stream);
 int mdqe_swin_window_f32(const float* src, const float* shortcut, float* dst, int B, int H, int W, int C, int ws,

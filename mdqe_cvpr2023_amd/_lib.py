@@ -51,6 +51,8 @@ SIGNATURES = {
     "mdqe_final_masks_u8": [p, i, p, i, i, i, i, i, i, i, i, p, l, i, p],
     "mdqe_set_gemm_precision": [i],
     "mdqe_layernorm_post_f32": [p, p, p, p, p, l, i, f, p],
+    "mdqe_gemm_nt_swin_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, p],
+    "mdqe_layernorm_swin_scatter_f32": [p, p, p, p, p, i, i, i, i, i, i, f, p],
     "mdqe_patch4_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],
     "mdqe_swin_window_f32": [p, p, p, i, i, i, i, i, i, i, p],
     "mdqe_window_attn_f32": [p, l, p, l, i, i, i, i, p, p, p, i, p],

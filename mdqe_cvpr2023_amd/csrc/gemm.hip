@@ -355,6 +355,32 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   }
 }
 
+// qkv = window_partition(roll(pad(x))) W^T + bias without the partitioned copy: the Swin block's first product reads its A rows straight
+// from the NHWC map through the window order (SwinTransformerBlock.forward, swin_transformer_v2.py:236-262 -> WindowAttention.forward
+// :153-155).  X [B, H, Wd, lda >= K]; C [B * Hp * Wp, ldc] in window order (Hp, Wp: H, Wd rounded up to multiples of ws).  Exact fp32
+// MFMA only (the split-precision kernels do not know the row map: MDQE_EINVAL in that mode; the host then partitions first).
+extern "C" int mdqe_gemm_nt_swin_f32(const float* X, long lda, const float* W, const float* bias, float* C, long ldc, int B, int H, int Wd,
+                                     int ws, int shift, int N, int K, void* stream) {
+  MDQE_REQUIRE(B >= 0 && H > 0 && Wd > 0 && ws > 0 && shift >= 0 && shift < ws && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K &&
+               ldc >= N);
+  if (g_gemm_precision != 0) return MDQE_EINVAL;
+  const int Hp = (H + ws - 1) / ws * ws, Wp = (Wd + ws - 1) / ws * ws;
+  const long Ml = (long)B * Hp * Wp;
+  if (Ml == 0) return MDQE_OK;
+  MDQE_REQUIRE(Ml < 0x7FFFFFFFL);
+  MDQE_CHECK_PTR(X); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C);
+  MDQE_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0);
+  const long ab = (((long)B * H * Wd - 1) * lda + K) * 4, wb = (long)N * K * 4;
+  MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  GemmParams p = {};
+  p.A = X; p.W = W; p.C = C; p.M = (int)Ml; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
+  p.bias = bias; p.act = MDQE_ACT_NONE;
+  p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.ksplit = 1; p.kchunk = K;
+  p.swin_ws = ws; p.swin_shift = shift; p.swin_H = H; p.swin_W = Wd;
+  mdqe_clear_error();
+  return dispatch_gemm(p, 0, (hipStream_t)stream);
+}
+
 // C = LayerNorm(A W^T + bias + residual) * gamma + beta over N == 256 columns, ONE kernel (64x256 tile: the block owns whole
 // rows, statistics in the epilogue).  Always exact fp32 MFMA.  C may alias the residual.
 extern "C" int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N,

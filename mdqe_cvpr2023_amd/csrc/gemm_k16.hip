@@ -79,6 +79,14 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
         const int ow = m % p.OW; const int t = m / p.OW; const int oh = t % p.OH; const int img = t / p.OH;
         ih0[j] = oh * p.stride - p.pad; iw0[j] = ow * p.stride - p.pad;
         voff[j] = (unsigned)(((long)img * p.img_stride + ((long)ih0[j] * p.Wd + iw0[j]) * p.Cin) * 4) + (unsigned)(kch[j] * 4);   // may wrap
+      } else if (!CAT && !LN && p.swin_ws > 0) {   // window-ordered row m -> its pixel of the [B, H, W, lda] map (or zeros)
+        const int ws = p.swin_ws, nWx = (p.swin_W + ws - 1) / ws, nWy = (p.swin_H + ws - 1) / ws;
+        const int ix = m % ws; int t = m / ws;
+        const int iy = t % ws; t /= ws;
+        const int wx = t % nWx; t /= nWx;
+        const int wy = t % nWy; const int b = t / nWy;
+        const int y = (wy * ws + iy + p.swin_shift) % (nWy * ws), x = (wx * ws + ix + p.swin_shift) % (nWx * ws);
+        voff[j] = (y < p.swin_H && x < p.swin_W) ? (unsigned)((((long)b * p.swin_H + y) * p.swin_W + x) * p.lda * 4) + (unsigned)(kch[j] * 4) : OOB_OFF;
       } else {
         voff[j] = (unsigned)((long)m * p.lda * 4) + (unsigned)(kch[j] * 4);
         if constexpr (CAT) {                       // the second operand's row: pixel (oh*stride, ow*stride) of image img
@@ -404,6 +412,7 @@ static int launch_k16_(const GemmParams& p, hipStream_t st) {
 // tile: 1 128x128, 2 128x64, 3 64x64 (as gemm.hip), 7 32x64, 8 32x128, 9 64x128; the split-K reduce pass is launched by the caller
 int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st) {
   if (p.side != nullptr && (p.conv || p.ksplit > 1 || tile == 6 || p.A2 != nullptr)) return MDQE_EINVAL;   // side term: plain tiles only
+  if (p.swin_ws > 0 && (p.conv || p.ksplit > 1 || tile == 6 || p.A2 != nullptr)) return MDQE_EINVAL;        // window gather: plain tiles only
   if (p.A2 != nullptr) {                                // cat mode: two A operands side by side along K
     if (p.conv || p.ksplit > 1) return MDQE_EINVAL;
     switch (tile) {

@@ -28,6 +28,10 @@ struct GemmParams {
   // for n < side_cols, before the activation.  The decoder's `(x + pos) W^T` with pos = Linear(2 -> C)(box centre) is
   // `x W^T + box (W P)^T`: the position embedding is never materialised (mdqe_gemm_nt_side_f32)
   const float* side; const float* side_w; int side_cols;
+  // Swin window gather (K-step-16 kernel, plain tiles; swin_ws > 0): A is an NHWC map [B, swin_H, swin_W, lda] and output row m is the
+  // m-th row of its window partition after zero padding to multiples of swin_ws and the cyclic shift (swin_transformer_v2.py:236-262):
+  // the row's source pixel is computed once per block, a padded position reads zeros -- the partitioned copy is never materialised
+  int swin_ws, swin_shift, swin_H, swin_W;
   int stagger;              // K-step-16 kernel: the first resident round of blocks starts (slot on the CU) x stagger 10-ns ticks late (0: off)
 };
 

@@ -22,14 +22,30 @@ __device__ __forceinline__ float wave_sum_c256(float v) {
 
 // y[r,:] = LN(x[r,:] + res[r,:]) * gamma + beta   (nn.LayerNorm eps=1e-5; transformer_enc.py:103-108,
 // transformer_dec.py:345-358).  Optional second output y2 = y + add2[(r % add2_mod), :].
+// SwinMap (ws > 0): x rows are in WINDOW order; `post` and `y` are the NHWC map [B, H, W, C] -- row r goes to its pixel (window reverse +
+// un-shift + crop, swin_transformer_v2.py:273-287), rows of the zero padding are dropped: y[pix] = post[pix] + LN(x[r]).
+struct SwinMap { int ws, shift, H, W; };
+
 template <int NCH>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
-                 const float* __restrict__ beta, const float* __restrict__ post, float* __restrict__ y, long rows, int C, float eps) {
+                 const float* __restrict__ beta, const float* __restrict__ post, float* __restrict__ y, long rows, int C, float eps,
+                 SwinMap sm) {
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nw = (long)gridDim.x * (blockDim.x >> 6);
   for (long r = wid; r < rows; r += nw) {
+    long ro = r;                                 // row of `post` / `y`
+    if (sm.ws > 0) {
+      const int ws = sm.ws, nWx = (sm.W + ws - 1) / ws, nWy = (sm.H + ws - 1) / ws;
+      const int ix = (int)(r % ws); long t = r / ws;
+      const int iy = (int)(t % ws); t /= ws;
+      const int wx = (int)(t % nWx); t /= nWx;
+      const int wy = (int)(t % nWy); const long b = t / nWy;
+      const int yy = (wy * ws + iy + sm.shift) % (nWy * ws), xx = (wx * ws + ix + sm.shift) % (nWx * ws);
+      if (yy >= sm.H || xx >= sm.W) continue;    // (wave-uniform: one wave per row)
+      ro = (b * sm.H + yy) * sm.W + xx;
+    }
     f32x4 v[NCH];
     float s = 0.f;
 #pragma unroll
@@ -62,15 +78,15 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, con
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
         const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
         f32x4 o = (v[i] - mean) * rstd * g + b;
-        if (post != nullptr) o += *reinterpret_cast<const f32x4*>(post + r * C + c);
-        *reinterpret_cast<f32x4*>(y + r * C + c) = o;
+        if (post != nullptr) o += *reinterpret_cast<const f32x4*>(post + ro * C + c);
+        *reinterpret_cast<f32x4*>(y + ro * C + c) = o;
       }
     }
   }
 }
 
 static int layernorm_impl(const float* x, const float* res, const float* gamma, const float* beta, const float* post, float* y,
-                          long rows, int C, float eps, void* stream) {
+                          long rows, int C, float eps, void* stream, SwinMap sm = SwinMap{0, 0, 0, 0}) {
   MDQE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 2048);
   if (rows == 0) return MDQE_OK;
   MDQE_CHECK_PTR(x); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta); MDQE_CHECK_PTR(y);
@@ -78,10 +94,10 @@ static int layernorm_impl(const float* x, const float* res, const float* gamma, 
   long nb = (rows + 3) / 4;
   if (nb > 256 * 32) nb = 256 * 32;
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
-  else if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
-  else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
-  else hipLaunchKernelGGL((layernorm_kernel<8>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps);
+  if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps, sm);
+  else if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps, sm);
+  else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps, sm);
+  else hipLaunchKernelGGL((layernorm_kernel<8>), dim3((unsigned)nb), dim3(256), 0, st, x, res, gamma, beta, post, y, rows, C, eps, sm);
   return mdqe_launch_status();
 }
 
@@ -95,6 +111,17 @@ extern "C" int mdqe_layernorm_post_f32(const float* x, const float* gamma, const
                                        long rows, int C, float eps, void* stream) {
   MDQE_CHECK_PTR(post);
   return layernorm_impl(x, nullptr, gamma, beta, post, y, rows, C, eps, stream);
+}
+
+// out[pix] = shortcut[pix] + LN(rows[r]) * gamma + beta with r the window-order row of pixel pix: norm1 of a Swin block, window reverse,
+// un-shift, crop and the residual add in ONE pass (swin_transformer_v2.py:273-287); rows [B * Hp * Wp, C]; shortcut / out [B, H, W, C]
+// (out may alias shortcut: every pixel is written by exactly one row).
+extern "C" int mdqe_layernorm_swin_scatter_f32(const float* rows_, const float* gamma, const float* beta, const float* shortcut, float* out,
+                                               int B, int H, int W, int C, int ws, int shift, float eps, void* stream) {
+  MDQE_REQUIRE(B >= 0 && H > 0 && W > 0 && ws > 0 && shift >= 0 && shift < ws);
+  MDQE_CHECK_PTR(shortcut);
+  const long Hp = (H + ws - 1) / ws * ws, Wp = (W + ws - 1) / ws * ws;
+  return layernorm_impl(rows_, nullptr, gamma, beta, shortcut, out, (long)B * Hp * Wp, C, eps, stream, SwinMap{ws, shift, H, W});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ def _fold_bn(sd, p, eps=1e-5):
 
 GEO_CACHE = max(1, int(os.environ.get("MDQE_GEO_CACHE", "16")))     # resolutions whose constants stay resident
 STEM_FUSED = os.environ.get("MDQE_STEM_FUSED", "1") != "0"      # 0: im2col + GEMM (debug / A-B)
+SWIN_FUSED = os.environ.get("MDQE_SWIN_FUSED", "1") != "0"      # 0: window partition / reverse as copy kernels (debug / A-B)
 RESNET_CAT = os.environ.get("MDQE_RESNET_CAT", "1") != "0"      # 0: projection shortcut and conv3 as two launches (debug / A-B)
 
 
@@ -443,12 +444,23 @@ class Engine:
             N = ws * ws
             nWy, nWx = (H + ws - 1) // ws, (W + ws - 1) // ws
             x4 = x.view(NI, H, W, C)
+            # round 4: the window partition rides on the qkv product's A loads and its reverse on norm1's stores (no partitioned copy,
+            # no scatter pass: 4 passes over [rows, C] per block fewer); exact-fp32 GEMM mode (the split-precision kernels partition first)
+            fuse = SWIN_FUSED and ops.get_gemm_precision() == "f32" and x4.is_contiguous()
+            own = False                                  # x4 is this stage's own buffer (safe to update in place)
             for blk in stg.blocks:
-                win = ops.swin_window_gather(x4, ws, blk.shift)
-                qkv = ops.linear(win, blk.wqkv, blk.bqkv)
+                if fuse:
+                    qkv = ops.linear_swin(x4, blk.wqkv, blk.bqkv, ws, blk.shift)
+                else:
+                    qkv = ops.linear(ops.swin_window_gather(x4, ws, blk.shift), blk.wqkv, blk.bqkv)
                 a = ops.window_attn(qkv, NI * nWy * nWx, N, C, nh, blk.scale, blk.bias, mask if blk.shift > 0 else None, nWy * nWx)
-                pr = ops.layernorm(ops.linear(a, blk.wproj, blk.bproj), *blk.n1)           # norm1(attn(x)), window order
-                x4 = ops.swin_window_scatter_add(pr, x4, ws, blk.shift)                     # shortcut + ... (:287)
+                if fuse:                                                                         # shortcut + norm1(attn(x)) (:287)
+                    x4 = ops.layernorm_swin_scatter(ops.linear(a, blk.wproj, blk.bproj), *blk.n1, x4, ws, blk.shift,
+                                                    out=x4 if own else torch.empty_like(x4))
+                else:
+                    pr = ops.layernorm(ops.linear(a, blk.wproj, blk.bproj), *blk.n1)           # norm1(attn(x)), window order
+                    x4 = ops.swin_window_scatter_add(pr, x4, ws, blk.shift)
+                own = True
                 x2 = x4.view(-1, C)
                 h = ops.linear(x2, *blk.fc1, act="gelu")
                 x4 = ops.layernorm_post(ops.linear(h, *blk.fc2), *blk.n2, post=x2).view(NI, H, W, C)   # x + norm2(mlp(x)) (:288)

@@ -470,6 +470,32 @@ def swin_window_scatter_add(rows, shortcut, ws, shift, out=None):
     return out
 
 
+def linear_swin(x, weight, bias, ws, shift, out=None):
+    """x [B,H,W,C] (contiguous NHWC) -> window_partition(roll(pad(x))) @ weight^T + bias as rows [B*Hp*Wp, N] in window order, without
+    the partitioned copy (mdqe_gemm_nt_swin_f32; exact-fp32 GEMM mode only -- callers check get_gemm_precision())."""
+    _chk(x, "x"); _chk(weight, "weight"); _chk(bias, "bias")
+    B, H, W, C = x.shape
+    N = weight.shape[0]
+    Hp, Wp = (H + ws - 1) // ws * ws, (W + ws - 1) // ws * ws
+    if out is None:
+        out = torch.empty((B * Hp * Wp, N), dtype=torch.float32, device=x.device)
+    check(lib.mdqe_gemm_nt_swin_f32(ptr(x), C, ptr(weight), ptr(bias), ptr(out), out.stride(0), B, H, W, ws, shift, N, C, cur_stream()),
+          "gemm_nt_swin")
+    return out
+
+
+def layernorm_swin_scatter(rows, gamma, beta, shortcut, ws, shift, eps=1e-5, out=None):
+    """out[b,y,x] = shortcut[b,y,x] + LN(rows[window-order row of (b,y,x)]) * gamma + beta; rows [B*Hp*Wp, C], shortcut [B,H,W,C].
+    out=None writes over `shortcut` (every pixel is written by exactly one row)."""
+    _chk(rows, "rows"); _chk(shortcut, "shortcut"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    B, H, W, C = shortcut.shape
+    if out is None:
+        out = shortcut
+    check(lib.mdqe_layernorm_swin_scatter_f32(ptr(rows), ptr(gamma), ptr(beta), ptr(shortcut), ptr(out), B, H, W, C, ws, shift, eps,
+                                              cur_stream()), "layernorm_swin_scatter")
+    return out
+
+
 def window_attn(qkv, n_windows, N, C, nh, scale, bias, mask=None, nW=1):
     _chk(qkv, "qkv"); _chk(scale, "scale"); _chk(bias, "bias"); _chk(mask, "mask")
     out = torch.empty((n_windows * N, C), dtype=torch.float32, device=qkv.device)

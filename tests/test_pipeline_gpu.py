@@ -177,6 +177,52 @@ def test_swinv2_backbone_vs_reference():
         _rm("swin_small: " + name, o, ref, 2e-4)
 
 
+def test_swin_window_partition_fused_into_gemm_and_norm_is_bit_identical():
+    """Round 4: the window partition as row addressing of the qkv product's A loads (mdqe_gemm_nt_swin_f32) and its reverse + residual as
+    the stores of norm1 (mdqe_layernorm_swin_scatter_f32) against the copy kernels they replace: the same products on the same rows, the
+    same LayerNorm, one commutative add -- equal bits, on maps whose sizes are NOT multiples of the window (zero-padded windows), with
+    and without the cyclic shift, and through the whole reduced backbone."""
+    from mdqe_cvpr2023_amd import engine as E, ops
+    from mdqe_cvpr2023_amd.config import MDQEConfig
+    from mdqe_cvpr2023_amd.params import head_manifest
+    from synth import synth_tensor
+    g = torch.Generator().manual_seed(3)
+    for (B, H, W, C, ws, shift) in ((3, 15, 27, 96, 6, 0), (2, 15, 27, 96, 6, 3), (2, 30, 54, 192, 12, 6), (1, 8, 14, 48, 4, 2)):
+        x = torch.randn(B, H, W, C, generator=g).cuda()
+        w = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda()
+        b = torch.randn(3 * C, generator=g).cuda()
+        ref = ops.linear(ops.swin_window_gather(x, ws, shift), w, b)
+        got = ops.linear_swin(x, w, b, ws, shift)
+        assert got.shape == ref.shape and torch.equal(got, ref), (B, H, W, C, ws, shift)
+        rows = torch.randn(ref.shape[0], C, generator=g).cuda()
+        gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+        want = ops.swin_window_scatter_add(ops.layernorm(rows, gam, bet), x, ws, shift)
+        assert torch.equal(ops.layernorm_swin_scatter(rows, gam, bet, x, ws, shift, out=torch.empty_like(x)), want)
+        xc = x.clone()
+        assert torch.equal(ops.layernorm_swin_scatter(rows, gam, bet, xc, ws, shift), want) and xc.data_ptr() != x.data_ptr()   # in place
+    fx = Fixture("swin_small")
+    cfg = MDQEConfig(backbone="SwinV2", swin_embed_dim=32, swin_depths=(2, 2, 2, 2), swin_heads=(2, 4, 8, 16), swin_window=4,
+                     backbone_channels=(64, 128, 256), enc_layers=1, dec_layers=1, pixel_mean=(0., 0., 0.), pixel_std=(1., 1., 1.))
+    sd = {k.replace("bb.", "detr.backbone.0.backbone.", 1): v for k, v in fx.state().items()}
+    for k in fx.z.files:
+        if k.startswith("ls::"):
+            sd["detr.backbone.0.backbone." + k[4:]] = fx.t(k)
+    sd.update({k: synth_tensor(k, s, 9) for k, s in head_manifest(cfg).items()})
+    eng = E.Engine(cfg, sd)
+    x = fx.t("x").cuda().contiguous()
+    geo = eng.geometry(64, 96)
+    old = E.SWIN_FUSED
+    try:
+        E.SWIN_FUSED = True
+        a = eng.backbone(x, geo)
+        E.SWIN_FUSED = False
+        b = eng.backbone(x, geo)
+    finally:
+        E.SWIN_FUSED = old
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 def test_build_swinv2_backbone_surface_vs_reference():
     """The detectron2-facing builder (`build_swinv2_backbone(cfg, input_shape)`, swin_transformer_v2.py:675-702): reference parameter
     names through `load_state_dict`, `forward(x)` -> {"stage3","stage4","stage5"} NCHW equal to the reference run (fixture swin_small),
