@@ -720,16 +720,17 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         };
         // two blocks of 1024 threads per CU need the 8-waves-per-SIMD build (variant bit 256 of the tools/ sweep turns it off)
         const bool wpe8 = !(g_msda_variant >= 0 && (g_msda_variant & 256)) && 2 * smem + 1024 <= 160 * 1024;
-        // Which build (round 4, tools/msda_r04_ab.py, profiles/r04_msda_compile_time_level_ab.txt; all forms give the same bits):
-        //  * two 1024-thread blocks fit a CU (the encoder at 360p: 2 x 75 KB): round 3's code in the 8-waves-per-SIMD build -- 435 us
-        //    against 454 (natural allocation, one block per CU) and 458 (compile-time level);
-        //  * otherwise, two staged levels: the compile-time-level form (a level's 16 corner loads in flight) -- decoder box level at
-        //    360p 103 against 108 us, Swin-L encoder 223 against 228, 640p encoder equal;
-        //  * the coarsest level only (decoder at 640p): the runtime form (149 against 152 us).
-        // variant bits of the tools/ sweep: 256 = no 8-waves build, 512 = never the compile-time form, 1024 = always where LS is 2 or 3
-        const bool force_rt = g_msda_variant >= 0 && (g_msda_variant & 512), force_ct = g_msda_variant >= 0 && (g_msda_variant & 1024);
+        // Which build (round 4; all forms give the same bits).  Alone (tools/msda_r04_ab.py, profiles/r04_msda_compile_time_level_ab.txt):
+        // where two 1024-thread blocks fit a CU (the encoder at 360p, 2 x 75 KB) the runtime form in the 8-waves-per-SIMD build takes 435 us
+        // against 454 (natural allocation, one block per CU) and 458 (compile-time level, a level's 16 loads in flight); elsewhere the
+        // compile-time form is 0-5 % faster alone (decoder box level 103 against 108 us, Swin-L encoder 223 against 228, 640p equal).
+        // INSIDE the pipeline (tools/msda_form_in_pipeline_ab.py, profiles/r04_msda_form_in_pipeline_ab.txt) its 126-VGPR blocks wait longer
+        // for room beside the frame stream's GEMM blocks (decoder box level 614-632 us against 437-455) and frames/s are equal within
+        // noise, single-GPU and sharded -- so the shipped choice is the runtime form everywhere, in the 8-waves build where that buys a
+        // second block per CU.  variant bits of the tools/ sweep: 256 = no 8-waves build, 1024 = the compile-time form where LS is 2 or 3
+        const bool force_ct = g_msda_variant >= 0 && (g_msda_variant & 1024);
         const bool two_blocks = nt == 1024 && wpe8;
-        const int lsc = force_rt ? -1 : (force_ct && (LS == 2 || LS == 3)) ? LS : (LS == 2 && !two_blocks) ? 2 : -1;
+        const int lsc = (force_ct && (LS == 2 || LS == 3)) ? LS : -1;
         auto pick = [&](auto lsc_) {
           constexpr int C = decltype(lsc_)::value;
           if constexpr (C < 0) {
@@ -775,7 +776,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
           hipLaunchKernelGGL(kern, dim3((unsigned)nbt), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
                              ref, ref_bstride, grid, lv, B, M, Q, LS, (int)px, chunk, runs, scale, out, ldout);
         };
-        const int lsc = (g_msda_variant >= 0 && (g_msda_variant & 512)) ? -1 : (LS == 2 || LS == 3) ? LS : -1;
+        const int lsc = (g_msda_variant >= 0 && (g_msda_variant & 1024) && (LS == 2 || LS == 3)) ? LS : -1;     // (as the box-level launch: tools/ only)
         auto pick = [&](auto lsc_) {
           constexpr int C = decltype(lsc_)::value;
           if (nt == 1024) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 1024, C>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 1024, C>); }

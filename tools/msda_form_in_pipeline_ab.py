@@ -1,6 +1,7 @@
 """Round 4: the compile-time-level form of the staged gathers (126 VGPRs: one block per CU) against round 3's runtime form (68 VGPRs: two
 blocks per CU) INSIDE the pipeline -- the single-GPU bench and the sharded schedule through a one-rank RCCL communicator (decoder on
-one stream).  MDQE_MSDA_VARIANT=520 = bits 8 (staged) + 512 (never the compile-time form).
+one stream).  (Measured when the compile-time form was the dispatcher's choice for two staged levels; since then the runtime form is the default and
+MDQE_MSDA_VARIANT=1032 = bits 8 (staged) + 1024 selects the compile-time form.)
 python tools/msda_form_in_pipeline_ab.py [steps] [reps]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +9,7 @@ steps = sys.argv[1] if len(sys.argv) > 1 else "10"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for r in range(reps):
     for sharded in (False, True):
-        for name, env in (("r04 dispatch", {}), ("runtime level everywhere", {"MDQE_MSDA_VARIANT": "520"})):
+        for name, env in (("default: runtime level", {}), ("compile-time level", {"MDQE_MSDA_VARIANT": "1032"})):
             e = dict(os.environ, **env)
             if sharded:
                 e["MDQE_BENCH_FORCE_SHARDED"] = "1"

@@ -56,7 +56,7 @@ def t_us(n=20):
 
 base = 1 | 8 if form != "dec" else 0 | 8
 variants = (("r04 default (dispatcher's choice)", base), ("compile-time level, a level's 16 loads in flight, 1 block/CU", base | 1024 | 256),
-            ("runtime level (r03 code) in the 8-waves/SIMD build where 2 blocks fit", base | 512), ("r03 as shipped (runtime level, natural allocation)", base | 512 | 256))
+            ("r03 as shipped (runtime level, natural allocation)", base | 256))
 print(what, flush=True)
 ref = None
 for rep in range(3):
