@@ -183,11 +183,17 @@ def test_swin_window_partition_fused_into_gemm_and_norm_is_bit_identical():
     same LayerNorm, one commutative add -- equal bits, on maps whose sizes are NOT multiples of the window (zero-padded windows), with
     and without the cyclic shift, and through the whole reduced backbone."""
     from mdqe_cvpr2023_amd import engine as E, ops
+    from mdqe_cvpr2023_amd._lib import MdqeError
     from mdqe_cvpr2023_amd.config import MDQEConfig
     from mdqe_cvpr2023_amd.params import head_manifest
     from synth import synth_tensor
     g = torch.Generator().manual_seed(3)
+    if ops.get_gemm_precision() != "f32":              # the split-precision kernels do not know the row map: the op refuses, the engine
+        with pytest.raises(MdqeError):                 # partitions first (both backbone runs below then take the copy kernels)
+            ops.linear_swin(torch.zeros(1, 8, 8, 32).cuda(), torch.zeros(96, 32).cuda(), torch.zeros(96).cuda(), 4, 0)
     for (B, H, W, C, ws, shift) in ((3, 15, 27, 96, 6, 0), (2, 15, 27, 96, 6, 3), (2, 30, 54, 192, 12, 6), (1, 8, 14, 48, 4, 2)):
+        if ops.get_gemm_precision() != "f32":
+            break
         x = torch.randn(B, H, W, C, generator=g).cuda()
         w = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda()
         b = torch.randn(3 * C, generator=g).cuda()
