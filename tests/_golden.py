@@ -57,8 +57,8 @@ def record_margin(group, stage, abs_err, scale=1.0, tol=None):
 
 
 def margins_table():
-    rows = ["%-58s %-34s %12s %12s %10s %8s %5s" % ("group", "stage", "max abs err", "scale", "rel err", "tol", "n")]
+    rows = ["%-66s %-56s %12s %12s %10s %8s %5s" % ("group", "stage", "max abs err", "scale", "rel err", "tol", "n")]
     for (g, st), m in sorted(MARGINS.items()):
-        rows.append("%-58s %-34s %12.3e %12.3e %10.2e %8s %5d" % (g, st, m["abs"], m["scale"], m["rel"],
+        rows.append("%-66s %-56s %12.3e %12.3e %10.2e %8s %5d" % (g, st, m["abs"], m["scale"], m["rel"],
                                                                      "%.0e" % m["tol"] if m["tol"] is not None else "-", m["n"]))
     return "\n".join(rows) + "\n"
