@@ -140,3 +140,26 @@ def test_same_output_compares_bit_for_bit():
     assert same_output(a, b)[0] is False and same_output(a, None)[0] is False
     b = dict(a, pred_scores=[0.5, 0.2500001])
     assert same_output(a, b)[0] is False
+
+
+def test_soft_deadline_prints_what_it_has_and_leaves_with_exit_code_zero():
+    """bench.Deadline guards the optional halo-exchange A/B of a multi-GPU run: if the guarded region does not finish in time, the
+    callback runs (rank 0 prints the line it already has) and the process leaves with exit code 0 -- the headline is never lost to a
+    hang in an extra; a region that finishes in time cancels the timer."""
+    import subprocess
+    import textwrap
+    script = textwrap.dedent('''
+        import sys, time
+        sys.path.insert(0, %r)
+        from bench import Deadline
+        with Deadline(30.0, lambda: print("NEVER")):
+            pass                                            # finishes in time: timer cancelled
+        print("FIRST", flush=True)
+        with Deadline(0.3, lambda: print('{"value": 1.0, "halo_exchange": {"error": "did not finish"}}', flush=True)):
+            time.sleep(60)                                  # a collective that never returns
+        print("UNREACHABLE")
+    ''' % ROOT)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.splitlines()
+    assert out[0] == "FIRST" and out[1].startswith('{"value": 1.0') and "UNREACHABLE" not in r.stdout and "NEVER" not in r.stdout
