@@ -73,6 +73,9 @@ class MDQE(nn.Module):
         # reference only picks the device the window results wait on (mdqe/mdqe.py:185-186,337,354-355) and never changes an output.
         self.early_masks = os.environ.get("MDQE_EARLY_MASKS", "1") != "0"
         self.decode_ahead = os.environ.get("MDQE_DECODE_AHEAD", "1") != "0"         # trailing short clips decoded beside the last full group
+        # the decoder of a group starts as soon as ITS inputs of the group's last frame pass exist (queries + value projections); the
+        # mask-feature head of that pass, which only inference_clip reads, runs beside the decoder's first layers (round 4)
+        self.early_decode = os.environ.get("MDQE_EARLY_DECODE", "1") != "0"
         self._ahead_stream = None
         self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.clip_priority = os.environ.get("MDQE_CLIP_PRIORITY", "1") != "0"       # per-clip stages on a high-priority stream
@@ -186,24 +189,33 @@ class MDQE(nn.Module):
                 return self.inference_image(batched_inputs)
             return self.inference_vis(batched_inputs)
 
-    def _frame_cache(self, frames, geo, ring=None, at=0, keep_enc=False):
+    def _frame_cache(self, frames, geo, ring=None, at=0, keep_enc=False, dec_ready=None):
         """Per-frame stages a1-a11 for a batch of frames: everything a clip needs, computed once.  With `ring`
         (preallocated per-frame buffers) the results land in ring[k][at:at+n] -- the 63 MB/frame decoder value
         cache is written there directly by its GEMM.  keep_enc: the encoder tokens stay in the cache too (5.2 MB per frame;
-        a sharded video ships the tokens of a chunk's last T-1 frames to the neighbour, sharding._Halo)."""
+        a sharded video ships the tokens of a chunk's last T-1 frames to the neighbour, sharding._Halo).
+        Order (round 4): what the DECODER reads -- query selection / content / embeddings and the value projections -- comes first and
+        `dec_ready` (an event) is recorded behind it; the mask-feature head, which only `inference_clip` reads, runs after.  The decoder
+        of a group can then start while the mask head of its last frame pass is still running: at the end of a video that pass has
+        nothing else to overlap with, and the decoder's chain of small dependent launches is latency-bound."""
         eng = self.engine
         n = frames.shape[0]
         feats = eng.backbone(frames, geo)
         enc = eng.encode(feats, geo)
         del feats
-        mf = eng.mask_features(enc, geo)
         coords, content, emb = eng.frame_queries(enc, geo)
         extra = (("enc", enc),) if keep_enc else ()
         if ring is None:
-            return dict({"mf": mf, "coords": coords, "content": content, "emb": emb, "vals": eng.dec_values(enc, geo)}, **dict(extra))
+            vals = eng.dec_values(enc, geo)
+            if dec_ready is not None:
+                dec_ready.record(torch.cuda.current_stream(self.device))
+            return dict({"mf": eng.mask_features(enc, geo), "coords": coords, "content": content, "emb": emb, "vals": vals}, **dict(extra))
         eng.dec_values(enc, geo, out=ring["vals"][at:at + n])
-        for k, v in (("mf", mf), ("coords", coords), ("content", content), ("emb", emb)) + extra:
+        for k, v in (("coords", coords), ("content", content), ("emb", emb)) + extra:
             ring[k][at:at + n].copy_(v)
+        if dec_ready is not None:
+            dec_ready.record(torch.cuda.current_stream(self.device))
+        ring["mf"][at:at + n].copy_(eng.mask_features(enc, geo))
         return None
 
     def _cache_from_tokens(self, enc, mf, geo, ring, at):
@@ -323,6 +335,9 @@ class MDQE(nn.Module):
                         fstream.wait_event(free_ev[slot])
                 base, count = ls, 0
                 nxt_before = nxt
+                # what the DECODER reads of this state is complete (the mask features may still be on their way); not with the halo exchange,
+                # whose straddling clips rebuild cache rows on the clip stream
+                dec_ready = torch.cuda.Event() if cuda and self.early_decode and halo is None else None
                 if prev is not None:                               # carry frames [ls, prev end) -- never more than T-1
                     keep = prev["base"] + prev["count"] - ls
                     if keep > 0:
@@ -349,8 +364,10 @@ class MDQE(nn.Module):
                         for k, v in first.items():
                             rings[slot][k][count:count + n_new].copy_(v)
                         del first
+                        if dec_ready is not None:                  # (a ring's first fill copies everything at the end: nothing is early)
+                            dec_ready.record(fstream)
                     else:
-                        self._frame_cache(frames_dev[nxt:c1], geo, ring=rings[slot], at=count, keep_enc=halo is not None)
+                        self._frame_cache(frames_dev[nxt:c1], geo, ring=rings[slot], at=count, keep_enc=halo is not None, dec_ready=dec_ready)
                     if halo is not None and strad and nxt == 0:        # this chunk's first T-1 frames: the straddling clips read them
                         for k, v in rings[slot].items():
                             own_first[k] = v[count:count + Tn - 1].clone()
@@ -366,7 +383,9 @@ class MDQE(nn.Module):
                 if cuda:
                     ready = torch.cuda.Event()
                     ready.record(fstream)
-            return {"slot": slot, "base": base, "count": count, "ready": ready, "covered": nxt, "new_frames": nxt - nxt_before,
+                    if dec_ready is not None and nxt == nxt_before:   # no new frame pass (carried rows only): the copies above are all there is
+                        dec_ready = None
+            return {"slot": slot, "base": base, "count": count, "ready": ready, "dec_ready": dec_ready, "covered": nxt, "new_frames": nxt - nxt_before,
                     "cache": {k: v[:count] for k, v in rings[slot].items()}}
 
         def frames_queued():
@@ -438,8 +457,9 @@ class MDQE(nn.Module):
             cur = states.popleft()
             cache, base, T = cur["cache"], cur["base"], cur["T"]
             group = clips[cur["i"]:cur["j"]]
+            dr = cur.get("dec_ready") if cuda else None
             if cuda:
-                clip_stream.wait_event(cur["ready"])
+                clip_stream.wait_event(dr if dr is not None else cur["ready"])
             starts = [c[0] - frame_offset - base for c in group]
             if strad and T == Tn and (cur["j"] >= len(clips) or clips[cur["j"]][1] - clips[cur["j"]][0] != Tn):
                 # the last full-length group of the chunk: the straddling clips join it.  Cache rows [count, count + 2(T-1)) of
@@ -479,6 +499,8 @@ class MDQE(nn.Module):
                 with torch.cuda.stream(aux):
                     g2 = clips[nx["i"]:nx["j"]]
                     nx["outs"] = eng.decode_clips(nx["cache"], [c[0] - frame_offset - nx["base"] for c in g2], nx["T"], geo)
+            if dr is not None:
+                clip_stream.wait_event(cur["ready"])               # the mask features of the group's last pass (inference_clip reads them)
             ress = eng.inference_clips(outs, cache["mf"], starts, T)
             ready = None
             if cuda:
