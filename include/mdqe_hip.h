@@ -154,6 +154,7 @@ int mdqe_debug_gemm_rows_dot(int v); /* products with N <= 8 columns: 1 (default
 int mdqe_debug_gemm_stagger(int v);  /* K-step-16 kernel: start offset between the blocks of a CU's first round, 10-ns ticks; 0 = off */
 int mdqe_debug_gemm_stages(int v);   /* K-step-16 kernel, 64x64 and smaller tiles: LDS stages 2 / 4; 0 = by grid size (default) */
 int mdqe_debug_msda_dec_stage_kb(int kb);   /* tools/ only: LDS staging budget of the decoder's box-level deformable launch (default 72: two blocks per CU) */
+int mdqe_debug_trk_siou_blocks(int blocks);   /* tools/ only: blocks the tracker's sign-intersection launch aims at (0 = default 512) */
 int mdqe_debug_gemm_lds_pad(int bytes);   /* tools/ only: extra dynamic LDS per block of the K-step-16 GEMM launches (caps the blocks per CU) */
 /* tools/ only: window attention kernel form, 1 = MFMA where it applies (default), 0 = scalar everywhere. */
 int mdqe_debug_window_attn_variant(int v);

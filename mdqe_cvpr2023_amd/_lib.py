@@ -66,6 +66,7 @@ SIGNATURES = {
     "mdqe_debug_gemm_stagger": [i],
     "mdqe_debug_gemm_stages": [i],
     "mdqe_debug_gemm_lds_pad": [i],
+    "mdqe_debug_trk_siou_blocks": [i],
     "mdqe_debug_msda_dec_stage_kb": [i],
     "mdqe_debug_window_attn_variant": [i],
     "mdqe_debug_mha_variant": [i],

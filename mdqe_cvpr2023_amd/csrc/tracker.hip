@@ -45,6 +45,9 @@ trk_siou_kernel(const float* __restrict__ saved, long saved_stride, const float*
   }
 }
 
+static int g_trk_siou_blocks = 0;
+extern "C" int mdqe_debug_trk_siou_blocks(int v) { g_trk_siou_blocks = v; return MDQE_OK; }
+
 extern "C" int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
                                  int n_in, long n, float* out3, void* stream) {
   MDQE_REQUIRE(n_saved >= 0 && n_in >= 0 && n >= 0 && n % 4 == 0 && saved_stride % 4 == 0 && inp_stride % 4 == 0);
@@ -56,7 +59,8 @@ extern "C" int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_sa
   if (hipMemsetAsync(out3, 0, (size_t)n_saved * n_in * 3 * sizeof(float), st) != hipSuccess) return MDQE_ELAUNCH;
   int chunks = 1;
   const long pairs = (long)n_saved * n_in;
-  if (pairs < 512) { chunks = (int)(512 / pairs); const long maxc = (n / 4 + 1023) / 1024; if (chunks > maxc) chunks = (int)maxc; if (chunks < 1) chunks = 1; }
+  const long target = g_trk_siou_blocks > 0 ? g_trk_siou_blocks : 512;       // blocks the launch aims at (tools/ A/B: mdqe_debug_trk_siou_blocks)
+  if (pairs < target) { chunks = (int)(target / pairs); const long maxc = (n / 4 + 1023) / 1024; if (chunks > maxc) chunks = (int)maxc; if (chunks < 1) chunks = 1; }
   hipLaunchKernelGGL(trk_siou_kernel, dim3(n_in, n_saved, chunks), dim3(256), 0, st, saved, saved_stride, inp,
                      inp_stride, n, out3, n_in);
   return mdqe_launch_status();
