@@ -795,7 +795,7 @@ def main():
 
         def give_up():
             if rank == 0:
-                line["halo_exchange"] = {"error": "did not finish within %.0f s (soft deadline); the headline above is unaffected" % budget}
+                line["halo_exchange"] = {"error": "did not finish within %g s (soft deadline); the headline above is unaffected" % budget}
                 emit(json.dumps(line))
         sync()
         with Deadline(budget, give_up):

@@ -121,6 +121,11 @@ int mdqe_gemm_nt_cat2_f32(const float* A1, long lda1, int K1, const float* A2, l
  * C = LN(A W^T + bias + residual) * gamma + beta, N must be 256; C may alias the residual.  Exact fp32 MFMA. */
 int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
                      const float* residual, long ldr, const float* gamma, const float* beta, float eps, void* stream);
+/* ... followed by a second LayerNorm of the result in the same epilogue: C2 = LN(C) * gamma2 + beta2 (the decoder's shared
+ * `decoder_norm` behind `norm3`, transformer_dec.py:492-495); C2 equals mdqe_layernorm_f32(C) bit for bit. */
+int mdqe_gemm_ln2_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
+                      const float* residual, long ldr, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                      float* C2, long ldc2, float eps, void* stream);
 
 /* A projection of `x + pos` whose pos is a linear function of four numbers per row -- the decoder's query position embedding
  * point2pos_proj(box centre) (mdqe/models/transformer_dec.py:42,469,480,495,503), consumed as `x + pos` by the self-attention q/k

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mdqe_conv2d_nhwc_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, i, i, i, p, l, i, i, p, i, p, p],
     "mdqe_layernorm_f32": [p, p, p, p, p, l, i, f, p],
     "mdqe_gemm_ln_f32": [p, l, p, p, p, l, i, i, i, p, l, p, p, f, p],
+    "mdqe_gemm_ln2_f32": [p, l, p, p, p, l, i, i, i, p, l, p, p, p, p, p, l, f, p],
     "mdqe_gemm_nt_side_f32": [p, l, p, p, p, l, i, i, i, p, p, i, p, p],
     "mdqe_gemm_nt_cat2_f32": [p, l, i, p, l, i, i, i, i, i, i, i, p, p, p, l, i, i, p],
     "mdqe_groupnorm_nhwc_f32": [p, l, l, p, l, l, i, i, i, i, p, p, f, i, p, p],

@@ -403,6 +403,31 @@ extern "C" int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const 
   return mdqe_launch_gemm_k16(p, 6, (hipStream_t)stream);
 }
 
+// ... with a SECOND LayerNorm of the result in the same epilogue: C = LN(A W^T + bias + residual) * gamma + beta and
+// C2 = LN(C) * gamma2 + beta2 -- the decoder's `x = norm3(x + ffn(x))` followed by the shared `decoder_norm(x)` that feeds the box head
+// (transformer_dec.py:352-358,492-495).  C2 equals mdqe_layernorm_f32 applied to C bit for bit (same reduction tree).
+extern "C" int mdqe_gemm_ln2_f32(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N,
+                                 int K, const float* residual, long ldr, const float* gamma, const float* beta, const float* gamma2,
+                                 const float* beta2, float* C2, long ldc2, float eps, void* stream) {
+  MDQE_REQUIRE(M >= 0 && N == 256 && K > 0 && K % 4 == 0 && lda % 4 == 0 && lda >= K && ldc >= N && ldc % 4 == 0 && ldc2 >= N && ldc2 % 4 == 0);
+  if (M == 0) return MDQE_OK;
+  MDQE_CHECK_PTR(A); MDQE_CHECK_PTR(W); MDQE_CHECK_PTR(C); MDQE_CHECK_PTR(gamma); MDQE_CHECK_PTR(beta);
+  MDQE_CHECK_PTR(gamma2); MDQE_CHECK_PTR(beta2); MDQE_CHECK_PTR(C2);
+  MDQE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)gamma |
+                 (uintptr_t)beta | (uintptr_t)gamma2 | (uintptr_t)beta2 | (uintptr_t)C2) & 15) == 0);
+  MDQE_REQUIRE(residual == nullptr || (ldr >= N && ldr % 4 == 0));
+  const long ab = ((long)(M - 1) * lda + K) * 4, wb = (long)N * K * 4;
+  MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  GemmParams p = {};
+  p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
+  p.bias = bias; p.residual = residual; p.ldr = ldr; p.act = MDQE_ACT_NONE;
+  p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.ksplit = 1; p.kchunk = K; p.vec_ok = 1;
+  p.ln_g = gamma; p.ln_b = beta; p.ln_eps = eps;
+  p.ln2_g = gamma2; p.ln2_b = beta2; p.C2 = C2; p.ldc2 = ldc2;
+  mdqe_clear_error();
+  return mdqe_launch_gemm_k16(p, 6, (hipStream_t)stream);
+}
+
 
 // ---- N <= 8 output columns (the decoder's box head 256 -> 4 and time weights 256 -> 1, on 31 360 rows a pass): a 128x64 MFMA tile
 // computes 64 columns to keep 4, and the launch is bound by reading A anyway.  Here a wave takes 4 rows at a time, a lane 4

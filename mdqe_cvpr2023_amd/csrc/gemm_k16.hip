@@ -281,8 +281,61 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int m = m0 + i * 32 + it * 8 + rsub;
-          if (m < p.M) *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
+          vv[i][j][it] = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
+          if (m < p.M) *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = vv[i][j][it];
         }
+    }
+    if (p.ln2_g != nullptr) {
+      // second LayerNorm, of the values just written (they are still in vv): the same two passes over the same reduction tree --
+      // a lane's two chunks in stage order, the 8 lanes of a 32-column group, the four wave slices as (w0 + w1) + (w2 + w3)
+      __syncthreads();                               // every wave has read red1 / red2 of the first LayerNorm
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          float x = 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) { const f32x4 v = vv[i][j][it]; x += (v[0] + v[1]) + (v[2] + v[3]); }
+          x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4);
+          if (c4 == 0) red1[wave * BM + i * 32 + it * 8 + rsub] = x;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = i * 32 + it * 8 + rsub;
+          mean[i][it] = ((red1[row] + red1[BM + row]) + (red1[2 * BM + row] + red1[3 * BM + row])) * (1.f / 256.f);
+          float q = 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const f32x4 d = vv[i][j][it] - mean[i][it];
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+          }
+          q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+          if (c4 == 0) red2[wave * BM + row] = q;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = i * 32 + it * 8 + rsub;
+          rstd[i][it] = rsqrtf(((red2[row] + red2[BM + row]) + (red2[2 * BM + row] + red2[3 * BM + row])) * (1.f / 256.f) + p.ln_eps);
+        }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = wn * 64 + j * 32 + c4 * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln2_g + n);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln2_b + n);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int m = m0 + i * 32 + it * 8 + rsub;
+            if (m < p.M) *reinterpret_cast<f32x4*>(p.C2 + (long)m * p.ldc2 + n) = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
+          }
+      }
     }
     return;
   }

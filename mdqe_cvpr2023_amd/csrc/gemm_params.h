@@ -21,6 +21,9 @@ struct GemmParams {
   unsigned long long* stamps;   // debug: per-block s_memtime stamps (mdqe_debug_gemm_stamps), null in production
   const void* Wh; const void* Wl;   // pre-split f16 planes of W ([N][K] each; gemm_f16x3w.hip) or null
   const float* ln_g; const float* ln_b; float ln_eps;   // tile 6: LayerNorm over the 256 columns in the epilogue
+  // ... and optionally a SECOND LayerNorm of that result into C2 (the decoder's `decoder_norm(norm3(..))`, transformer_dec.py:492-495):
+  // C2 = LN(C) * ln2_g + ln2_b, statistics by the same reduction tree (= layernorm_kernel on C, bit for bit)
+  const float* ln2_g; const float* ln2_b; float* C2; long ldc2;
   // cat mode (A2 != null, K-step-16 kernel, plain tiles): k < K1 comes from A, k >= K1 from row (img, oh*stride, ow*stride) of the NHWC
   // tensor A2 [*, H, Wd, lda2] -- output row m = (img, oh, ow) on the OH x OW grid (H, Wd, OH, OW, stride as in conv mode)
   const float* A2; long lda2; int K1; unsigned a2_bytes;

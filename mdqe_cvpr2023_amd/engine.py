@@ -604,9 +604,10 @@ class Engine:
         fused = DEC_FUSED
         small = fused and C == 256                                  # the two wave-per-(clip, query) kernels are written for C == 256
 
-        def refine(z, prev):
-            """bbox_embed(decoder_norm(z)) -> refined boxes + clip boxes (transformer_dec.py:473-480, 492-503)."""
-            z = ops.layernorm(z, *P.dec_norm)
+        def refine(z, prev, zn=None):
+            """bbox_embed(decoder_norm(z)) -> refined boxes + clip boxes (transformer_dec.py:473-480, 492-503).  zn: decoder_norm(z) when
+            the producing GEMM's epilogue has already computed it (ops.linear_ln(second=...))."""
+            z = ops.layernorm(z, *P.dec_norm) if zn is None else zn
             if small:
                 h = ops.linear(ops.linear(z, *P.bbox_embed[0], act="gelu"), *P.bbox_embed[1], act="gelu")
                 return ops.box_head_refine(h, *P.bbox_embed[2], prev, Bc, T, Q, t0, t1)
@@ -687,7 +688,11 @@ class Engine:
             sx = x
             x = ops.linear_ln(qkv(L.sa, x, boxes, BT), L.sa.wo, L.sa.bo, x, *L.norm1)
             hdn = ops.linear(x, *L.linear1, act="gelu")
-            x = ops.linear_ln(hdn, *L.linear2, x, *L.norm3)
+            xn = None
+            if L is not P.dec[-1]:                  # the refinement behind this layer reads decoder_norm(x): second LayerNorm of the same epilogue
+                x, xn = ops.linear_ln(hdn, *L.linear2, x, *L.norm3, second=P.dec_norm)
+            else:
+                x = ops.linear_ln(hdn, *L.linear2, x, *L.norm3)
             # ---- instance level (transformer_dec.py:361-409)
             vi_inst = vi
             if L.ta is not None:
@@ -704,7 +709,7 @@ class Engine:
             # ---- iterative box refinement (transformer_dec.py:492-503); the boxes behind the LAST layer feed nothing at eval (the
             # decoder's outputs are the instance queries' heads, :505-513), so that refinement is not run
             if L is not P.dec[-1]:
-                boxes, ibox = refine(x, boxes)
+                boxes, ibox = refine(x, boxes, xn)
         if two:
             main.wait_stream(side)                      # (x_inst lives in the side stream's pool; the next call's side work starts behind
             del hold                                    #  `side.wait_stream(main)` above, i.e. behind everything that reads it on main)

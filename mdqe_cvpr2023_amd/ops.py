@@ -175,10 +175,12 @@ LINEAR_LN_FUSED = os.environ.get("MDQE_LINEAR_LN_FUSED", "1") != "0"     # 0: GE
 LINEAR_LN_MIN_ROWS = 16384        # below this the 64x256 tile leaves CUs idle: 64x64 GEMM + LayerNorm kernel is faster
 
 
-def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratch=None):
+def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratch=None, second=None):
     """out = LayerNorm(x @ weight^T + bias + residual) * gamma + beta over N == 256 columns; `out` may be `residual`.
     One kernel (64x256 tile, statistics in the epilogue) in exact-fp32 mode with enough rows to fill the chip; otherwise
-    the GEMM (own tile / f16x3 arithmetic) into `scratch` followed by the LayerNorm kernel."""
+    the GEMM (own tile / f16x3 arithmetic) into `scratch` followed by the LayerNorm kernel.
+    second=(gamma2, beta2): also returns out2 = LayerNorm(out) * gamma2 + beta2 -- in the same epilogue where the one-kernel form runs
+    (mdqe_gemm_ln2_f32), by one more LayerNorm launch otherwise; the two give the same bits."""
     M, K = x.shape
     N = weight.shape[0]
     if out is None:
@@ -189,12 +191,23 @@ def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratc
     full = nb >= 1024 or nb / (256.0 * ((nb + 255) // 256)) >= 0.8
     if LINEAR_LN_FUSED and N == 256 and M >= LINEAR_LN_MIN_ROWS and full and get_gemm_precision() == "f32" and x.stride(1) == 1:
         _chk(weight, "weight"); _chk(bias, "bias"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(residual, "residual"); _chk(out, "out")
+        if second is not None and LINEAR_LN2_FUSED:
+            _chk(second[0], "gamma2"); _chk(second[1], "beta2")
+            out2 = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            check(lib.mdqe_gemm_ln2_f32(ptr(x), x.stride(0) if M > 1 else K, ptr(weight), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                                        ptr(residual), residual.stride(0) if residual is not None else 0, ptr(gamma), ptr(beta),
+                                        ptr(second[0]), ptr(second[1]), ptr(out2), out2.stride(0), eps, cur_stream()), "gemm_ln2_f32")
+            return out, out2
         check(lib.mdqe_gemm_ln_f32(ptr(x), x.stride(0) if M > 1 else K, ptr(weight), ptr(bias), ptr(out), out.stride(0), M, N, K,
                                    ptr(residual), residual.stride(0) if residual is not None else 0, ptr(gamma), ptr(beta), eps,
                                    cur_stream()), "gemm_ln_f32")
-        return out
+        return out if second is None else (out, layernorm(out, second[0], second[1], eps=eps))
     y = linear(x, weight, bias, residual=residual, out=scratch)
-    return layernorm(y, gamma, beta, eps=eps, out=out)
+    out = layernorm(y, gamma, beta, eps=eps, out=out)
+    return out if second is None else (out, layernorm(out, second[0], second[1], eps=eps))
+
+
+LINEAR_LN2_FUSED = os.environ.get("MDQE_LINEAR_LN2_FUSED", "1") != "0"   # 0: the second LayerNorm as its own launch (debug / A-B)
 
 
 def linear_side(x, weight, bias, side, side_w, side_cols, out=None):

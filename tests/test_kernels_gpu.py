@@ -438,6 +438,34 @@ def test_linear_layernorm_fused():
         assert out2.data_ptr() == rc.data_ptr() and torch.equal(out2, out)
 
 
+def test_linear_layernorm_with_a_second_layernorm_in_the_epilogue():
+    """mdqe_gemm_ln2_f32 (round 4): `x = norm3(x + ffn(x))` and the shared `decoder_norm(x)` that feeds the box head
+    (transformer_dec.py:352-358,492-495) from ONE epilogue.  The first output equals mdqe_gemm_ln_f32's and the second equals
+    mdqe_layernorm_f32 applied to the first, BIT FOR BIT (same reduction tree) -- so which form a launch takes (one-kernel form from
+    16384 rows up, GEMM + two LayerNorm launches below) never changes a result; ragged row counts, both K of the decoder."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M, K in ((29008, 1024), (16384 + 37, 256), (204000, 1024), (7252, 1024)):
+        x = torch.randn(M, K, device="cuda", generator=g); w = torch.randn(256, K, device="cuda", generator=g) / K ** 0.5
+        b = torch.randn(256, device="cuda", generator=g); r = torch.randn(M, 256, device="cuda", generator=g) * 3 + 0.5
+        g1, b1 = torch.randn(256, device="cuda", generator=g), torch.randn(256, device="cuda", generator=g)
+        g2, b2 = torch.rand(256, device="cuda", generator=g) + 0.5, torch.randn(256, device="cuda", generator=g)
+        one = ops.linear_ln(x, w, b, r, g1, b1)
+        want2 = ops.layernorm(one, g2, b2)
+        got1, got2 = ops.linear_ln(x, w, b, r, g1, b1, second=(g2, b2))
+        assert torch.equal(got1, one) and torch.equal(got2, want2), (M, K)
+        old = ops.LINEAR_LN2_FUSED
+        try:
+            ops.LINEAR_LN2_FUSED = False               # the second LayerNorm as its own launch
+            a1, a2 = ops.linear_ln(x, w, b, r, g1, b1, second=(g2, b2))
+        finally:
+            ops.LINEAR_LN2_FUSED = old
+        assert torch.equal(a1, one) and torch.equal(a2, want2)
+    ref = F.layer_norm(F.layer_norm(x.double() @ w.double().t() + b.double() + r.double(), (256,), g1.double(), b1.double(), 1e-5),
+                       (256,), g2.double(), b2.double(), 1e-5)
+    assert float((got2.double() - ref).abs().max()) < 3e-5
+
+
 @pytest.mark.parametrize("shapes,B,M,D", [
     ([(12, 20), (6, 10), (3, 5), (2, 3)], 3, 8, 32),          # 96x160 frames
     ([(8, 12), (4, 6), (2, 3), (1, 2)], 17, 8, 32),           # the tests' 64x96 frames; 17 >= 16 frames: XCD-aware block order
