@@ -168,7 +168,10 @@ int mdqe_debug_msda_dec_staged(int v); /* fused MSDA, decoder box-level launch: 
 int mdqe_debug_msda_stage_kb(int v);   /* fused MSDA (encoder / box level): LDS budget in KB of the staged coarse levels (default 150); tools/ A/B */
 int mdqe_debug_msda_tp_staged(int v);  /* fused MSDA, decoder temporal launch: 1 (default) = frame-by-frame LDS staging (msda_fused_tp_kernel), 0 = v2 */
 int mdqe_debug_msda_op_staged(int v); /* native MSDA op: 1 (default) = coarse levels staged in LDS (msda_fwd_v3_kernel), 0 = v2 */
-int mdqe_debug_msda_variant(int v);   /* fused MSDA: block-to-query map 0 / 1 / 2 (+4: 8 waves per SIMD); -1 = default */
+int mdqe_debug_msda_variant(int v);   /* fused MSDA (tools/ only), bit field: block-to-query map 0 / 1 / 2 of the gather form; +4: its 8-waves-per-SIMD
+                                        * hint; +8: coarse levels staged in LDS; (v >> 4) & 7: queries per block 32 << (k - 1); +128: 512-thread blocks;
+                                        * +256: no 8-waves-per-SIMD build of the staged encoder kernel; +1024: first staged level as a compile-time
+                                        * constant (a level's 16 corner loads in flight); -1 = default (by shape) */
 int mdqe_debug_mha_variant(int v);   /* same for the 196-token decoder self-attention */
 
 /* ---- NHWC convolution as implicit GEMM on the same kernel ---------------------------------------
