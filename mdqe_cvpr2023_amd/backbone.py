@@ -65,8 +65,11 @@ class SwinTransformerV2(nn.Module):
             m = m._modules[p]
         m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
-    def _load_from_state_dict(self, *a, **k):
-        super()._load_from_state_dict(*a, **k)
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        for key in list(state_dict):                   # the reference's fixed buffers (swin_transformer_v2.py:120,133): accepted and dropped
+            if key.startswith(prefix) and key.endswith(("relative_coords_table", "relative_position_index", "attn_mask")):
+                state_dict.pop(key)
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
         self._engine = None                            # repack on the next call
 
     def train(self, mode=True):

@@ -90,8 +90,11 @@ class MDQE(nn.Module):
         # accept (and drop) the reference checkpoint's aliased / non-eval keys
         for k in list(state_dict):
             kk = k[len(prefix):]
+            # (+ the SwinV2 blocks' fixed buffers -- `relative_coords_table`, `relative_position_index`, swin_transformer_v2.py:120,133 -- and
+            # the shift masks some exports carry: functions of the window size, rebuilt here)
             if any(kk.startswith(a) for a in ALIASES) or kk.endswith((".sampling_offsets", "lvl_spatial_scales",
-                                                                      "query_relpos_grid", "num_batches_tracked")) \
+                                                                      "query_relpos_grid", "num_batches_tracked",
+                                                                      "relative_coords_table", "relative_position_index", "attn_mask")) \
                     or kk.startswith("criterion."):
                 if not (kk.endswith(".sampling_offsets.weight") or kk.endswith(".sampling_offsets.bias")):
                     state_dict.pop(k)
