@@ -423,12 +423,6 @@ int mdqe_swin_window_f32(const float* src, const float* shortcut, float* dst, in
                          int shift, int mode, void* stream);
 int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int N, int C, int nh,
                          const float* scale, const float* bias, const float* mask, int nW, void* stream);
-/* The same attention with the position bias and the shift mask in their GENERATING form (round 4): rel_tab [nh, (2 ws - 1)^2] (the bias by
- * relative position, WindowAttention's relative_position_index :101-131) and region [nW, N] uint8 (the cyclic shift's region of every
- * token of the nW window positions of an image, BasicLayer.forward :397-415; NULL: no shift) instead of the dense [nh, N, N] / [nW, N, N]
- * tables, which cost every (window, head) block 2 x 83 KB of L2 reads at N = 144.  N = ws * ws, head dim 32.  Equal bits. */
-int mdqe_window_attn_compact_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int ws, int C, int nh,
-                                 const float* scale, const float* rel_tab, const unsigned char* region, int nW, void* stream);
 int mdqe_patch_merge_gather_f32(const float* x, float* out, int B, int H, int W, int C, void* stream);
 
 #ifdef __cplusplus

@@ -56,7 +56,6 @@ SIGNATURES = {
     "mdqe_patch4_im2col_f32": [p, i, l, i, i, i, i, i, p, p, p, p],
     "mdqe_swin_window_f32": [p, p, p, i, i, i, i, i, i, i, p],
     "mdqe_window_attn_f32": [p, l, p, l, i, i, i, i, p, p, p, i, p],
-    "mdqe_window_attn_compact_f32": [p, l, p, l, i, i, i, i, p, p, p, i, p],
     "mdqe_patch_merge_gather_f32": [p, p, i, i, i, i, p],
     "mdqe_gemm_nt_f32": [p, l, p, p, p, l, i, i, i, i, i, p, l, i, i, p, i, i, i, p, p, p],
     "mdqe_f16x3_split_f32": [p, l, p, p],

@@ -180,33 +180,19 @@ window_attn_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o
 //   second product if ITS k index is taken as that same key order (B = V[key][d] is read from LDS in any order), so the
 //   probabilities never leave their registers;  O tile (16 queries x 16 d) += P . V.
 // Softmax statistics per query: 36 scores in-lane, then two cross-lane steps over the four 16-lane groups.
-// COMPACT (round 4): the position bias and the shift mask in their generating form.  bias[h, i, j] depends only on the relative position
-// of tokens i and j inside the window -- (2 ws - 1)^2 values per head (WindowAttention.__init__ :101-131: relative_position_index) -- and
-// mask[w, i, j] is -100 where i and j lie in different regions of the cyclic shift, else 0 (BasicLayer.forward :397-415).  The dense
-// [nh, N, N] / [nW, N, N] tables cost every (window, head) block 2 x 83 KB of L2 reads at N = 144 -- three quarters of the bytes a block
-// touches; here the block stages its head's (2 ws - 1)^2 table (2 KB) and its window's N region ids in LDS and indexes them: the same
-// float values in the same order of additions, so the same bits.
-template <int NWV, bool COMPACT = false>
+template <int NWV>
 __global__ void __launch_bounds__(64 * NWV)
 window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restrict__ o, long ldo, int N, int C, int nh,
-                        const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ mask, int nW,
-                        const float* __restrict__ rel_tab, const unsigned char* __restrict__ region, int ws) {
+                        const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ mask, int nW) {
   constexpr int D = 32, LDK = 36, MAXT = 12;         // up to 12 key tiles (N <= 192)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NT = (N + 15) / 16, NP = NT * 16;
   float* sK = sm;                                    // [NP][36] normalised keys (rows >= N zero)
   float* sV = sm + NP * LDK;                         // [NP][36]
-  float* sTab = sV + NP * LDK;                       // COMPACT: [(2 ws - 1)^2] bias of this head by relative position
-  unsigned char* sReg = reinterpret_cast<unsigned char*>(sTab + (2 * ws - 1) * (2 * ws - 1));   // COMPACT: [N] region id of this window's tokens
   const int win = blockIdx.x / nh, h = blockIdx.x % nh;
   const long row0 = (long)win * N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, g = lane >> 4;
-  if constexpr (COMPACT) {
-    const int nt = (2 * ws - 1) * (2 * ws - 1);
-    for (int i = tid; i < nt; i += 64 * NWV) sTab[i] = rel_tab[(long)h * nt + i];
-    for (int i = tid; i < N; i += 64 * NWV) sReg[i] = region != nullptr ? region[(long)(win % nW) * N + i] : (unsigned char)0;
-  }
   for (int r = tid; r < NP; r += 64 * NWV) {
     f32x4 kk[8], vv[8];
     float ss = 0.f;
@@ -243,11 +229,8 @@ window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restric
       q[0] = a[0] * inv; q[1] = a[1] * inv; q[2] = a[2] * inv; q[3] = a[3] * inv;
       q[4] = b[0] * inv; q[5] = b[1] * inv; q[6] = b[2] * inv; q[7] = b[3] * inv;
     }
-    const float* bp = COMPACT ? nullptr : bias + ((long)h * N + qi) * N;
-    const float* mp = (!COMPACT && mask != nullptr) ? mask + ((long)(win % nW) * N + qi) * N : nullptr;
-    const int qy = qi / ws, qx = qi - qy * ws;         // COMPACT: the query's cell inside the window
-    const int qreg = COMPACT ? (int)sReg[qi] : 0;
-    const bool masked = COMPACT && region != nullptr;
+    const float* bp = bias + ((long)h * N + qi) * N;
+    const float* mp = mask != nullptr ? mask + ((long)(win % nW) * N + qi) * N : nullptr;
     f32x4 sT[MAXT];
     float mx = -INFINITY;
 #pragma unroll
@@ -262,18 +245,8 @@ window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restric
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[t], q[4 + t], acc, 0, 0, 0);
         const int j = jt * 16 + 4 * g;                               // this lane's four keys j .. j+3 (N % 4 == 0)
         if (j < N) {
-          f32x4 bb;
-          if constexpr (COMPACT) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int ky = (j + r) / ws, kx = (j + r) - ky * ws;
-              bb[r] = sTab[(qy - ky + ws - 1) * (2 * ws - 1) + (qx - kx + ws - 1)];
-              if (masked) bb[r] += ((int)sReg[j + r] != qreg) ? -100.0f : 0.0f;
-            }
-          } else {
-            bb = *reinterpret_cast<const f32x4*>(bp + j);
-            if (mp != nullptr) bb += *reinterpret_cast<const f32x4*>(mp + j);
-          }
+          f32x4 bb = *reinterpret_cast<const f32x4*>(bp + j);
+          if (mp != nullptr) bb += *reinterpret_cast<const f32x4*>(mp + j);
 #pragma unroll
           for (int r = 0; r < 4; ++r) { acc[r] = __builtin_fmaf(bb[r], L2E, acc[r]); mx = fmaxf(mx, acc[r]); }
         } else {
@@ -325,51 +298,30 @@ window_attn_mfma_kernel(const float* __restrict__ qkv, long ld, float* __restric
 static int g_window_attn_variant = 1;   // 1: MFMA form where it applies, 0: scalar form everywhere (tools/ A/B)
 extern "C" int mdqe_debug_window_attn_variant(int v) { g_window_attn_variant = v; return MDQE_OK; }
 
-static int window_attn_impl(const float* qkv, long ld, float* o, long ldo, int n_windows, int N, int C, int nh, const float* scale,
-                            const float* bias, const float* mask, int nW, const float* rel_tab, const unsigned char* region, int ws,
-                            void* stream) {
+extern "C" int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int N, int C, int nh,
+                                    const float* scale, const float* bias, const float* mask, int nW, void* stream) {
   MDQE_REQUIRE(n_windows >= 0 && N > 0 && N <= 256 && nh > 0 && C % nh == 0 && ld % 4 == 0 && ldo % 4 == 0 && nW > 0);
   const int D = C / nh;
   MDQE_REQUIRE(D == 32 || D == 24 || D == 16 || D == 8);
   if (n_windows == 0) return MDQE_OK;
-  MDQE_CHECK_PTR(qkv); MDQE_CHECK_PTR(o); MDQE_CHECK_PTR(scale);
-  const bool compact = rel_tab != nullptr;
-  if (!compact) MDQE_CHECK_PTR(bias);
+  MDQE_CHECK_PTR(qkv); MDQE_CHECK_PTR(o); MDQE_CHECK_PTR(scale); MDQE_CHECK_PTR(bias);
   mdqe_clear_error();
   hipStream_t st = (hipStream_t)stream;
   if (D == 32 && N <= 192 && N % 4 == 0 && g_window_attn_variant != 0) {
-    size_t smem2 = (size_t)2 * ((N + 15) / 16 * 16) * 36 * sizeof(float);
-    if (compact) smem2 += (size_t)(2 * ws - 1) * (2 * ws - 1) * sizeof(float) + (size_t)((N + 15) / 16 * 16);
+    const size_t smem2 = (size_t)2 * ((N + 15) / 16 * 16) * 36 * sizeof(float);
     // 9 row tiles of 16 queries (N = 144) over NWV waves; g_window_attn_variant: 1 = the measured best, 2 -> 3 waves, 3 -> 5, 4 -> 9
-#define LW(NW_, CP_) hipLaunchKernelGGL((window_attn_mfma_kernel<NW_, CP_>), dim3(n_windows * nh), dim3(64 * NW_), smem2, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW, rel_tab, region, ws)
+#define LW(NW_) hipLaunchKernelGGL((window_attn_mfma_kernel<NW_>), dim3(n_windows * nh), dim3(64 * NW_), smem2, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW)
     const int nwv = g_window_attn_variant == 2 ? 3 : g_window_attn_variant == 3 ? 5 : g_window_attn_variant == 4 ? 9 : 3;
-    if (compact) { if (nwv == 5) LW(5, true); else if (nwv == 9) LW(9, true); else LW(3, true); }
-    else { if (nwv == 5) LW(5, false); else if (nwv == 9) LW(9, false); else LW(3, false); }
+    if (nwv == 5) LW(5); else if (nwv == 9) LW(9); else LW(3);
 #undef LW
     return mdqe_launch_status();
   }
-  if (compact) return MDQE_EINVAL;                   // the scalar form takes the dense tables
   const size_t smem = (size_t)2 * N * D * sizeof(float);
 #define L(DD) do { (void)hipFuncSetAttribute((const void*)window_attn_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL((window_attn_kernel<DD>), dim3(n_windows * nh), dim3(256), smem, st, qkv, ld, o, ldo, N, C, nh, scale, bias, mask, nW); } while (0)
   if (D == 32) L(32); else if (D == 24) L(24); else if (D == 16) L(16); else L(8);
 #undef L
   return mdqe_launch_status();
-}
-
-extern "C" int mdqe_window_attn_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int N, int C, int nh,
-                                    const float* scale, const float* bias, const float* mask, int nW, void* stream) {
-  return window_attn_impl(qkv, ld, o, ldo, n_windows, N, C, nh, scale, bias, mask, nW, nullptr, nullptr, 0, stream);
-}
-
-// The same attention with the position bias and the shift mask in their generating form: rel_tab [nh, (2 ws - 1)^2] = the bias by relative
-// position (index (yi - yj + ws - 1) * (2 ws - 1) + (xi - xj + ws - 1)), region [nW, N] uint8 = the shift region of every token of the nW
-// window positions of an image (NULL: no shift).  N == ws * ws, head dim 32 (MDQE_EINVAL otherwise: use the dense form).  Equal bits.
-extern "C" int mdqe_window_attn_compact_f32(const float* qkv, long ld, float* o, long ldo, int n_windows, int ws, int C, int nh,
-                                            const float* scale, const float* rel_tab, const unsigned char* region, int nW, void* stream) {
-  MDQE_REQUIRE(ws > 0 && ws * ws <= 192 && (ws * ws) % 4 == 0 && nh > 0 && C == nh * 32);
-  MDQE_CHECK_PTR(rel_tab);
-  return window_attn_impl(qkv, ld, o, ldo, n_windows, ws * ws, C, nh, scale, nullptr, nullptr, nW, rel_tab, region, ws, stream);
 }
 
 // ---- patch merging gather (PatchMerging.forward :311-335): [B,H,W,C] -> [B*H2*W2, 4C] = (x0|x1|x2|x3) ----------------

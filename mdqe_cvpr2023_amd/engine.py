@@ -40,7 +40,6 @@ def _fold_bn(sd, p, eps=1e-5):
 
 GEO_CACHE = max(1, int(os.environ.get("MDQE_GEO_CACHE", "16")))     # resolutions whose constants stay resident
 STEM_FUSED = os.environ.get("MDQE_STEM_FUSED", "1") != "0"      # 0: im2col + GEMM (debug / A-B)
-SWIN_COMPACT = os.environ.get("MDQE_SWIN_COMPACT", "1") != "0"  # 0: dense bias / mask tables in the window attention (debug / A-B)
 SWIN_FUSED = os.environ.get("MDQE_SWIN_FUSED", "1") != "0"      # 0: window partition / reverse as copy kernels (debug / A-B)
 RESNET_CAT = os.environ.get("MDQE_RESNET_CAT", "1") != "0"      # 0: projection shortcut and conv3 as two launches (debug / A-B)
 
@@ -61,20 +60,6 @@ def _swin_rel_tables(ws):
     rel[:, :, 1] += ws - 1
     rel[:, :, 0] *= 2 * ws - 1
     return tab, rel.sum(-1)
-
-
-def _swin_shift_regions(H, W, ws):
-    """Region id (0..8) of every token of every window position under the cyclic shift -> uint8 [nW, N]: the generating form of
-    _swin_shift_mask (mask[w, i, j] = -100 where region[w, i] != region[w, j])."""
-    ss = ws // 2
-    Hp, Wp = int(np.ceil(H / ws)) * ws, int(np.ceil(W / ws)) * ws
-    img = torch.zeros(Hp, Wp)
-    cnt = 0
-    for h in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
-        for w in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
-            img[h, w] = cnt
-            cnt += 1
-    return img.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws).to(torch.uint8).contiguous()
 
 
 def _swin_shift_mask(H, W, ws):
@@ -160,15 +145,13 @@ class Packed:
                     # continuous position bias: input independent -> evaluated once here (the reference re-runs the
                     # cpb MLP in every block of every call, :164-169)
                     t = F.linear(F.relu(F.linear(tab, sd[a + ".cpb_mlp.0.weight"], sd[a + ".cpb_mlp.0.bias"])), sd[a + ".cpb_mlp.2.weight"])
-                    rel = 16 * torch.sigmoid(t.view(-1, nhs))                          # [(2 ws - 1)^2, nh]: the bias by relative position
-                    bias = rel[idx.view(-1)].view(ws * ws, ws * ws, nhs).permute(2, 0, 1).contiguous()
+                    bias = 16 * torch.sigmoid(t.view(-1, nhs)[idx.view(-1)].view(ws * ws, ws * ws, nhs).permute(2, 0, 1).contiguous())
                     scale = torch.clamp(sd[a + ".logit_scale"], max=math.log(1. / 0.01)).exp().flatten()
                     stg.blocks.append(NS(
                         shift=0 if j % 2 == 0 else ws // 2,
                         wqkv=up(sd[a + ".qkv.weight"]),
                         bqkv=up(torch.cat([sd[a + ".q_bias"], torch.zeros_like(sd[a + ".v_bias"]), sd[a + ".v_bias"]])),
                         wproj=up(sd[a + ".proj.weight"]), bproj=up(sd[a + ".proj.bias"]), scale=up(scale), bias=up(bias),
-                        rel=up(rel.t().contiguous()),
                         n1=(up(sd[q + ".norm1.weight"]), up(sd[q + ".norm1.bias"])), n2=(up(sd[q + ".norm2.weight"]), up(sd[q + ".norm2.bias"])),
                         fc1=(up(sd[q + ".mlp.fc1.weight"]), up(sd[q + ".mlp.fc1.bias"])),
                         fc2=(up(sd[q + ".mlp.fc2.weight"]), up(sd[q + ".mlp.fc2.bias"]))))
@@ -350,10 +333,8 @@ class Geometry:
         if P.swin is not None:
             H, W = self.Hp // 4, self.Wp // 4
             self.swin_masks = []
-            self.swin_regions = []
             for stg in P.swin.stages:
                 self.swin_masks.append((H, W, _swin_shift_mask(H, W, stg.ws).to(dev)))
-                self.swin_regions.append(_swin_shift_regions(H, W, stg.ws).to(dev))
                 H, W = (H + 1) // 2, (W + 1) // 2
 
     @staticmethod
@@ -472,12 +453,7 @@ class Engine:
                     qkv = ops.linear_swin(x4, blk.wqkv, blk.bqkv, ws, blk.shift)
                 else:
                     qkv = ops.linear(ops.swin_window_gather(x4, ws, blk.shift), blk.wqkv, blk.bqkv)
-                if SWIN_COMPACT and C == nh * 32 and N <= 192 and N % 4 == 0:
-                    # bias by relative position + shift regions instead of the dense [nh, N, N] / [nW, N, N] tables (equal bits)
-                    a = ops.window_attn_compact(qkv, NI * nWy * nWx, ws, C, nh, blk.scale, blk.rel,
-                                                geo.swin_regions[si] if blk.shift > 0 else None, nWy * nWx)
-                else:
-                    a = ops.window_attn(qkv, NI * nWy * nWx, N, C, nh, blk.scale, blk.bias, mask if blk.shift > 0 else None, nWy * nWx)
+                a = ops.window_attn(qkv, NI * nWy * nWx, N, C, nh, blk.scale, blk.bias, mask if blk.shift > 0 else None, nWy * nWx)
                 if fuse:                                                                         # shortcut + norm1(attn(x)) (:287)
                     x4 = ops.layernorm_swin_scatter(ops.linear(a, blk.wproj, blk.bproj), *blk.n1, x4, ws, blk.shift,
                                                     out=x4 if own else torch.empty_like(x4))

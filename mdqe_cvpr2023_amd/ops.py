@@ -517,16 +517,6 @@ def window_attn(qkv, n_windows, N, C, nh, scale, bias, mask=None, nW=1):
     return out
 
 
-def window_attn_compact(qkv, n_windows, ws, C, nh, scale, rel_tab, region=None, nW=1):
-    """window_attn with the bias as a [nh, (2 ws - 1)^2] table by relative position and the shift mask as uint8 region ids [nW, ws*ws]
-    (None: no shift) -- mdqe_window_attn_compact_f32; head dim 32 only."""
-    _chk(qkv, "qkv"); _chk(scale, "scale"); _chk(rel_tab, "rel_tab"); _chk(region, "region", torch.uint8)
-    out = torch.empty((n_windows * ws * ws, C), dtype=torch.float32, device=qkv.device)
-    check(lib.mdqe_window_attn_compact_f32(ptr(qkv), qkv.stride(0), ptr(out), C, n_windows, ws, C, nh, ptr(scale), ptr(rel_tab), ptr(region), nW,
-                                           cur_stream()), "window_attn_compact")
-    return out
-
-
 def patch_merge_gather(x):
     _chk(x, "x")
     B, H, W, C = x.shape
