@@ -41,7 +41,7 @@ def test_bench_line_contract():
 
 def test_bench_gpus_2_runs_two_ranks_without_torchrun():
     """`python bench.py --gpus 2` spawns its own ranks (rehearsal hooks: both on this box's one GPU, gloo instead of RCCL) and prints a
-    line for TWO ranks; without the hooks on a 1-GPU box it fails loudly instead of printing `n_gpus: 1`."""
+    line for TWO ranks."""
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     # (--halo-exchange: the rehearsal also takes the neighbour send/recv of the partitioned chunks through bench.py itself, on its own
@@ -51,8 +51,8 @@ def test_bench_gpus_2_runs_two_ranks_without_torchrun():
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "24", "--no-cpu-baseline", "--no-fast-mode"]
     env["MDQE_BENCH_HALO_AB"] = "1"
     if torch.cuda.device_count() < 2:
-        r = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+        # (that the same command WITHOUT the rehearsal hooks fails loudly on a box with fewer GPUs than ranks is held by
+        # tests/test_bench_cpu.py::test_bench_never_reports_the_wrong_world -- the ranks' own device-count check, no GPU needed)
         env.update(MDQE_BENCH_BACKEND="gloo", MDQE_BENCH_ONE_DEVICE="1")
     r = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
