@@ -165,6 +165,8 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
     // this wave's LDS-DMA for step kt has landed: at most the loads of the stages issued after it may still be in flight
     if constexpr (NS == 2) {
       wait_vmcnt<0>();
+    } else if constexpr (NS == 3) {
+      if (nk - 1 - kt >= 1) wait_vmcnt<IPW>(); else wait_vmcnt<0>();     // step kt + 1 may still be in flight
     } else {
       const int behind = nk - 1 - kt;                  // stages already issued behind step kt: min(NS - 2, behind)
       if (behind >= 2) wait_vmcnt<2 * IPW>(); else if (behind == 1) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
@@ -451,6 +453,11 @@ static int launch_k16_ns_(const GemmParams& p_in, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
 static int launch_k16_(const GemmParams& p, hipStream_t st) {
+  if constexpr (!LN && !CONV && BM * BN >= 128 * 64 && BM * BN <= 128 * 128) {
+    // tools/ only (mdqe_debug_gemm_stages(3)): three LDS stages for the large plain tiles -- two K-steps of look-ahead (48 KB per 128x128
+    // block: three blocks per CU instead of four); measured in tools/gemm_stages3_ab.py
+    if (g_k16_stages == 3) return launch_k16_ns_<BM, BN, WM, WN, CONV, LN, 3>(p, st);
+  }
   if constexpr (!LN && BM * BN <= 64 * 64) {
     // small tiles on a small grid (about one block per CU or less per SIMD wave slot): deep look-ahead
     const long blocks = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.ksplit > 1 ? p.ksplit : 1);
