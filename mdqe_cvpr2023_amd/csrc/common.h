@@ -51,6 +51,10 @@ __device__ __forceinline__ float mdqe_gelu(float x) {
   return x >= 0.f ? x - xh : xh;
 }
 
+// The activation of a float4 of a GEMM / conv epilogue (defined below mdqe_act).  ReLU and GELU -- every activation on the per-frame path -- are their own inlined
+// loops; the heads' sigmoid / tanh go through ONE rolled loop.  (Round 4: `mdqe_act`'s four-way switch, tanhf included, used to be
+// inlined per ELEMENT into every unrolled copy of the epilogue: the 128x128 GEMM kernel was 28 000 instructions long and even a ReLU
+// epilogue cost 12 % of the launch -- 107 against 120 TF on the FFN1 shape -- in instruction fetch.)  Same functions, same bits.
 __device__ __forceinline__ float mdqe_act(float x, int act) {
   switch (act) {
     case MDQE_ACT_RELU: return x > 0.f ? x : 0.f;
@@ -58,5 +62,25 @@ __device__ __forceinline__ float mdqe_act(float x, int act) {
     case MDQE_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
     case MDQE_ACT_TANH: return tanhf(x);
     default: return x;
+  }
+}
+
+template <typename V4, typename ColOk>
+__device__ __forceinline__ void mdqe_act4(V4& v, int act, ColOk col_ok) {
+  if (act == MDQE_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col_ok(e)) v[e] = v[e] > 0.f ? v[e] : 0.f;
+  } else if (act == MDQE_ACT_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col_ok(e)) v[e] = mdqe_gelu(v[e]);
+  } else if (act != MDQE_ACT_NONE) {
+#pragma unroll 1
+    for (int e = 0; e < 4; ++e) {                      // (rolled; the vector rotates through the loop: no dynamic register index)
+      float x = v[0];
+      if (col_ok(e)) x = mdqe_act(x, act);
+      v = V4{v[1], v[2], v[3], x};
+    }
   }
 }

@@ -354,7 +354,9 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
       for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[i][j][r];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
+      // (rolled, round 4: the body -- bias, side term, residual, activation, mask, the ragged-edge path -- is long, and sixteen unrolled
+      // copies of it per kernel made the epilogue an instruction-cache problem)
+#pragma unroll 1
       for (int it = 0; it < 4; ++it) {
         const int idx = it * 64 + lane;
         const int row = idx >> 3, c4 = idx & 7;
@@ -383,11 +385,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           f32x4 rv = {0.f, 0.f, 0.f, 0.f};
           if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
           if (p.res_first) v += rv;
-          if (p.act != MDQE_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (p.act_cols <= 0 || n + e < p.act_cols) v[e] = mdqe_act(v[e], p.act);
-          }
+          mdqe_act4(v, p.act, [&](int e) { return p.act_cols <= 0 || n + e < p.act_cols; });
           if (!p.res_first) v += rv;
           if (masked) {
 #pragma unroll
