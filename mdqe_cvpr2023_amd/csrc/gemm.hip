@@ -199,8 +199,8 @@ gemm_nt_f32_kernel(const GemmParams p) {
   const bool vec = p.vec_ok;
   int rr0 = 0;
   if (p.residual != nullptr && p.res_mod > 0) rr0 = m0 % p.res_mod;
-#pragma unroll 4
-  for (int it = 0; it < NV; ++it) {
+#pragma unroll 1
+  for (int it = 0; it < NV; ++it) {                   // (rolled: see gemm_k16.hip's epilogue)
     const int idx = it * (64 * NW) + tid;
     const int row = idx / C4, c4 = idx - row * C4;
     const int m = m0 + row, n = n0 + c4 * 4;
@@ -215,11 +215,7 @@ gemm_nt_f32_kernel(const GemmParams p) {
       f32x4 rv = {0.f, 0.f, 0.f, 0.f};
       if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
       if (p.res_first) v += rv;
-      if (p.act != MDQE_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (p.act_cols <= 0 || n + e < p.act_cols) v[e] = mdqe_act(v[e], p.act);
-      }
+      mdqe_act4(v, p.act, [&](int e) { return p.act_cols <= 0 || n + e < p.act_cols; });
       if (!p.res_first) v += rv;
       if (masked) {
 #pragma unroll

@@ -213,11 +213,7 @@ gemm_nt_f16x3_kernel(const GemmParams p) {
       f32x4 rv = {0.f, 0.f, 0.f, 0.f};
       if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
       if (p.res_first) v += rv;
-      if (p.act != MDQE_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (p.act_cols <= 0 || n + e < p.act_cols) v[e] = mdqe_act(v[e], p.act);
-      }
+      mdqe_act4(v, p.act, [&](int e) { return p.act_cols <= 0 || n + e < p.act_cols; });
       if (!p.res_first) v += rv;
       if (masked) {
 #pragma unroll
