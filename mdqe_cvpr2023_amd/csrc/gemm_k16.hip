@@ -348,21 +348,10 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   __syncthreads();                                   // every wave is done reading the last K-step
   float* sC = lds + wave * 1024;
   const bool vec = p.vec_ok;
-  // ONE copy of the epilogue body for the wave's MT x NT sub-tiles (round 4): the loop over sub-tiles is rolled; only the restage of the
-  // accumulator registers -- which must be indexed at compile time -- is selected by a (wave-uniform) switch.  With four inlined copies of the
-  // body (each with its own rolled / ragged paths and activation code) the 128x128 kernel was 28 000 instructions long before this round
-  // and its epilogue paid for that in instruction fetch: 107 against 120 TF on FFN1's shape with a ReLU that costs one instruction per value.
-#pragma unroll 1
-  for (int st_ = 0; st_ < MT * NT; ++st_) {
-      const int i = st_ / NT, j = st_ - i * NT;
+  auto sub = [&](auto i_, auto j_) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
 #pragma unroll
-      for (int ii = 0; ii < MT; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < NT; ++jj)
-          if (st_ == ii * NT + jj) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[ii][jj][r];
-          }
+      for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[i][j][r];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       // (rolled, round 4: the body -- bias, side term, residual, activation, mask, the ragged-edge path -- is long, and sixteen unrolled
@@ -405,14 +394,10 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           }
           *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
         } else {
-          // ragged edge / unaligned operands: element by element, ROLLED (the vector rotates through the loop so that no register is
-          // indexed dynamically) -- the generic activation switch, tanhf included, appears once here instead of four times
-#pragma unroll 1
+#pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (n + e >= p.N) break;
-            const float ve = v[0];
-            v = f32x4{v[1], v[2], v[3], ve};
-            float x = ve + (p.bias != nullptr ? p.bias[n + e] : 0.f);
+            float x = v[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f);
             if (p.side != nullptr && n + e < p.side_cols) {
               const float* s4 = p.side + (long)m * 4; const float* w4 = p.side_w + (long)(n + e) * 4;
               x += (s4[0] * w4[0] + s4[1] * w4[1]) + (s4[2] * w4[2] + s4[3] * w4[3]);
@@ -428,7 +413,12 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-  }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  sub(I0{}, I0{});
+  if constexpr (NT > 1) sub(I0{}, I1{});
+  if constexpr (MT > 1) sub(I1{}, I0{});
+  if constexpr (MT > 1 && NT > 1) sub(I1{}, I1{});
   if (p.stamps && tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long* o = p.stamps + (long)blockIdx.x * 4;
