@@ -394,10 +394,14 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           }
           *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
         } else {
-#pragma unroll
+          // ragged edge / unaligned operands: element by element, ROLLED (the vector rotates through the loop so that no register is
+          // indexed dynamically) -- the generic activation switch, tanhf included, appears once here instead of four times
+#pragma unroll 1
           for (int e = 0; e < 4; ++e) {
             if (n + e >= p.N) break;
-            float x = v[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f);
+            const float ve = v[0];
+            v = f32x4{v[1], v[2], v[3], ve};
+            float x = ve + (p.bias != nullptr ? p.bias[n + e] : 0.f);
             if (p.side != nullptr && n + e < p.side_cols) {
               const float* s4 = p.side + (long)m * 4; const float* w4 = p.side_w + (long)(n + e) * 4;
               x += (s4[0] * w4[0] + s4[1] * w4[1]) + (s4[2] * w4[2] + s4[3] * w4[3]);
