@@ -80,7 +80,7 @@ class Meter:
         from mdqe_cvpr2023_amd import ops, _lib
         L = _lib.load_library()
         raw, raw_conv, raw_ln, raw_cat = L.mdqe_gemm_nt_f32, L.mdqe_conv2d_nhwc_f32, L.mdqe_gemm_ln_f32, L.mdqe_gemm_nt_cat2_f32
-        raw_side, raw_msda = L.mdqe_gemm_nt_side_f32, L.mdqe_msda_fused_f32
+        raw_side, raw_msda, raw_ln2 = L.mdqe_gemm_nt_side_f32, L.mdqe_msda_fused_f32, L.mdqe_gemm_ln2_f32
         meter = self
 
         def timed(fn, a, sink, work):
@@ -116,6 +116,14 @@ class Meter:
                 if not (((M + 127) // 128) * ((N + 127) // 128) >= 192 and meter.take()):
                     return raw_ln(*a)
                 return timed(raw_ln, a, meter.rec, 2.0 * M * N * K)
+
+            def mdqe_gemm_ln2_f32(self_, *a):                 # ... with the second LayerNorm in the epilogue (same leading arguments)
+                M, N, K = a[6], a[7], a[8]
+                if meter.counting:
+                    meter.flops += 2.0 * M * N * K
+                if not (((M + 127) // 128) * ((N + 127) // 128) >= 192 and meter.take()):
+                    return raw_ln2(*a)
+                return timed(raw_ln2, a, meter.rec, 2.0 * M * N * K)
 
             def mdqe_gemm_nt_cat2_f32(self_, *a):             # bottleneck conv3 + projection shortcut as one product (same kernel template)
                 K1, K2, NI, OH, OW, N = a[2], a[5], a[6], a[7], a[8], a[16]
