@@ -587,11 +587,20 @@ def main():
             run(args.warmup, stream, **dict(kw, stats=None))
             sync()
             meter.enabled = meter_on
+            prof = None
+            if os.environ.get("MDQE_BENCH_CPROFILE") and rank == 0:    # tools/: where the HOST time of the timed steps goes (stderr)
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
             t0 = time.perf_counter()
             o = run(args.steps, stream, **kw)
             sync()
             d = time.perf_counter() - t0
             meter.enabled = False
+            if prof is not None:
+                import pstats
+                prof.disable()
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(int(os.environ["MDQE_BENCH_CPROFILE"]))
         if dist is not None:
             t = torch.tensor([d], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -322,6 +322,14 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     const int n256 = (p.N + 255) / 256 * 256, n128 = (p.N + 127) / 128 * 128;
     int bn = 256;
     if (n256 > n128 || (long)((p.M + 127) / 128) * (n256 / 256) < 200) bn = 128;
+    else {
+      // the kernel is persistent, one block per CU: tiles are dealt in rounds of g_num_cus, and a 128-column tile costs ~0.55 of a
+      // 256-column one (profiles/r04_f16x3w_one_site_ab.txt, columns "rule 8" / "rule 12") -- few-round grids take the narrow tile
+      // when that saves a partial round (300 tiles: 2 rounds -> 3 half rounds, 93.6 -> 82.7 us)
+      const long t256 = (long)((p.M + 127) / 128) * (n256 / 256), cus = 256;
+      const long r256 = (t256 + cus - 1) / cus, r128 = (2 * t256 + cus - 1) / cus;
+      if (r256 <= 4 && 0.55 * (double)r128 < 0.97 * (double)r256) bn = 128;
+    }
     int rc = mdqe_launch_gemm_f16x3w(p, bn, st);
     if (rc || p.ksplit <= 1) return rc;
     long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;
