@@ -348,7 +348,12 @@ class Geometry:
         if not self.any_pad:
             return None
         if n not in self._masks_rep:
-            self._masks_rep[n] = self.mask_flat.view(torch.uint8).repeat(n).contiguous()
+            m = self.mask_flat.view(torch.uint8).repeat(n).contiguous()
+            if m.is_cuda:
+                # built once per pass size on whatever stream asks first and then read from every stream of the pipeline (two frame
+                # streams, the clip stream's halo rows): complete before anyone can find it in the table
+                torch.cuda.current_stream(m.device).synchronize()
+            self._masks_rep[n] = m
         return self._masks_rep[n]
 
 
