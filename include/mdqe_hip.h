@@ -139,7 +139,11 @@ int mdqe_gemm_nt_side_f32(const float* A, long lda, const float* W, const float*
 /* GEMM arithmetic of the 128x128 tile (process-wide): 0 = exact fp32 MFMA (default), 1 = "f16x3": operands split
  * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752). */
 int mdqe_set_gemm_precision(int mode);
-int mdqe_get_gemm_precision(void);
+int mdqe_get_gemm_precision(void);   /* the mode the CALLING thread's launches use (its override if set, else the process-wide one) */
+/* The calling host thread's override of the mode: 0 / 1, or -1 = none (follow the process-wide mode).  Lets one region of the model --
+ * the regions the reference's harness runs under fp16 autocast (train_net.py:207) -- take the split-precision kernels
+ * while another host thread's launches (the sharded schedule's tracker replay) keep theirs. */
+int mdqe_set_gemm_precision_thread(int mode);
 
 /* One-time split of a CONSTANT weight tensor W (n = N*K fp32 values, row-major [N][K]) into the two f16 planes the
  * f16x3 mode consumes: planes = { hi[n], lo[n] } (4*n bytes), hi = f16_rtz(w), lo = f16_rtz((w - hi) * 2048).

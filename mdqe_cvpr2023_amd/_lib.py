@@ -50,6 +50,7 @@ SIGNATURES = {
     "mdqe_final_masks_rle": [p, i, p, i, i, i, i, i, i, i, i, i, p, p, p],
     "mdqe_final_masks_u8": [p, i, p, i, i, i, i, i, i, i, i, p, l, i, p],
     "mdqe_set_gemm_precision": [i],
+    "mdqe_set_gemm_precision_thread": [i],
     "mdqe_layernorm_post_f32": [p, p, p, p, p, l, i, f, p],
     "mdqe_gemm_nt_swin_f32": [p, l, p, p, p, l, i, i, i, i, i, i, i, p],
     "mdqe_layernorm_swin_scatter_f32": [p, p, p, p, p, i, i, i, i, i, i, f, p],

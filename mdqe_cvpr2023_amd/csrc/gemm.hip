@@ -291,10 +291,20 @@ extern "C" int mdqe_debug_gemm_rows_dot(int v) { g_gemm_rows_dot = v; return MDQ
 static int g_gemm_variant = 2;         // fp32 kernel form: 0 = K-step 32 (gemm.hip), 1 = K-step 16 (gemm_k16.hip), 2 = by shape
 extern "C" int mdqe_debug_gemm_variant(int v) { g_gemm_variant = v; return MDQE_OK; }
 
-static int g_gemm_precision = 0;      // 0: exact fp32 MFMA; 1: f16x3 split on the 128-row tiles (gemm_f16x3.hip)
+static int g_gemm_precision_all = 0;  // 0: exact fp32 MFMA; 1: f16x3 split on the 128-row tiles (gemm_f16x3.hip) -- process-wide
+// The calling THREAD's override (-1 = none): a region of the model (the reference's autocast regions, engine.Engine.amp) switches
+// the mode for its own launches without changing what another host thread -- the sharded schedule's tracker replay -- launches
+// meanwhile.  Every reader below goes through the macro.
+static thread_local int tl_gemm_precision = -1;
+#define g_gemm_precision (tl_gemm_precision >= 0 ? tl_gemm_precision : g_gemm_precision_all)
 extern "C" int mdqe_set_gemm_precision(int mode) {
   if (mode != 0 && mode != 1) return MDQE_EINVAL;
-  g_gemm_precision = mode;
+  g_gemm_precision_all = mode;
+  return MDQE_OK;
+}
+extern "C" int mdqe_set_gemm_precision_thread(int mode) {
+  if (mode != -1 && mode != 0 && mode != 1) return MDQE_EINVAL;
+  tl_gemm_precision = mode;
   return MDQE_OK;
 }
 extern "C" int mdqe_get_gemm_precision(void) { return g_gemm_precision; }

@@ -15,6 +15,7 @@ path runs in libmdqe_hip.so (ops.*): torch supplies memory, streams and the host
 (numpy index arrays, the two host syncs of a decoder batch).  What is left on torch device ops is
 listed in DESIGN.md §4.
 """
+import contextlib
 import math
 import os
 from types import SimpleNamespace as NS
@@ -384,6 +385,17 @@ class Engine:
         self.dev = self.P.dev
         self.backbone_fn = backbone_fn           # optional callable(frames [NI,3,h,w], geo) -> list of NHWC feats
         self._geo = {}
+        # "reference": the GEMMs / convs of the regions that the reference's harness runs in fp16 under autocast on a GPU (train_net.py:207;
+        # backbone, input_proj convs, rpn_cls_embed / track_embed / cls_embed / mask_embed MLPs, MaskHead) take the f16x3
+        # split-precision kernels (operand error 2^-21, fp32 accumulate, fp32 in / out: ~2000x finer than that fp16), everything the
+        # reference forces to fp32 (encoder, decoder, both MSDA forms) stays exact fp32.  "" (default): exact fp32 everywhere.
+        self.precision_map = os.environ.get("MDQE_PRECISION_MAP", "")
+
+    def amp(self):
+        """Context for one of the reference's autocast regions (see `precision_map`)."""
+        if self.precision_map == "reference" and self.dev.type == "cuda":
+            return ops.gemm_precision("f16x3")
+        return contextlib.nullcontext()
 
     def geometry(self, h, w) -> Geometry:
         """Per-resolution constants, least-recently-used cache (GEO_CACHE entries: an eval set has a few dozen frame sizes and
@@ -404,8 +416,10 @@ class Engine:
         (STRIDE_IN_1X1 False, FrozenBN folded; configs/R50_coco.yaml:7-10)."""
         if self.backbone_fn is not None:
             return self.backbone_fn(frames, geo)
-        if self.P.swin is not None:
-            return self.backbone_swin(frames, geo)
+        with self.amp():
+            return self.backbone_swin(frames, geo) if self.P.swin is not None else self._backbone_r50(frames, geo)
+
+    def _backbone_r50(self, frames, geo):
         bb, cfg = self.P.bb, self.cfg
         NI = frames.shape[0]
         if STEM_FUSED:
@@ -494,13 +508,14 @@ class Engine:
         src = None
         for l in range(cfg.n_levels):
             ip = P.inproj[l]
-            if l < len(feats):
-                f = feats[l]
-                y = ops.linear(f.reshape(-1, f.shape[-1]), ip.w.view(C, -1), ip.b)
-            else:
-                src = feats[-1] if l == len(feats) else src
-                y = ops.conv2d_nhwc(src, ip.w, ip.b, 2, 1)
-                src = None                      # deeper extra levels would chain on the normalised output
+            with self.amp():                    # (input_proj's convs sit outside the encoder's forced-fp32 region)
+                if l < len(feats):
+                    f = feats[l]
+                    y = ops.linear(f.reshape(-1, f.shape[-1]), ip.w.view(C, -1), ip.b)
+                else:
+                    src = feats[-1] if l == len(feats) else src
+                    y = ops.conv2d_nhwc(src, ip.w, ip.b, 2, 1)
+                    src = None                  # deeper extra levels would chain on the normalised output
             s0, hw = geo.starts[l], geo.hw[l]
             ops.groupnorm_nhwc(y.view(NI, hw, C), 32, ip.g, ip.beta, out=x[:, s0:s0 + hw])
         M, nh = NI * N, cfg.nheads
@@ -532,6 +547,10 @@ class Engine:
     # ---- a10: mask-feature head -------------------------------------------------------------------
     def mask_features(self, enc, geo):
         """models/mdqe.py:107-117 + segmentation.py:42-63 -> [NI, Hm, Wm, M] (channels-last)."""
+        with self.amp():
+            return self._mask_features(enc, geo)
+
+    def _mask_features(self, enc, geo):
         mh, cfg = self.P.mh, self.cfg
         NI, N, C = enc.shape
         lv = [enc[:, geo.starts[l]:geo.starts[l] + geo.hw[l]].view(NI, geo.shapes[l][0], geo.shapes[l][1], C) for l in range(3)]
@@ -564,10 +583,12 @@ class Engine:
         NI, N, C = enc.shape
         H, W = geo.shapes[0]
         nb = cfg.n_bins
-        conf = self._mlp(enc[:, :H * W].reshape(-1, C), self.P.rpn_cls).view(NI, H, W, -1)
+        with self.amp():
+            conf = self._mlp(enc[:, :H * W].reshape(-1, C), self.P.rpn_cls).view(NI, H, W, -1)
         coords = ops.query_select(conf, nb)                      # sigmoid-max, bilinear resize, per-cell first argmax
         content = ops.sample_levels_mean(enc, coords, geo.shapes, geo.starts)               # [NI,Q,C]
-        emb = self._mlp(content.view(-1, C), self.P.track_embed).view(NI, nb * nb, -1)
+        with self.amp():
+            emb = self._mlp(content.view(-1, C), self.P.track_embed).view(NI, nb * nb, -1)
         return coords, content, emb
 
     def dec_values(self, enc, geo, out=None):
@@ -724,9 +745,10 @@ class Engine:
             main.wait_stream(side)                      # (x_inst lives in the side stream's pool; the next call's side work starts behind
             del hold                                    #  `side.wait_stream(main)` above, i.e. behind everything that reads it on main)
         n = ops.layernorm(x_inst, *P.dec_norm)
-        return {"cls": self._mlp(n, P.cls_embed, "sigmoid").view(Bc, Q, -1),
-                "mask_coeff": self._mlp(n, P.mask_embed, "tanh").view(Bc, Q, -1),
-                "query_embed": x_inst.view(Bc, Q, C)}
+        with self.amp():
+            return {"cls": self._mlp(n, P.cls_embed, "sigmoid").view(Bc, Q, -1),
+                    "mask_coeff": self._mlp(n, P.mask_embed, "tanh").view(Bc, Q, -1),
+                    "query_embed": x_inst.view(Bc, Q, C)}
 
     # ---- a15: inference_clip (mdqe/mdqe.py:368-428), batched over clips ---------------------------
     def inference_clip(self, out, mask_feats):

@@ -117,6 +117,18 @@ class MDQE(nn.Module):
                 self._engine = Engine(self.cfg, sd, self.device, backbone_fn=self._backbone_fn)
         return self._engine
 
+    @property
+    def precision_map(self):
+        """"" = exact fp32 everywhere (default); "reference" = the reference harness's own precision map on a GPU with its fp16 regions on the
+        f16x3 split-precision kernels (engine.Engine.precision_map; env MDQE_PRECISION_MAP)."""
+        return self.engine.precision_map
+
+    @precision_map.setter
+    def precision_map(self, v):
+        if v not in ("", "reference"):
+            raise ValueError("precision_map: '' or 'reference'")
+        self.engine.precision_map = v
+
     # ---- forward (mdqe/mdqe.py:194-242) ------------------------------------------------------------
     def _make_streams(self):
         """The pipeline's normal-priority streams, created TOGETHER and in a fixed order (copy, frame, tracker) the first time the model

@@ -3,7 +3,9 @@
 All tensors are CUDA fp32 contiguous unless stated; images are NHWC.  Nothing here falls back to
 torch arithmetic: a missing library or an unsupported shape raises.
 """
+import contextlib
 import os
+import threading
 
 import torch
 
@@ -38,7 +40,26 @@ def set_gemm_precision(mode):
 
 
 def get_gemm_precision():
+    """The mode this thread's launches use (its `gemm_precision` region if inside one, else the process-wide mode)."""
     return {0: "f32", 1: "f16x3"}[lib.mdqe_get_gemm_precision()]
+
+
+_tl_prec = threading.local()
+
+
+@contextlib.contextmanager
+def gemm_precision(mode):
+    """`with gemm_precision("f16x3"):` -- the GEMM mode of the CALLING thread's launches inside the block (C ABI
+    mdqe_set_gemm_precision_thread); nests; other host threads and the process-wide mode are untouched."""
+    prev = getattr(_tl_prec, "v", -1)
+    cur = {"f32": 0, "f16x3": 1}[mode]
+    check(lib.mdqe_set_gemm_precision_thread(cur), "set_gemm_precision_thread")
+    _tl_prec.v = cur
+    try:
+        yield
+    finally:
+        check(lib.mdqe_set_gemm_precision_thread(prev), "set_gemm_precision_thread")
+        _tl_prec.v = prev
 
 
 # ---- constant weights: pre-split f16 planes for the f16x3 mode (gemm_f16x3w.hip) ---------------------

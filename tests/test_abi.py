@@ -43,3 +43,37 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 s = open(os.path.join(dp, f)).read()
                 assert "mdqe_oracle" not in s and "import oracle" not in s and "from oracle" not in s, f
+
+
+def test_gemm_precision_override_is_per_thread():
+    """`ops.gemm_precision(...)` (C ABI mdqe_set_gemm_precision_thread) changes the mode of the CALLING thread's launches only, nests and
+    restores; the process-wide mode is what a thread without an override sees (no GPU needed: the mode is host state)."""
+    import threading
+    from mdqe_cvpr2023_amd import _lib, ops
+    h = _lib.load_library()
+    assert h.mdqe_set_gemm_precision_thread(2) != 0 and h.mdqe_set_gemm_precision_thread(-2) != 0       # EINVAL, nothing changed
+    assert ops.get_gemm_precision() == "f32"
+    seen = {}
+
+    def other():
+        seen["other"] = ops.get_gemm_precision()
+
+    with ops.gemm_precision("f16x3"):
+        assert ops.get_gemm_precision() == "f16x3"
+        t = threading.Thread(target=other); t.start(); t.join()
+        with ops.gemm_precision("f32"):
+            assert ops.get_gemm_precision() == "f32"
+        assert ops.get_gemm_precision() == "f16x3"
+        with pytest.raises(RuntimeError):
+            with ops.gemm_precision("f32"):
+                raise RuntimeError("boom")
+        assert ops.get_gemm_precision() == "f16x3"                # restored on the way out of a failing block too
+    assert ops.get_gemm_precision() == "f32" and seen["other"] == "f32"
+    ops.set_gemm_precision("f16x3")
+    try:
+        with ops.gemm_precision("f32"):
+            assert ops.get_gemm_precision() == "f32"
+            t = threading.Thread(target=other); t.start(); t.join()
+        assert seen["other"] == "f16x3" and ops.get_gemm_precision() == "f16x3"
+    finally:
+        ops.set_gemm_precision("f32")

@@ -216,6 +216,28 @@ def test_r50_ovis_360_full_size_end_to_end(gemm_precision):
     _direct(ref, model, 360, 640)
 
 
+def test_r50_ovis_360_full_size_reference_precision_map():
+    """`precision_map = "reference"`: the regions the reference's harness runs under fp16 autocast on a GPU (backbone, input_proj, the
+    embed MLPs, the mask head) on the f16x3 split-precision kernels, the forced-fp32 regions exact -- frames -> boolean masks
+    against the fp32 CPU oracle under the same 1e-3 bars, and the regions really switch kernels (the thread-scoped mode is visible inside
+    an autocast region only)."""
+    from mdqe_cvpr2023_amd import ops
+    ref = _workload("R50_ovis_360", 360, 640, 6, 4)
+    model = _model(ref)
+    model.engine.precision_map = "reference"
+    assert ops.get_gemm_precision() == "f32"
+    with model.engine.amp():
+        assert ops.get_gemm_precision() == "f16x3"
+    assert ops.get_gemm_precision() == "f32"
+    GROUP["name"] = "R50_ovis_360 6x360x640 reference precision map direct"
+    out = _direct(ref, model, 360, 640)
+    model.engine.precision_map = ""
+    with torch.no_grad():
+        exact = model.inference_vis([{"image": ref["frames"], "height": 360, "width": 640}])
+    assert out["pred_labels"] == exact["pred_labels"]
+    assert out["pred_scores"] != exact["pred_scores"]            # a different arithmetic ran (not a silently ignored switch)
+
+
 def test_r50_ovis_720_geometry_full_size(gemm_precision):
     """configs/R50_ovis_720.yaml geometry: 640x1138 -> 640x1152, N=15300; 3 frames (one short clip -> last-frame repeat in the
     temporal attention, transformer_dec.py:382-386), APPLY_CLS_THRES 0.2, MERGE_ON_CPU both ways."""
