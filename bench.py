@@ -814,7 +814,12 @@ def main():
             line["clip_stage"] = clip_stage
         line.update(extra)
         if not sharded and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
+            if args.config == "R50_ovis_360":
+                line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
+            else:
+                # the CPU leg is BASELINE.json's configs[0] -- R50_ovis_360, 4 frames on the host cores -- and is quoted on the metric's
+                # config only (the oracle's Swin-L / 640p passes take minutes per frame on a CPU)
+                line["cpu_baseline"] = None
 
     # N > 1: the halo-exchange form of the same job as an extra key of the same line, so that one multi-GPU run decides the default.
     # It has never run over RCCL with more than one rank, so it runs LAST and under a soft deadline: if it has not finished in time,
