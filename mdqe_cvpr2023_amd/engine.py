@@ -390,6 +390,8 @@ class Engine:
         # split-precision kernels (operand error 2^-21, fp32 accumulate, fp32 in / out: ~2000x finer than that fp16), everything the
         # reference forces to fp32 (encoder, decoder, both MSDA forms) stays exact fp32.  "" (default): exact fp32 everywhere.
         self.precision_map = os.environ.get("MDQE_PRECISION_MAP", "")
+        if self.precision_map not in ("", "reference"):
+            raise ValueError("MDQE_PRECISION_MAP: '' (exact fp32 everywhere) or 'reference', not %r" % self.precision_map)
 
     def amp(self):
         """Context for one of the reference's autocast regions (see `precision_map`)."""
