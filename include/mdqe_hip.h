@@ -160,6 +160,7 @@ int mdqe_debug_gemm_stamps(void* buf);
 int mdqe_debug_gemm_variant(int v);
 int mdqe_debug_gemm_tile_rule(int v); /* auto tile rule variants (tools/ A/B); 0 = default */
 int mdqe_debug_gemm_rows_dot(int v); /* products with N <= 8 columns: 1 (default) = rows_dot_kernel, 0 = MFMA tiles */
+int mdqe_debug_gemm_fast_epilogue(int v); /* K-step-16 kernel (tools/ A/B): 1 (default) = interior tiles of plain products take the few-instruction epilogue, 0 = the general one */
 int mdqe_debug_gemm_stagger(int v);  /* K-step-16 kernel: start offset between the blocks of a CU's first round, 10-ns ticks; 0 = off */
 int mdqe_debug_gemm_stages(int v);   /* K-step-16 kernel, 64x64 and smaller tiles: LDS stages 2 / 4; 0 = by grid size (default) */
 int mdqe_debug_msda_dec_stage_kb(int kb);   /* tools/ only: LDS staging budget of the decoder's box-level deformable launch (default 72: two blocks per CU) */

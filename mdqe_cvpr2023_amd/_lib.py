@@ -65,6 +65,7 @@ SIGNATURES = {
     "mdqe_debug_gemm_tile_rule": [i],
     "mdqe_debug_gemm_rows_dot": [i],
     "mdqe_debug_gemm_stagger": [i],
+    "mdqe_debug_gemm_fast_epilogue": [i],
     "mdqe_debug_gemm_stages": [i],
     "mdqe_debug_gemm_lds_pad": [i],
     "mdqe_debug_trk_siou_blocks": [i],

@@ -17,6 +17,9 @@
 // [5292,256]x[256,256] product) and measured at no gain, so it stays behind mdqe_debug_gemm_stages(4).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// tools/ A/B: mdqe_debug_gemm_fast_epilogue(0) sends every tile through the general epilogue (GemmParams::fast_epi)
+__device__ __forceinline__ bool g_k16_fast_epilogue_on(const GemmParams& p) { return p.fast_epi != 0; }
+
 template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false, int NS = 2, bool CAT = false>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN > 4) ? 2 : 4)
 gemm_nt_f32_k16_kernel(const GemmParams p) {
@@ -348,6 +351,113 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   __syncthreads();                                   // every wave is done reading the last K-step
   float* sC = lds + wave * 1024;
   const bool vec = p.vec_ok;
+
+  // ---- fast path (round 4): an interior tile of a plain product -- bias, none / ReLU / GELU on every column, optional full residual.
+  // The f32 MFMA runs at the vector rate on the SIMD's own lanes: while the three other waves of a SIMD are in their K loops, a wave
+  // in its epilogue gets a vector issue slot about once per MFMA (in-kernel stamps: 30 us for the ~2000 vector instructions of the
+  // general epilogue below, 16 K-steps take 46), and every vector instruction it does issue is matrix time lost.  So this path
+  // spends as few as it can: the C / residual addresses are ONE per-lane byte offset into a buffer resource + a scalar offset per
+  // (sub-tile, trip) -- no per-store address arithmetic, no bounds compares (the tile is interior), no masks, no side term; the
+  // residual rows of the NEXT sub-tile are requested before this sub-tile's stores (vmcnt retires loads and stores in issue order:
+  // a load issued behind a store cannot be waited for without waiting for that store's acknowledgement).  Same arithmetic per
+  // element as the general path (which edge tiles of the same launch take): equal bits.
+  if constexpr (!LN) {
+    const long c_bytes = (long)p.M * p.ldc * 4, r_bytes = p.residual != nullptr ? (long)p.M * p.ldr * 4 : 0;
+    const bool fast = vec && p.ksplit <= 1 && p.side == nullptr && p.rowmask == nullptr && p.res_mod <= 0 && p.act_cols <= 0 &&
+                      (p.act == MDQE_ACT_NONE || p.act == MDQE_ACT_RELU || p.act == MDQE_ACT_GELU) && m0 + BM <= p.M && n0 + BN <= p.N &&
+                      c_bytes < (1L << 31) && r_bytes < (1L << 31) && g_k16_fast_epilogue_on(p);
+    if (fast) {
+      const int c4 = lane & 7, r8 = lane >> 3;
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)c_bytes, 0x00020000);
+      const auto rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual != nullptr ? p.residual : p.C), 0, (int)(p.residual != nullptr ? r_bytes : c_bytes), 0x00020000);
+      const int row0 = m0 + wm * (BM / WM), col0 = n0 + wn * (BN / WN);
+      const unsigned vC = (unsigned)((r8 * p.ldc + c4 * 4) * 4), vR = (unsigned)((r8 * p.ldr + c4 * 4) * 4);
+      const bool has_res = p.residual != nullptr, has_bias = p.bias != nullptr;
+      f32x4 bj[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bj[j] = has_bias ? *reinterpret_cast<const f32x4*>(p.bias + col0 + j * 32 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      auto load_res = [&](int i, int j, f32x4 (&r)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int so = (int)((((long)row0 + i * 32 + it * 8) * p.ldr + col0 + j * 32) * 4);
+          r[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vR, so, 0));
+        }
+      };
+      // one specialised copy per (activation, residual, bias) combination that the per-frame stages use, chosen by a UNIFORM branch:
+      // a select between "with" and "without" costs vector instructions on every value, a branch around the other copies none
+      auto run = [&](auto act_, auto res_, auto bias_) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_)::value;
+        constexpr bool RES = decltype(res_)::value, BIAS = decltype(bias_)::value;
+        f32x4 rbuf[2][4];
+        if constexpr (RES) load_res(0, 0, rbuf[0]);
+        auto fsub = [&](auto i_, auto j_, auto s_) __attribute__((always_inline)) {
+          constexpr int i = decltype(i_)::value, j = decltype(j_)::value, sidx = decltype(s_)::value;
+          constexpr int nsub = MT * NT;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[i][j][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          f32x4 v[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(sC + (it * 8 + r8) * 32 + c4 * 4);
+          if constexpr (RES && sidx + 1 < nsub) {        // the next sub-tile's residual rows, BEFORE this one's stores
+            constexpr int s1 = sidx + 1;
+            constexpr int i1 = (NT > 1) ? s1 / NT : s1, j1 = (NT > 1) ? s1 % NT : 0;
+            load_res(i1, j1, rbuf[s1 & 1]);
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            f32x4 x = v[it];
+            if constexpr (BIAS) x += bj[j];
+            if constexpr (RES) { if (p.res_first) x += rbuf[sidx & 1][it]; }
+            if constexpr (ACT == MDQE_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) x[e] = x[e] > 0.f ? x[e] : 0.f;
+            } else if constexpr (ACT == MDQE_ACT_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) x[e] = mdqe_gelu(x[e]);
+            }
+            if constexpr (RES) { if (!p.res_first) x += rbuf[sidx & 1][it]; }
+            const int so = (int)((((long)row0 + i * 32 + it * 8) * p.ldc + col0 + j * 32) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, x), rsC, vC, so, 0);
+            // The next trip's first vector instruction may write the registers this 16-byte store is still reading (hipcc 7.2 places a
+            // v_pk_add_f32 into v[26:27] directly behind `buffer_store_dwordx4 v[26:29] ... s8 offen` and inserts no wait state --
+            // its hazard table exempts stores with an SGPR offset; on gfx950 the second register of the store then carries the NEW
+            // value in lanes 12-15 of every 16).  Two wait states, fenced so that nothing is scheduled into them.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 1" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        };
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+        using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+        if constexpr (MT == 1 && NT == 1) { fsub(J0{}, J0{}, J0{}); }
+        else if constexpr (MT == 1 && NT == 2) { fsub(J0{}, J0{}, J0{}); fsub(J0{}, J1{}, J1{}); }
+        else if constexpr (MT == 2 && NT == 1) { fsub(J0{}, J0{}, J0{}); fsub(J1{}, J0{}, J1{}); }
+        else { fsub(J0{}, J0{}, J0{}); fsub(J0{}, J1{}, J1{}); fsub(J1{}, J0{}, J2{}); fsub(J1{}, J1{}, J3{}); }
+      };
+      using AN = std::integral_constant<int, MDQE_ACT_NONE>; using AR = std::integral_constant<int, MDQE_ACT_RELU>;
+      using AG = std::integral_constant<int, MDQE_ACT_GELU>;
+      using T = std::true_type; using F = std::false_type;
+      // (the combinations of the per-frame stages: bias always; ReLU with / without residual -- ResNet; GELU without -- FFN1;
+      // none with / without -- projections.  Anything else takes the general path below.)
+      bool done = true;
+      if (!has_bias) done = false;
+      else if (p.act == MDQE_ACT_RELU) { if (has_res) run(AR{}, T{}, T{}); else run(AR{}, F{}, T{}); }
+      else if (p.act == MDQE_ACT_GELU) { if (has_res) done = false; else run(AG{}, F{}, T{}); }
+      else { if (has_res) run(AN{}, T{}, T{}); else run(AN{}, F{}, T{}); }
+      if (done) {
+        if (p.stamps && tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned long long* o = p.stamps + (long)blockIdx.x * 4;
+          o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = wall_clock64();
+        }
+        return;
+      }
+    }
+  }
   auto sub = [&](auto i_, auto j_) __attribute__((always_inline)) {
       constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
 #pragma unroll
@@ -430,6 +540,8 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   }
 }
 
+static int g_k16_fast_epi = 1;     // tools/ A/B: 0 = every tile through the general epilogue
+extern "C" int mdqe_debug_gemm_fast_epilogue(int v) { g_k16_fast_epi = v ? 1 : 0; return MDQE_OK; }
 static int g_k16_stagger = 0;      // tools/ A/B: first-round start offset between the blocks of a CU, in 10-ns ticks
 extern "C" int mdqe_debug_gemm_stagger(int v) { g_k16_stagger = v; return MDQE_OK; }
 static int g_k16_lds_pad = 0;      // tools/ A/B: extra dynamic LDS bytes per block (caps the blocks per CU: occupancy experiments)
@@ -441,6 +553,7 @@ template <int BM, int BN, int WM, int WN, bool CONV, bool LN, int NS, bool CAT =
 static int launch_k16_ns_(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
   p.stagger = g_k16_stagger;
+  p.fast_epi = g_k16_fast_epi;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   size_t smem = (size_t)NS * (BM + BN) * 16 * sizeof(float);
   if (smem < (size_t)WM * WN * 4096) smem = (size_t)WM * WN * 4096;        // per-wave epilogue slices

@@ -35,6 +35,7 @@ struct GemmParams {
   // m-th row of its window partition after zero padding to multiples of swin_ws and the cyclic shift (swin_transformer_v2.py:236-262):
   // the row's source pixel is computed once per block, a padded position reads zeros -- the partitioned copy is never materialised
   int swin_ws, swin_shift, swin_H, swin_W;
+  int fast_epi;             // K-step-16 kernel: 1 (default) = interior tiles of plain products take the few-instruction epilogue
   int stagger;              // K-step-16 kernel: the first resident round of blocks starts (slot on the CU) x stagger 10-ns ticks late (0: off)
 };
 
