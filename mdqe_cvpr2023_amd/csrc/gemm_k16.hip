@@ -362,14 +362,26 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   // a load issued behind a store cannot be waited for without waiting for that store's acknowledgement).  Same arithmetic per
   // element as the general path (which edge tiles of the same launch take): equal bits.
   if constexpr (!LN) {
-    const long c_bytes = (long)p.M * p.ldc * 4, r_bytes = p.residual != nullptr ? (long)p.M * p.ldr * 4 : 0;
-    const bool fast = vec && p.ksplit <= 1 && p.side == nullptr && p.rowmask == nullptr && p.res_mod <= 0 && p.act_cols <= 0 &&
-                      (p.act == MDQE_ACT_NONE || p.act == MDQE_ACT_RELU || p.act == MDQE_ACT_GELU) && m0 + BM <= p.M && n0 + BN <= p.N &&
-                      c_bytes < (1L << 31) && r_bytes < (1L << 31) && g_k16_fast_epilogue_on(p);
+    // a residual that repeats every res_mod rows (the encoder's position table): its row is m % res_mod -- a uniform shift of the
+    // tile's rows unless the tile straddles a period (1 tile in 40 at 360p: general path)
+    const int rshift = p.res_mod > 0 ? m0 - m0 % p.res_mod : 0;
+    const long res_rows = p.res_mod > 0 ? p.res_mod : p.M;
+    const long c_bytes = (long)p.M * p.ldc * 4, r_bytes = p.residual != nullptr ? res_rows * p.ldr * 4 : 0;
+    bool fast = vec && p.ksplit <= 1 && p.side == nullptr && p.act_cols <= 0 &&
+                (p.res_mod <= 0 || (p.residual != nullptr && m0 - rshift + BM <= p.res_mod)) &&
+                (p.act == MDQE_ACT_NONE || p.act == MDQE_ACT_RELU || p.act == MDQE_ACT_GELU) && m0 + BM <= p.M && n0 + BN <= p.N &&
+                c_bytes < 0xFFFF0000L && r_bytes < 0xFFFF0000L && g_k16_fast_epilogue_on(p);      // (buffer offsets are unsigned 32-bit)
+    if (fast && p.rowmask != nullptr) {
+      // masked rows (padding tokens, ~6 % of the rows at 360p): the decision is per WAVE -- nothing below is block-wide -- so a wave
+      // whose 32 / 64 rows hold none takes the fast path and the others the general one
+      constexpr int WR = BM / WM;
+      const bool mrow = lane < WR && p.rowmask[m0 + wm * WR + lane] != 0;
+      fast = __builtin_amdgcn_ballot_w64(mrow) == 0;
+    }
     if (fast) {
       const int c4 = lane & 7, r8 = lane >> 3;
-      const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)c_bytes, 0x00020000);
-      const auto rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual != nullptr ? p.residual : p.C), 0, (int)(p.residual != nullptr ? r_bytes : c_bytes), 0x00020000);
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)(unsigned)c_bytes, 0x00020000);
+      const auto rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual != nullptr ? p.residual : p.C), 0, (int)(unsigned)(p.residual != nullptr ? r_bytes : c_bytes), 0x00020000);
       const int row0 = m0 + wm * (BM / WM), col0 = n0 + wn * (BN / WN);
       const unsigned vC = (unsigned)((r8 * p.ldc + c4 * 4) * 4), vR = (unsigned)((r8 * p.ldr + c4 * 4) * 4);
       const bool has_res = p.residual != nullptr, has_bias = p.bias != nullptr;
@@ -379,7 +391,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
       auto load_res = [&](int i, int j, f32x4 (&r)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int so = (int)((((long)row0 + i * 32 + it * 8) * p.ldr + col0 + j * 32) * 4);
+          const int so = (int)((((long)row0 - rshift + i * 32 + it * 8) * p.ldr + col0 + j * 32) * 4);
           r[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vR, so, 0));
         }
       };
@@ -397,9 +409,6 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[i][j][r];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_wave_barrier();
-          f32x4 v[4];
-#pragma unroll
-          for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(sC + (it * 8 + r8) * 32 + c4 * 4);
           if constexpr (RES && sidx + 1 < nsub) {        // the next sub-tile's residual rows, BEFORE this one's stores
             constexpr int s1 = sidx + 1;
             constexpr int i1 = (NT > 1) ? s1 / NT : s1, j1 = (NT > 1) ? s1 % NT : 0;
@@ -407,7 +416,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
           }
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            f32x4 x = v[it];
+            f32x4 x = *reinterpret_cast<const f32x4*>(sC + (it * 8 + r8) * 32 + c4 * 4);
             if constexpr (BIAS) x += bj[j];
             if constexpr (RES) { if (p.res_first) x += rbuf[sidx & 1][it]; }
             if constexpr (ACT == MDQE_ACT_RELU) {
