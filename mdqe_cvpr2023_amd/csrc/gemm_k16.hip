@@ -113,9 +113,9 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   int t_kh = 0, t_kw = 0, t_c = 0;                 // conv: filter tap of the K-step about to be issued (Cin % 16 == 0)
   if (CONV) { const int tap = kbeg / p.Cin; t_c = kbeg - tap * p.Cin; t_kh = tap / p.KW; t_kw = tap - t_kh * p.KW; }
 
-  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+  auto issue_impl = [&](int kt, int buf, auto tail_) __attribute__((always_inline)) {
+    constexpr bool ktail = decltype(tail_)::value;   // the last K-step of a ragged K checks lanes against K
     const int k0 = kt * BK;
-    const bool ktail = k0 + BK > p.K;              // only the last K-step of a ragged K checks lanes against K
     float* base = lds + buf * (ROWS * BK);
     int tap_off = 0;
     if (CONV) tap_off = ((t_kh * p.Wd + t_kw) * p.Cin + t_c) * 4;
@@ -144,6 +144,14 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
     }
     if (CONV) { t_c += BK; if (t_c >= p.Cin) { t_c = 0; if (++t_kw == p.KW) { t_kw = 0; ++t_kh; } } }
   };
+  // Two copies behind a UNIFORM branch: folded into one, the ragged-K check is a compare + select per LDS-DMA address in EVERY step,
+  // and every vector instruction of this loop is matrix-pipe time (the f32 MFMA runs at the vector rate).  The empty asm keeps the
+  // optimiser from merging the copies back.
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    if constexpr (CONV) { issue_impl(kt, buf, std::false_type{}); }          // (Cin % 16 == 0: a conv's K is never ragged)
+    else if (kt * BK + BK > p.K) { asm volatile("; ragged last K-step" ::: "memory"); issue_impl(kt, buf, std::true_type{}); }
+    else issue_impl(kt, buf, std::false_type{});
+  };
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -159,11 +167,55 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
   for (int i = 0; i < MT; ++i) { const int row = wm * (BM / WM) + i * 32 + lr; fa[i] = row * BK + ((lh ^ ((row >> 2) & 3)) << 2); }
 #pragma unroll
   for (int j = 0; j < NT; ++j) { const int row = BM + wn * (BN / WN) + j * 32 + lr; fb[j] = row * BK + ((lh ^ ((row >> 2) & 3)) << 2); }
+  int fa1[MT], fb1[NT];                            // the second 8-wide half of a K-step (chunk bit 1 flipped)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) fa1[i] = fa[i] ^ 8;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb1[j] = fb[j] ^ 8;
 
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) issue(kt0 + s, s);
   if (p.stamps) t_pro = wall_clock64();
+  // One K-step on LDS stage S (compile-time: the fragment reads of a stage are then `base register + immediate`, where a run-time
+  // stage costs one vector add per fragment address per step).
+  auto kstep2 = [&](int kt, auto S_) __attribute__((always_inline)) {
+    constexpr int S = decltype(S_)::value;
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt0 + kt + 1, S ^ 1);
+    const float* sI = lds + S * (ROWS * BK);
+    f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(sI + fa[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b0[j] = *reinterpret_cast<const f32x4*>(sI + fb[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const f32x4*>(sI + fa1[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b1[j] = *reinterpret_cast<const f32x4*>(sI + fb1[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][s], b0[j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][s], b1[j][s], acc[i][j], 0, 0, 0);
+  };
+  if constexpr (NS == 2) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      kstep2(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 < nk) kstep2(kt + 1, std::integral_constant<int, 1>{});
+    }
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's LDS-DMA for step kt has landed: at most the loads of the stages issued after it may still be in flight
     if constexpr (NS == 2) {
