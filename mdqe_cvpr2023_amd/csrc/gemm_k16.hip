@@ -419,7 +419,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
     const int rshift = p.res_mod > 0 ? m0 - m0 % p.res_mod : 0;
     const long res_rows = p.res_mod > 0 ? p.res_mod : p.M;
     const long c_bytes = (long)p.M * p.ldc * 4, r_bytes = p.residual != nullptr ? res_rows * p.ldr * 4 : 0;
-    bool fast = vec && p.ksplit <= 1 && p.side == nullptr && p.act_cols <= 0 &&
+    bool fast = vec && p.ksplit <= 1 && (p.side == nullptr || (MT * NT == 1 && p.act == MDQE_ACT_NONE && p.residual == nullptr && p.side_cols % 4 == 0)) && p.act_cols <= 0 &&
                 (p.res_mod <= 0 || (p.residual != nullptr && m0 - rshift + BM <= p.res_mod)) &&
                 (p.act == MDQE_ACT_NONE || p.act == MDQE_ACT_RELU || p.act == MDQE_ACT_GELU) && m0 + BM <= p.M && n0 + BN <= p.N &&
                 c_bytes < 0xFFFF0000L && r_bytes < 0xFFFF0000L && g_k16_fast_epilogue_on(p);      // (buffer offsets are unsigned 32-bit)
@@ -449,11 +449,21 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
       };
       // one specialised copy per (activation, residual, bias) combination that the per-frame stages use, chosen by a UNIFORM branch:
       // a select between "with" and "without" costs vector instructions on every value, a branch around the other copies none
-      auto run = [&](auto act_, auto res_, auto bias_) __attribute__((always_inline)) {
+      auto run = [&](auto act_, auto res_, auto bias_, auto side_) __attribute__((always_inline)) {
         constexpr int ACT = decltype(act_)::value;
-        constexpr bool RES = decltype(res_)::value, BIAS = decltype(bias_)::value;
+        constexpr bool RES = decltype(res_)::value, BIAS = decltype(bias_)::value, SIDE = decltype(side_)::value;
         f32x4 rbuf[2][4];
         if constexpr (RES) load_res(0, 0, rbuf[0]);
+        // rank-4 side term (the decoder's position embeddings folded into the q / k / offset products): the wave's 64 / 32 side rows
+        // [row, 4] are requested up front, one per (sub-tile row block, trip); a lane's 4 columns' side weights once per column block
+        f32x4 srow[SIDE ? MT : 1][4];
+        if constexpr (SIDE) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+              srow[i][it] = *reinterpret_cast<const f32x4*>(p.side + (long)(row0 + i * 32 + it * 8 + r8) * 4);
+        }
         auto fsub = [&](auto i_, auto j_, auto s_) __attribute__((always_inline)) {
           constexpr int i = decltype(i_)::value, j = decltype(j_)::value, sidx = decltype(s_)::value;
           constexpr int nsub = MT * NT;
@@ -466,10 +476,25 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
             constexpr int i1 = (NT > 1) ? s1 / NT : s1, j1 = (NT > 1) ? s1 % NT : 0;
             load_res(i1, j1, rbuf[s1 & 1]);
           }
+          f32x4 sw[SIDE ? 4 : 1];
+          bool sidecol = false;
+          if constexpr (SIDE) {
+            sidecol = col0 + j * 32 + c4 * 4 < p.side_cols;          // (side_cols % 4 == 0: a lane's 4 columns together)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              sw[e] = sidecol ? *reinterpret_cast<const f32x4*>(p.side_w + (long)(col0 + j * 32 + c4 * 4 + e) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             f32x4 x = *reinterpret_cast<const f32x4*>(sC + (it * 8 + r8) * 32 + c4 * 4);
             if constexpr (BIAS) x += bj[j];
+            if constexpr (SIDE) {
+              if (sidecol) {
+                const f32x4 s4 = srow[i][it];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] += (s4[0] * sw[e][0] + s4[1] * sw[e][1]) + (s4[2] * sw[e][2] + s4[3] * sw[e][3]);
+              }
+            }
             if constexpr (RES) { if (p.res_first) x += rbuf[sidx & 1][it]; }
             if constexpr (ACT == MDQE_ACT_RELU) {
 #pragma unroll
@@ -506,9 +531,14 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
       // none with / without -- projections.  Anything else takes the general path below.)
       bool done = true;
       if (!has_bias) done = false;
-      else if (p.act == MDQE_ACT_RELU) { if (has_res) run(AR{}, T{}, T{}); else run(AR{}, F{}, T{}); }
-      else if (p.act == MDQE_ACT_GELU) { if (has_res) done = false; else run(AG{}, F{}, T{}); }
-      else { if (has_res) run(AN{}, T{}, T{}); else run(AN{}, F{}, T{}); }
+      else if (MT * NT == 1 && p.side != nullptr) {
+        // (tiles of ONE sub-tile per wave only -- what the decoder's 29 008-row products run on; the 128 x 128 tile has no
+        // registers to spare for the side rows)
+        if constexpr (MT * NT == 1) run(AN{}, F{}, T{}, T{});
+      }
+      else if (p.act == MDQE_ACT_RELU) { if (has_res) run(AR{}, T{}, T{}, F{}); else run(AR{}, F{}, T{}, F{}); }
+      else if (p.act == MDQE_ACT_GELU) { if (has_res) done = false; else run(AG{}, F{}, T{}, F{}); }
+      else { if (has_res) run(AN{}, T{}, T{}, F{}); else run(AN{}, F{}, T{}, F{}); }
       if (done) {
         if (p.stamps && tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
