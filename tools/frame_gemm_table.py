@@ -18,6 +18,8 @@ model = MDQE(cfg, state_dict=random_state(cfg, seed=0)).eval()
 video = synth_video(0, nfr, seed=0, h=fh, w=fw).cuda()
 rec = []
 L = _lib.load_library()
+if os.environ.get("GEMM_VARIANT"):                       # tools/ A/B: 1 = the K-step-16 kernel for every shape
+    L.mdqe_debug_gemm_variant(int(os.environ["GEMM_VARIANT"]))
 raw = {n: getattr(L, n) for n in ("mdqe_gemm_nt_f32", "mdqe_gemm_ln_f32", "mdqe_conv2d_nhwc_f32", "mdqe_gemm_nt_cat2_f32")}
 
 
