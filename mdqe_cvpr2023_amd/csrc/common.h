@@ -40,6 +40,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (Abramowitz-Stegun 7.1.26, |err(erf)| <= 1.5e-7), written so that the negative side is a plain product (no
 // cancellation).  Max |error| against the exact function 3.4e-7 over [-12, 12] -- below torch's own fp32 GELU rounding.
 __device__ __forceinline__ float mdqe_gelu(float x) {
+  // No contraction inside: inlined into two differently shaped epilogues of ONE launch (gemm_k16.hip: interior tiles / edge tiles), the
+  // optimiser fused `x - x * h` into an fma in one of them and not in the other -- 1 ulp, and a frame's bits then depend on which tile
+  // of a pass it falls into.  Every fma below is written out.
+#pragma clang fp contract(off)
   const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
   float q = __builtin_fmaf(t, 0.5307027145f, -0.7265760135f);

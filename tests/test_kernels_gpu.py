@@ -718,3 +718,13 @@ def test_temporal_msda_with_frame_by_frame_staging_equals_the_gather_form(shapes
         lib.mdqe_debug_msda_tp_staged(1)
     assert torch.isfinite(outs[0]).all() and not torch.equal(outs[0], torch.zeros_like(outs[0]))
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * float(outs[1].abs().max())
+
+
+def test_gemm_fast_and_general_epilogue_give_equal_bits():
+    """The K-step-16 GEMM sends interior tiles through a few-instruction epilogue and edge tiles / waves with masked rows through the
+    general one IN THE SAME LAUNCH: any difference between the two would make a frame's bits depend on the pass it shares (the sharded
+    bench's self-verification caught a 1-ulp GELU contraction difference in round 4).  Every form the fast path takes, on against off."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_epilogue_paths.py")], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "0 differing cases" in r.stdout
