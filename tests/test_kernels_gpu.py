@@ -724,7 +724,10 @@ def test_gemm_fast_and_general_epilogue_give_equal_bits():
     """The K-step-16 GEMM sends interior tiles through a few-instruction epilogue and edge tiles / waves with masked rows through the
     general one IN THE SAME LAUNCH: any difference between the two would make a frame's bits depend on the pass it shares (the sharded
     bench's self-verification caught a 1-ulp GELU contraction difference in round 4).  Every form the fast path takes, on against off."""
+    import os
     import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_epilogue_paths.py")], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "0 differing cases" in r.stdout
