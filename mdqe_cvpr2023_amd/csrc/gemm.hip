@@ -410,6 +410,8 @@ extern "C" int mdqe_gemm_ln_f32(const float* A, long lda, const float* W, const 
   MDQE_REQUIRE(residual == nullptr || (ldr >= N && ldr % 4 == 0));
   const long ab = ((long)(M - 1) * lda + K) * 4, wb = (long)N * K * 4;
   MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  // (the epilogue addresses C and the residual through 32-bit buffer offsets)
+  MDQE_REQUIRE((long)M * ldc * 4 < 0xFFFF0000L && (residual == nullptr || (long)M * ldr * 4 < 0xFFFF0000L));
   GemmParams p = {};
   p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.act = MDQE_ACT_NONE;
@@ -434,6 +436,7 @@ extern "C" int mdqe_gemm_ln2_f32(const float* A, long lda, const float* W, const
   MDQE_REQUIRE(residual == nullptr || (ldr >= N && ldr % 4 == 0));
   const long ab = ((long)(M - 1) * lda + K) * 4, wb = (long)N * K * 4;
   MDQE_REQUIRE(ab < 0xFFFFFFF0L && wb < 0xFFFFFFF0L);
+  MDQE_REQUIRE((long)M * ldc * 4 < 0xFFFF0000L && (long)M * ldc2 * 4 < 0xFFFF0000L && (residual == nullptr || (long)M * ldr * 4 < 0xFFFF0000L));
   GemmParams p = {};
   p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.conv = 0;
   p.bias = bias; p.residual = residual; p.ldr = ldr; p.act = MDQE_ACT_NONE;

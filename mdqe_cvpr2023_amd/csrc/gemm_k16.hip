@@ -273,6 +273,14 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) rs[i][it] = 0.f;
     const int c4 = lane & 7, rsub = lane >> 3;
+    // (round 4) residual rows and the stores of C / C2 go through buffer resources sized to M rows: ONE per-lane byte offset + a scalar
+    // offset per (sub-tile, trip, column block), and the hardware's range check stands in for every `m < M` test -- a row past the end
+    // reads zeros and its store is dropped.  No 64-bit address arithmetic, no exec-mask branches: each vector instruction here is matrix
+    // time of the three other waves on the SIMD (see the fast epilogue below).  The launcher guarantees M * ld * 4 < 4 GB.
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual != nullptr ? p.residual : p.C), 0,
+                                                       (int)(unsigned)((long)p.M * (p.residual != nullptr ? p.ldr : p.ldc) * 4), 0x00020000);
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)(unsigned)((long)p.M * p.ldc * 4), 0x00020000);
+    const unsigned vR = (unsigned)((rsub * p.ldr + c4 * 4) * 4), vC = (unsigned)((rsub * p.ldc + c4 * 4) * 4);
     auto stage = [&](auto i_, auto j_) __attribute__((always_inline)) {
       constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
 #pragma unroll
@@ -284,9 +292,11 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + rsub;
-        int m = m0 + i * 32 + row; if (m > p.M - 1) m = p.M - 1;
         f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * 32 + c4 * 4) + bv;
-        if (p.residual != nullptr) v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
+        if (p.residual != nullptr) {
+          const int so = (int)((((long)m0 + i * 32 + it * 8) * p.ldr + wn * 64 + j * 32) * 4);
+          v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vR, so, 0));
+        }
         vv[i][j][it] = v;
         rs[i][it] += (v[0] + v[1]) + (v[2] + v[3]);
       }
@@ -337,15 +347,20 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int m = m0 + i * 32 + it * 8 + rsub;
           vv[i][j][it] = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
-          if (m < p.M) *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = vv[i][j][it];
+          const int so = (int)((((long)m0 + i * 32 + it * 8) * p.ldc + n - c4 * 4) * 4);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, vv[i][j][it]), rsC, vC, so, 0);
+          __builtin_amdgcn_sched_barrier(0);                       // (store-data hazard, see the fast epilogue)
+          asm volatile("s_nop 1" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (p.ln2_g != nullptr) {
       // second LayerNorm, of the values just written (they are still in vv): the same two passes over the same reduction tree --
       // a lane's two chunks in stage order, the 8 lanes of a 32-column group, the four wave slices as (w0 + w1) + (w2 + w3)
       __syncthreads();                               // every wave has read red1 / red2 of the first LayerNorm
+      const auto rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.C2, 0, (int)(unsigned)((long)p.M * p.ldc2 * 4), 0x00020000);
+      const unsigned vC2 = (unsigned)((rsub * p.ldc2 + c4 * 4) * 4);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -389,8 +404,12 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            const int m = m0 + i * 32 + it * 8 + rsub;
-            if (m < p.M) *reinterpret_cast<f32x4*>(p.C2 + (long)m * p.ldc2 + n) = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
+            const f32x4 y2 = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
+            const int so = (int)((((long)m0 + i * 32 + it * 8) * p.ldc2 + n - c4 * 4) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y2), rsC2, vC2, so, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 1" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
           }
       }
     }

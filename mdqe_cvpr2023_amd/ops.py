@@ -210,7 +210,8 @@ def linear_ln(x, weight, bias, residual, gamma, beta, eps=1e-5, out=None, scratc
     # rounds: 139 us against 117 for GEMM + LayerNorm, tools/ln_tile_ab.py) -- the two forms give identical bits, so the choice is free
     nb = (M + 63) // 64
     full = nb >= 1024 or nb / (256.0 * ((nb + 255) // 256)) >= 0.8
-    if LINEAR_LN_FUSED and N == 256 and M >= LINEAR_LN_MIN_ROWS and full and get_gemm_precision() == "f32" and x.stride(1) == 1:
+    small = M * max(out.stride(0), residual.stride(0) if residual is not None else 0) * 4 < 0xFFFF0000       # (32-bit buffer offsets in the epilogue)
+    if LINEAR_LN_FUSED and N == 256 and M >= LINEAR_LN_MIN_ROWS and full and small and get_gemm_precision() == "f32" and x.stride(1) == 1:
         _chk(weight, "weight"); _chk(bias, "bias"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(residual, "residual"); _chk(out, "out")
         if second is not None and LINEAR_LN2_FUSED:
             _chk(second[0], "gamma2"); _chk(second[1], "beta2")
