@@ -322,9 +322,10 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     else if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
     else if ((g_gemm_tile_rule & 1) && b128 >= 2000 && p.N >= 1024 && p.N < 2048 && p.K <= 256 && !p.conv) tile = 9;   // short K, wide N -> 64x128
     else if ((g_gemm_tile_rule & 2) && p.conv && p.KH == 3 && b128 < 2000 && b128 >= 400 && p.N >= 256 && p.K < 4096) tile = 9;   // mid-grid 3x3 convs
-    else if (b128 >= 2000 && (p.N >= 1024 || p.K >= 1024)) tile = 1;
+    else if (b128 >= 2000 && (p.N >= 768 || p.K >= 1024)) tile = 1;        // (round 4: 768-wide products too -- Swin-L's K = 192 FFN1: 782 vs 794 us)
     else if (b128 >= 2000 && (p.N > 256 || p.K > 256)) tile = 2;
-    else tile = 3;                                   // incl. the encoder's [204000,256]x[256,256] (64x64: 288 vs 329 us)
+    else if (b128 >= 2000 && p.N >= 128 && !p.conv) tile = 2;               // (round 4, with the few-instruction epilogue: [153000,256]x[256,256] 167 vs 174 us,
+    else tile = 3;                                                           //  Swin-L's [907200,192]x[192,192] 590 vs 616 us; before it 64x64 won: 288 vs 329 us)
   }
   if (tile == 1 && g_gemm_precision == 1 && p.Wh != nullptr && p.K % 32 == 0 && p.N >= 128 && p.N % 4 == 0 &&
       p.vec_ok && p.ksplit <= 1) {
