@@ -7,6 +7,14 @@
 // restaged per WAVE through a private 4-KB slice (32x32 sub-tile at a time, no block barrier): 32 KB per 128x128 block,
 // four blocks = four waves per SIMD resident, so prologues, epilogues and barrier waits of one block hide behind the
 // MFMAs of the others.
+//
+// Round 4 -- the rule everything below is written to: v_mfma_f32_32x32x2_f32 runs at the VECTOR rate and holds the SIMD's vector
+// issue, so a vector instruction of ANY wave on the SIMD is matrix time lost (in-kernel stamps: beside three waves in their K loops a
+// wave in its epilogue issues about one instruction per MFMA; counters: MFMA pipe busy 0.775 -> 0.880 with 61 % fewer non-MFMA vector
+// instructions, profiles/r04_pmc_gemm_epilogue.txt).  Hence: the K loop unrolled by its two LDS stages (fragment reads = base +
+// immediate) with the ragged-K check behind a uniform branch; interior tiles of plain products on a few-instruction epilogue (buffer
+// addressing with scalar offsets, one specialised copy per form behind uniform branches); the LayerNorm epilogue on buffer resources
+// whose range check replaces the row guards.  Uniform conditions are branches, never selects.
 #include "common.h"
 #include "gemm_params.h"
 #include <type_traits>
