@@ -36,7 +36,7 @@ class Meter:
 
     def __init__(self, stride=5, msda_stride=3):
         self.rec = []                     # (e0, e1, flops) of sampled GEMM launches
-        self.msda = {"encoder": [], "decoder_box": [], "decoder_temporal": []}       # (e0, e1, bytes)
+        self.msda = {"encoder": [], "decoder_box": [], "decoder_temporal": []}       # (e0, e1, bytes[, bytes in the per-clip convention])
         self._enabled = False
         # An event pair per launch costs the timed region 1.2 % (tools/early_late_ab.py: 746 -> 737 frames/s at 360p; a record is a
         # barrier packet on the stream): every `stride`-th qualifying launch is timed instead.  A step has 442 of them (not a multiple
@@ -80,15 +80,15 @@ class Meter:
         from mdqe_cvpr2023_amd import ops, _lib
         L = _lib.load_library()
         raw, raw_conv, raw_ln, raw_cat = L.mdqe_gemm_nt_f32, L.mdqe_conv2d_nhwc_f32, L.mdqe_gemm_ln_f32, L.mdqe_gemm_nt_cat2_f32
-        raw_side, raw_msda, raw_ln2 = L.mdqe_gemm_nt_side_f32, L.mdqe_msda_fused_f32, L.mdqe_gemm_ln2_f32
+        raw_side, raw_msda, raw_ln2, raw_swin = L.mdqe_gemm_nt_side_f32, L.mdqe_msda_fused_f32, L.mdqe_gemm_ln2_f32, L.mdqe_gemm_nt_swin_f32
         meter = self
 
-        def timed(fn, a, sink, work):
+        def timed(fn, a, sink, work, *more):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*a)
             e1.record()
-            sink.append((e0, e1, work))
+            sink.append((e0, e1, work) + more)
             return rc
 
         class Wrapped:
@@ -134,6 +134,16 @@ class Meter:
                     return raw_cat(*a)
                 return timed(raw_cat, a, meter.rec, 2.0 * M * N * (K1 + K2))
 
+            def mdqe_gemm_nt_swin_f32(self_, *a):             # Swin's qkv product: A rows read through the window order (same kernel template)
+                # (X, lda, W, bias, C, ldc, B, H, Wd, ws, shift, N, K, stream): C has B*Hp*Wp rows
+                B, H, Wd, ws, N, K = a[6], a[7], a[8], a[9], a[11], a[12]
+                M = B * (-(-H // ws) * ws) * (-(-Wd // ws) * ws)
+                if meter.counting:
+                    meter.flops += 2.0 * M * N * K
+                if not (N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 192 and meter.take()):
+                    return raw_swin(*a)
+                return timed(raw_swin, a, meter.rec, 2.0 * M * N * K)
+
             def mdqe_conv2d_nhwc_f32(self_, *a):
                 NI, H, W, Cin, Cout, KH, KW, stride, pad, tile = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[19]   # (include/mdqe_hip.h)
                 M = NI * ((H + 2 * pad - KH) // stride + 1) * ((W + 2 * pad - KW) // stride + 1)
@@ -150,11 +160,16 @@ class Meter:
                 kind = "encoder" if mode == 0 else ("decoder_temporal" if G > 1 else "decoder_box")
                 if not meter.take_msda(kind):
                     return raw_msda(*a)
-                # algorithmic bytes: the value maps a batch element reads + offsets + logits + output, fp32.  Encoder /
-                # decoder box level: one frame's map per element; temporal: the L frames of the clip.
+                # algorithmic bytes, fp32: the value rows the launch reads + offsets + logits + output.  Encoder: one frame's
+                # map per batch element (every row is read).  Decoder launches: a batch of stride-1 clips shares each cached frame's map
+                # T ways, so the compulsory value bytes are the UNIQUE rows of the cache the launch addresses through `vidx` (value_rows =
+                # the frames of the cache x N) -- not B x a whole map (SURVEY §8d's per-clip figure, kept as `per_clip` for reference only)
+                value_rows = a[-2]
                 frames = L if kind == "decoder_temporal" else 1
-                nbytes = 4.0 * B * (frames * v_brows * M * D + Q * M * L * P * 3 + Q * M * D)
-                return timed(raw_msda, a, meter.msda[kind], nbytes)
+                small = 4.0 * B * (Q * M * L * P * 3 + Q * M * D)      # (the temporal launch's G level groups share offsets and logits)
+                per_clip = 4.0 * B * frames * v_brows * M * D + small
+                nbytes = per_clip if kind == "encoder" else 4.0 * value_rows * M * D + small
+                return timed(raw_msda, a, meter.msda[kind], nbytes, per_clip)
         ops.lib = Wrapped()
 
     def summary(self):
@@ -168,10 +183,11 @@ class Meter:
         out = {}
         for kind, rec in self.msda.items():
             if rec:
-                ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-                by = sum(w for _, _, w in rec)
+                ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+                by = sum(r[2] for r in rec)
+                pc = sum(r[3] for r in rec)
                 out[kind] = dict(launches_timed=len(rec), launches_total=self.msda_count[kind], avg_us=1e3 * ms / len(rec),
-                                 avg_mbytes=by / len(rec) / 1e6, tbps=by / ms / 1e9)
+                                 avg_mbytes=by / len(rec) / 1e6, tbps=by / ms / 1e9, per_clip_mbytes=pc / len(rec) / 1e6, per_clip_tbps=pc / ms / 1e9)
         return out
 
 
@@ -351,22 +367,44 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+class EmitOnce:
+    """The ONE JSON line of a run: whoever calls first -- the main thread at the end, or a soft deadline's timer thread -- prints it; a
+    second call is a no-op (a deadline that fires while the main thread is already printing must not produce a second line)."""
+
+    def __init__(self, emit):
+        import threading
+        self.emit, self.lock, self.done = emit, threading.Lock(), False
+
+    def __call__(self, text):
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+            self.emit(text)
+            return True
+
+
 class Deadline:
     """A soft watchdog around an OPTIONAL measurement (the halo-exchange A/B at N > 1, which has never run over RCCL with more than
-    one rank): if the guarded region has not finished after `seconds`, `on_expire()` runs on a timer thread (rank 0 prints the line it
-    already has) and the process leaves with exit code 0 -- before the process group's own timeout (COLLECTIVE_TIMEOUT_S) would abort
-    it and lose the headline.  Every rank arms the same deadline at the same barrier."""
+    one rank; the extra configs and the root-load rehearsal of the N = 1 line): if the guarded region has not finished after `seconds`,
+    `on_expire()` runs on a timer thread (rank 0 prints the line it already has, marked `"degraded": true`) and the process leaves AT ONCE
+    with exit code 0 -- no process-group shutdown, which would wait for peers that have already left -- before the process group's own
+    timeout (COLLECTIVE_TIMEOUT_S) would abort it and lose the headline.  Every rank arms the same deadline at the same barrier.
+    `once` (an EmitOnce shared with the main thread): if the line has already been printed when the timer fires, nothing is printed
+    again; a timer that fires while the region is being left is harmless for the same reason."""
 
-    def __init__(self, seconds, on_expire=None):
+    def __init__(self, seconds, on_expire=None, once=None):
         import threading
         self.expired = False
+        self.once = once
 
         def fire():
             self.expired = True
             try:
-                if on_expire is not None:
+                if on_expire is not None and not (self.once is not None and self.once.done):
                     on_expire()
             finally:
+                sys.stdout.flush()
                 sys.stderr.flush()
                 os._exit(0)
         self.t = threading.Timer(seconds, fire)
@@ -475,7 +513,13 @@ def main():
         sys.exit(2)
     # MDQE_BENCH_FORCE_SHARDED=1: take the N > 1 path (chunks, per-round gather, replay thread) with whatever world size there is --
     # on a 1-GPU box that runs the sharded schedule through a ONE-rank RCCL communicator (the only RCCL execution a single GPU allows)
-    sharded = world > 1 or os.environ.get("MDQE_BENCH_FORCE_SHARDED") == "1"
+    # MDQE_BENCH_ROOT_LOAD=W (one rank): the N = W ROOT-LOAD rehearsal -- this rank computes rank 0's chunks of a W-rank job and its replay
+    # thread is fed every gathered round as rank 0 of that job would receive it (sharding.expand_root_load)
+    root_load = int(os.environ.get("MDQE_BENCH_ROOT_LOAD", "0"))
+    if root_load and world != 1:
+        print("bench.py: MDQE_BENCH_ROOT_LOAD is a one-rank rehearsal (WORLD_SIZE=%d)" % world, file=sys.stderr)
+        sys.exit(2)
+    sharded = world > 1 or os.environ.get("MDQE_BENCH_FORCE_SHARDED") == "1" or root_load > 0
     if one_dev:
         local = 0
     if not probe:
@@ -515,38 +559,54 @@ def main():
 
     from mdqe_cvpr2023_amd import _lib
     _lib.load_library()                                   # loud if the HIP library is missing
+    from types import SimpleNamespace as NS
     from mdqe_cvpr2023_amd.config import PRESETS
     from mdqe_cvpr2023_amd.meta_arch import MDQE
     from mdqe_cvpr2023_amd.params import random_state
     from mdqe_cvpr2023_amd import sharding
+    from mdqe_cvpr2023_amd import ops
 
-    cfg = PRESETS[args.config]
-    fh, fw = {"R50_ovis_360": (360, 640), "R50_ovis_720": (640, 1138), "swinl_ovis": (480, 853)}[args.config]
-    sd = random_state(cfg, seed=0, remove_zero_init_trap=(args.init == "workload"))
-    model = MDQE(cfg, state_dict=sd).eval()
-    model.rle_output = bool(args.rle_output)
-    bias_shift = calibrate_synthetic_scores(model, sd, cfg, fh, fw) if args.init == "workload" else 0.0
+    t_start = time.perf_counter()
     meter = Meter()
     meter.install()
 
+    def build(config, init):
+        """Model + synthetic weights of one config (calibrated class logits for the `workload` initialisation)."""
+        c = PRESETS[config]
+        h_, w_ = FRAME_SIZES[config]
+        sd_ = random_state(c, seed=0, remove_zero_init_trap=(init == "workload"))
+        m = MDQE(c, state_dict=sd_).eval()
+        shift = calibrate_synthetic_scores(m, sd_, c, h_, w_) if init == "workload" else 0.0
+        return NS(name=config, cfg=c, fh=h_, fw=w_, sd=sd_, model=m, bias_shift=shift)
+
+    wl = build(args.config, args.init)
+    cfg, fh, fw, sd, model, bias_shift = wl.cfg, wl.fh, wl.fw, wl.sd, wl.model, wl.bias_shift
+    model.rle_output = bool(args.rle_output)
+
     # The video starts in PINNED HOST memory, one tensor per frame as the mapper hands them over (mdqe/data/dataset_mapper.py:
     # 228-263); the host->device copy of a1 (mdqe/mdqe.py:480) is part of every timed step.
+    vworld = root_load if root_load > 0 else None         # root-load rehearsal: the plan of a `vworld`-rank job, rank 0's part of it
+    pworld = vworld or world                              # the world the chunks are dealt to
     L = args.frames * world
     T = cfg.n_frames_test
     like = torch.zeros(0, 3, fh, fw, device="cuda")
-    shards = {}                                            # halo_exchange (bool) -> (plan, {chunk: pinned frames})
-    if not sharded:
-        video = synth_video(0, L, seed=0, h=fh, w=fw).pin_memory()
-        host_frames = list(video)                          # L views [3,h,w] of the pinned block
-        chunk = None
-    else:
+    shards = {}                                            # key -> (plan, {chunk: pinned frames}, vworld)
+    chunk = None
+    if sharded or vworld:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
         chunk = sharding.round_sizes(args.frames, T) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
 
-        def shard(halo, n_frames=L, chunk_=None, seed=0):
-            pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk if chunk_ is None else chunk_, halo_exchange=halo, world=world)
-            return pl, {g: synth_video(pl[g][1], pl[g][2], seed=seed, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(pl, world, rank)}
-        shards[args.halo_exchange] = shard(args.halo_exchange)
+    def shard(halo, n_frames=None, chunk_=None, seed=0, vw=None):
+        pw = vw or world
+        n_frames = args.frames * pw if n_frames is None else n_frames
+        pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk if chunk_ is None else chunk_, halo_exchange=halo, world=pw)
+        return pl, {g: synth_video(pl[g][1], pl[g][2], seed=seed, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(pl, pw, rank)}, vw
+
+    if not sharded:
+        video = synth_video(0, L, seed=0, h=fh, w=fw).pin_memory()
+        host_frames = list(video)                          # L views [3,h,w] of the pinned block
+    else:
+        shards[args.halo_exchange] = shard(args.halo_exchange, vw=vworld)
     torch.cuda.synchronize()
 
     def sync():
@@ -554,37 +614,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from mdqe_cvpr2023_amd import ops
-
-    def run(k, stream, mdl=model, resident=None, halo=args.halo_exchange, stats=None):
+    def run(k, stream, mdl=model, resident=None, key=None, stats=None, step_ms=None, frames=None):
         """k steps (videos).  stream=False: one `model(inputs)` per video -- the metric as SURVEY §8(d) defines it (the
         reference's evaluator calls the model once per video, train_net.py:207).  stream=True: MDQE.forward_stream /
-        sharding.run_round_robin_stream -- the next video's first pass (round) is queued under the current video's tracker tail."""
+        sharding.run_round_robin_stream -- the next video's first pass (round) is queued under the current video's tracker tail.
+        key: which sharded form (a key of `shards`); None = the invocation's own (unsharded at N = 1).
+        step_ms: a list that receives the wall milliseconds of every step (a step ends with the host holding the video's result)."""
         o = None
-        if not sharded:
-            inp = [{"image": resident if resident is not None else host_frames, "height": fh, "width": fw}]
+        if key is None and sharded:
+            key = args.halo_exchange
+        if key is None:
+            fr = frames if frames is not None else host_frames
+            hh, ww = int(fr[0].shape[-2]), int(fr[0].shape[-1])
+            inp = [{"image": resident if resident is not None else fr, "height": hh, "width": ww}]
             if not stream:
                 for _ in range(k):
+                    t0 = time.perf_counter()
                     o = mdl(inp)
+                    if step_ms is not None:
+                        step_ms.append(1e3 * (time.perf_counter() - t0))
             else:
                 for o in mdl.forward_stream(inp for _ in range(k)):
                     pass
             return o
-        plan, chunk_frames = shards[halo]
+        plan, chunk_frames, vw = shards[key]
+        halo = key is True
         if not stream:
             for _ in range(k):
+                t0 = time.perf_counter()
                 o = sharding.run_round_robin(mdl, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), root_only=True,
-                                             halo_exchange=halo, like=like, stats=stats)
+                                             halo_exchange=halo, like=like, stats=stats, vworld=vw)
+                if step_ms is not None:
+                    step_ms.append(1e3 * (time.perf_counter() - t0))
         else:
             for o in sharding.run_round_robin_stream(mdl, ((chunk_frames, plan, like) for _ in range(k)), rank, world, dist,
-                                                     out_size=(fh, fw), root_only=True, halo_exchange=halo, stats=stats):
+                                                     out_size=(fh, fw), root_only=True, halo_exchange=halo, stats=stats, vworld=vw):
                 pass
         return o
 
-    def timed(precision, meter_on, stream=False, **kw):
+    def timed(precision, meter_on, stream=False, steps=None, warmup=None, **kw):
+        steps = args.steps if steps is None else steps
         ops.set_gemm_precision(precision)
         with torch.no_grad():
-            run(args.warmup, stream, **dict(kw, stats=None))
+            run(args.warmup if warmup is None else warmup, stream, **dict(kw, stats=None, step_ms=None))
             sync()
             meter.enabled = meter_on
             prof = None
@@ -593,7 +665,7 @@ def main():
                 prof = cProfile.Profile()
                 prof.enable()
             t0 = time.perf_counter()
-            o = run(args.steps, stream, **kw)
+            o = run(steps, stream, **kw)
             sync()
             d = time.perf_counter() - t0
             meter.enabled = False
@@ -607,8 +679,14 @@ def main():
             d = float(t.item())
         return d, o
 
-    def rate(d):
-        return {"value": L * args.steps / d, "unit": "frames/s", "ms_per_step": 1e3 * d / args.steps}
+    def rate(d, frames=None, steps=None):
+        steps = args.steps if steps is None else steps
+        return {"value": (L if frames is None else frames) * steps / d, "unit": "frames/s", "ms_per_step": 1e3 * d / steps}
+
+    def median(v):
+        v = sorted(v)
+        n = len(v)
+        return None if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
 
     verify_ref = {}
 
@@ -639,13 +717,14 @@ def main():
         sync()
         return bool(int(flag.item())), {"frames": Lv, "chunk_frames": cv, "rounds": -(-len(sharding.chunk_plan(Lv, T, cfg.clip_stride, cv, halo, world)) // world)}
 
+    STAT_KEYS = ("compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed", "replay_busy")
+
     def rank_stats(stats):
         """This rank's mean host milliseconds per video over the timed steps, gathered from all ranks -> {key: [rank 0, rank 1, ...]}."""
-        keys = ("compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed")
-        mine = {k: (sum(v[k] for v in stats) / max(len(stats), 1)) for k in keys}
+        mine = {k: (sum(v.get(k, 0.0) for v in stats) / max(len(stats), 1)) for k in STAT_KEYS}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
-        return {k: [round(r[k], 2) for r in allr] for k in keys}
+        return {k: [round(r[k], 2) for r in allr] for k in STAT_KEYS}
 
     verified = None
     if sharded:
@@ -657,41 +736,49 @@ def main():
         verified = dict(vinfo, ok=True, what="the sharded schedule and one plain model(inputs) call on rank 0 agree bit for bit (labels, scores, masks)")
 
     st_main = [] if sharded else None
-    dt, out = timed(args.precision, True, **({"stats": st_main} if sharded else {}))
+    steps_ms = []
+    dt, out = timed(args.precision, True, step_ms=steps_ms, **({"stats": st_main} if sharded else {}))
     g_timed, m_timed = meter.summary(), meter.msda_summary()
     breakdown = None
     if sharded:
-        breakdown = {"per_rank_ms": rank_stats(st_main), "halo_frac": round(sharding.halo_recompute_frac(shards[args.halo_exchange][0], L), 4),
-                     "rounds": len(chunk) if isinstance(chunk, list) else -(-len(shards[args.halo_exchange][0]) // world),
+        plan_main = shards[args.halo_exchange][0]
+        breakdown = {"per_rank_ms": rank_stats(st_main), "halo_frac": round(sharding.halo_recompute_frac(plan_main, args.frames * pworld), 4),
+                     "rounds": len(chunk) if isinstance(chunk, list) else -(-len(plan_main) // pworld),
                      "what": "mean host ms per video (step) on every rank: compute = queueing a round's frame passes + consuming its clip results "
                              "(ends with the sync behind the round's last clip kernel); gather_wait = size all-gather = waiting for the slowest "
                              "rank; gather_payload = the three padded gathers + one D2H of the clip tables; feed = hand-over to the replay thread; "
-                             "replay_exposed = rank 0 joining the tracker replay + video merge after the LAST gather (nothing hides it); halo_frac = "
-                             "per-frame work done twice"}
+                             "replay_exposed = rank 0 joining the tracker replay + video merge after the LAST gather (nothing hides it); replay_busy = "
+                             "the replay worker's busy time over the whole video (tracker, window flushes, final masks); halo_frac = per-frame work "
+                             "done twice"}
         pr = breakdown["per_rank_ms"]
         breakdown["replay_exposed_ms"] = pr["replay_exposed"][0]
         breakdown["gather_ms"] = round(max(a + b for a, b in zip(pr["gather_wait"], pr["gather_payload"])), 2)
     # The same launches with the streams serialized (one extra UNTIMED step): in the timed region the dominant GEMM shares
     # the chip with the clip-stream / tracker-stream kernels, which stretches its per-launch duration without being a
     # property of the kernel; both figures are reported.
-    g_iso = m_iso = clip_stage = None
-    if not sharded:
+
+    def isolated_pass(mdl, **kw):
+        """One extra untimed step with every stage on one stream and an event pair around EVERY qualifying launch."""
         meter.reset()
-        model.overlap_streams = False
+        mdl.overlap_streams = False
         strides = meter.stride, meter.msda_stride
-        meter.stride, meter.msda_stride = 1, 1             # (untimed: every launch gets its pair)
+        meter.stride, meter.msda_stride = 1, 1
         with torch.no_grad():
             meter.enabled = True
-            run(1, False)
+            run(1, False, mdl=mdl, **kw)
             sync()
             meter.enabled = False
         meter.stride, meter.msda_stride = strides
-        model.overlap_streams = True
-        g_iso, m_iso = meter.summary(), meter.msda_summary()
+        mdl.overlap_streams = True
+        return meter.summary(), meter.msda_summary()
+
+    g_iso = m_iso = clip_stage = None
+    if not sharded:
+        g_iso, m_iso = isolated_pass(model)
         if not args.no_fast_mode:
             clip_stage = clip_stage_alone(model, cfg, torch.stack(host_frames).cuda(), meter, L, T)
     extra = {}
-    if not args.no_fast_mode:
+    if not args.no_fast_mode and not vworld:
         d, _ = timed(args.precision, False, stream=True)
         extra["stream_mode"] = dict(rate(d), what="the same %d videos handed over as a stream (MDQE.forward_stream / run_round_robin_stream: the first pass of "
                                                    "video k+1 is queued under the tracker tail of video k; outputs identical, in order)" % args.steps)
@@ -718,13 +805,12 @@ def main():
             extra["late_masks"] = dict(rate(d), what="final masks in one pass + one device->host copy after the last window (the round-2 behaviour "
                                                      "of MERGE_ON_CPU = False configs) instead of per flushed window under the later windows' compute")
             if args.init == "workload":
-                sd_ref = random_state(cfg, seed=0, remove_zero_init_trap=False)
-                m_ref = MDQE(cfg, state_dict=sd_ref).eval()
+                m_ref = build(args.config, "reference").model
                 d, o_ref = timed(args.precision, False, mdl=m_ref)
                 extra["init_reference"] = dict(rate(d), instances_out=len(o_ref["pred_scores"]),
                                               what="the reference's own initialisation, untouched (zero-init trap in place: every query collapses into one "
                                                    "instance per clip, the data-dependent stages idle)")
-                del m_ref, sd_ref
+                del m_ref
     ops.set_gemm_precision("f32")
 
     if args.stages and rank == 0 and not sharded:
@@ -732,15 +818,142 @@ def main():
         with torch.no_grad():
             print(json.dumps({"stages_ms": profiling.stage_breakdown(model, torch.stack(host_frames).cuda())}), file=sys.stderr)
 
+    def roofline_keys(g, g_iso_, m, m_iso_, precision):
+        """`roofline` / `roofline_isolated` / `roofline_msda` of one measured configuration from the meter's summaries."""
+        keys = {}
+        if g:
+            pk = F32_MFMA_PEAK_TFLOPS if precision == "f32" else 2500.0 / 3
+            kname = ("gemm_nt_f32_k16_kernel (fp32 MFMA GEMM / implicit-GEMM conv incl. its LayerNorm-epilogue and window-order forms; every launch "
+                     "worth >= 192 tiles of 128x128, in whichever tile shape the dispatcher picks)" if precision == "f32" else
+                     "gemm_nt_f16x3w_kernel<256|128> (+ gemm_nt_f16x3_kernel<128,128> where B is not a constant weight)")
+            keys["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": g["tflops"], "peak": pk, "unit": "TFLOP/s", "frac": g["tflops"] / pk,
+                                # HBM bytes need rocprofv3 --pmc passes, which cannot run inside this process: not a live figure -> null;
+                                # the per-launch counters of the dominant launch shape are in the file named below
+                                "traffic": None,
+                                "traffic_ref": TRAFFIC_REF_GEMM,
+                                "launches": g["launches_timed"], "launches_timed": g["launches_timed"], "launches_total": g["launches_total"],
+                                "avg_launch_us": g["avg_us"],
+                                "sampled": "an event pair around every %d-th qualifying launch of the timed region (a pair per launch costs the region 1.2 %%): "
+                                           "launches_timed of launches_total" % meter.stride,
+                                "note": "timed region: launches overlap with the clip-stream and tracker-stream kernels"}
+            if g_iso_:
+                keys["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": g_iso_["tflops"], "peak": pk,
+                                             "unit": "TFLOP/s", "frac": g_iso_["tflops"] / pk, "launches": g_iso_["launches_timed"],
+                                             "avg_launch_us": g_iso_["avg_us"],
+                                             "note": "same launches, one extra untimed step with all stages on one stream"}
+        if m:
+            def entry(kernel, mm, iso):
+                e = {"bound": "hbm", "kernel": kernel, "achieved": mm["tbps"], "achieved_TBps": mm["tbps"], "peak": HBM_PEAK_TBPS, "unit": "TB/s",
+                     "frac": mm["tbps"] / HBM_PEAK_TBPS, "avg_launch_us": mm["avg_us"], "algorithmic_MB_per_launch": mm["avg_mbytes"],
+                     "launches_timed": mm["launches_timed"], "launches_total": mm["launches_total"]}
+                if iso:
+                    e.update(frac_isolated=iso["tbps"] / HBM_PEAK_TBPS, achieved_isolated_TBps=iso["tbps"], avg_launch_us_isolated=iso["avg_us"])
+                return e
+            iso = m_iso_ or {}
+            if "encoder" in m:
+                rm = entry("msda_fused_v3_kernel (mdqe_msda_fused_f32 mode 0: the encoder's multi-scale deformable gather, offsets + softmax + "
+                           "bilinear gather fused, the coarse levels staged in LDS)", m["encoder"], iso.get("encoder"))
+                rm["traffic"] = None
+                rm["traffic_ref"] = TRAFFIC_REF_MSDA
+                rm["bytes"] = ("algorithmic = SURVEY §8(d): value + sampling offsets + attention logits + output, fp32 = 18.3 MB per frame and layer "
+                               "at 360p, x the frames of the launch")
+                rm["sampled"] = "an event pair around every %d-th launch of the timed region" % meter.msda_stride
+                for k2, kn in (("decoder_box", "msda_fused_v3_kernel<832> (mode 1: the decoder's box-level launch, a clip-frame's map per batch element)"),
+                               ("decoder_temporal", "msda_fused_tp_kernel (the decoder's instance-level launch: 4 frames x 4 levels per clip)")):
+                    if k2 in m:
+                        rm[k2] = entry(kn, m[k2], iso.get(k2))
+                        rm[k2]["bytes"] = ("algorithmic = the UNIQUE value rows the launch addresses (the cached frames of the batch x N tokens x C: a batch "
+                                           "of stride-1 clips shares a frame's map T ways) + offsets + logits + output, fp32")
+                        rm[k2]["bytes_per_clip_convention"] = {
+                            "MB_per_launch": m[k2]["per_clip_mbytes"], "TBps": m[k2]["per_clip_tbps"],
+                            "what": "SURVEY §8(d)'s per-clip figure -- every clip(-frame) counts its frames' whole value maps -- for reference only: it "
+                                    "counts a shared map up to T times and is NOT a traffic figure (no fraction is quoted on it)"}
+                keys["roofline_msda"] = rm
+        return keys
+
+    def side_config(name, frames, steps):
+        """BASELINE.json configs[2] / configs[3] in the SAME invocation as the headline (extra keys of the line): its own model and
+        synthetic video, one warm-up step, `steps` timed steps with the meter on, one isolated pass."""
+        t_in = time.perf_counter()
+        w = build(name, "workload")
+        vid = synth_video(0, frames, seed=0, h=w.fh, w=w.fw).pin_memory()
+        fr = list(vid)
+        sm = []
+        meter.reset()
+        d, o = timed("f32", True, steps=steps, warmup=1, mdl=w.model, frames=fr, step_ms=sm)
+        g, m = meter.summary(), meter.msda_summary()
+        gi, mi = isolated_pass(w.model, frames=fr)
+        e = dict(rate(d, frames, steps), steps=steps, warmup=1, frames_per_step=frames, dtype="f32",
+                 value_median=frames * 1e3 / median(sm), value_is="mean over the timed steps; value_median = frames / median step time",
+                 workload="%s eval-only, H2D included: %d synthetic %dx%d uint8 frames per step from pinned host memory, %d-frame clips stride 1, "
+                          "%d-frame windows, one model(inputs) call per step, exact fp32" % (name, frames, w.fh, w.fw, w.cfg.n_frames_test, w.cfg.n_frames_window_test),
+                 instances_out=len(o["pred_scores"]), tracked_instances=getattr(w.model, "last_num_tracks", None),
+                 merge_on_cpu=bool(w.cfg.merge_on_cpu), cls_bias_shift=round(w.bias_shift, 3))
+        e.update(roofline_keys(g, gi, m, mi, "f32"))
+        del w, vid, fr
+        torch.cuda.empty_cache()
+        e["wall_s"] = round(time.perf_counter() - t_in, 1)
+        return e
+
+    def root_load_leg(W, steps):
+        """The N = W root load on this one GPU (sharding.expand_root_load): rank 0's own chunks of a W-rank job + the replay / final masks /
+        mask read-back of all W ranks' clips.  Needs a process group (one rank); `dist` of the enclosing scope is used when there is one."""
+        nonlocal dist
+        t_in = time.perf_counter()
+        made = False
+        if dist is None:
+            import datetime
+            import socket
+            import torch.distributed as d_
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            d_.init_process_group("nccl" if backend == "nccl" else backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                  timeout=datetime.timedelta(seconds=60), **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
+            dist, made = d_, True
+        try:
+            chunk_ = sharding.round_sizes(args.frames, T)
+            res = {"world": W, "frames_per_rank": args.frames, "frames_virtual": args.frames * W, "chunk_frames_per_round": chunk_}
+            base = {}
+            for key, vw in (("w1", None), ("wN", W)):
+                shards[key] = shard(False, chunk_=chunk_, vw=vw) if vw else shard(False, n_frames=args.frames, chunk_=chunk_)
+                st, sm = [], []
+                d, o = timed("f32", False, steps=steps, warmup=1, key=key, stats=st, step_ms=sm)
+                mean = {k: round(sum(v.get(k, 0.0) for v in st) / max(len(st), 1), 2) for k in STAT_KEYS}
+                base[key] = dict(ms_per_step=1e3 * d / steps, ms_median=median(sm), tracks=getattr(model, "last_num_tracks", None), **mean)
+                del shards[key]
+            w1, wN = base["w1"], base["wN"]
+            res.update(ms_per_step=wN["ms_per_step"], ms_per_step_median=wN["ms_median"], compute=wN["compute"], replay_exposed_ms=wN["replay_exposed"],
+                       replay_total_ms=wN["replay_busy"], gather_ms=round(wN["gather_wait"] + wN["gather_payload"], 2), tracked_instances=wN["tracks"],
+                       d2h_MB_per_step=round((wN["tracks"] or 0) * args.frames * W * fh * fw / 1e6, 1),
+                       sharded_world1={"ms_per_step": w1["ms_per_step"], "compute": w1["compute"], "replay_exposed_ms": w1["replay_exposed"],
+                                       "replay_total_ms": w1["replay_busy"], "tracked_instances": w1["tracks"]},
+                       predicted_efficiency=w1["ms_per_step"] / wN["ms_per_step"],
+                       what="rank 0 of a %d-rank job on this one GPU: it computes its own %d frames per step (the same chunks as in the real job) "
+                            "while its replay thread is fed every gathered round %d times under shifted frame indices (a %d-frame video whose foreign "
+                            "chunks repeat rank 0's clip results): tracker replay, bank updates, window flushes, final_mask_kernel and the device->host "
+                            "copies of the masks carry the N = %d volume.  predicted_efficiency = step time of the same sharded schedule with the root "
+                            "load of ONE rank / with the load of %d (rank 0 is the only rank that does more than compute + send, so its step time is "
+                            "the job's); the wire and the other ranks' pace are not in it" % (W, args.frames, W, args.frames * W, W, W))
+            res["wall_s"] = round(time.perf_counter() - t_in, 1)
+            return res
+        finally:
+            if made:
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+                dist = None
+
     line = None
     if rank == 0:
-        g = g_timed
         line = {
             "metric": {"R50_ovis_360": "frames/sec (eval-only) R50 OVIS 360p 4-frame clip",
                        "R50_ovis_720": "frames/sec (eval-only) R50 OVIS 640p 4-frame clip",
                        "swinl_ovis": "frames/sec (eval-only) Swin-L OVIS 480p 2-frame clip"}[args.config], "value": L * args.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_median": L * 1e3 / median(steps_ms) if steps_ms else None,
+            "value_is": "mean: frames of the K timed steps / wall time of the bracketed region (the driver's contract); value_median = frames / the "
+                        "MEDIAN of the K per-step wall times (SURVEY §8d; a step ends with the host holding the video's masks, so per-step times are exact)",
             "config": {"workload": "%s eval-only, H2D included: %d synthetic %dx%d uint8 frames per GPU per step start in pinned host memory (one tensor per "
                                    "frame) and are uploaded inside the step; %d-frame clips stride 1, %d-frame windows; one `model(inputs)` call per video "
                                    "and step, as the reference's evaluator makes it; OVIS-like synthetic video (textured rectangles moving over a textured "
@@ -761,94 +974,98 @@ def main():
                                           "halo exchange (T-1 frames of encoder tokens + mask features by send/recv)" if args.halo_exchange
                                           else "a chunk's T-1 frame halo is computed by its owner again")) if sharded else "single GPU"},
         }
+        if vworld:
+            line["config"]["root_load_world"] = vworld
+            line["config"]["workload"] += ("; ROOT-LOAD REHEARSAL (MDQE_BENCH_ROOT_LOAD=%d): this rank computes rank 0's %d frames of a %d-rank job and "
+                                           "replays the clips of all %d ranks (sharding.expand_root_load); `value` counts this rank's own frames only"
+                                           % (vworld, args.frames, vworld, vworld))
         if verified is not None:
             line["verified"] = True
             line["verification"] = verified
         if breakdown is not None:
             line["scaling_breakdown"] = breakdown
-        if g:
-            pk = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else 2500.0 / 3
-            kname = ("gemm_nt_f32_k16_kernel (fp32 MFMA GEMM / implicit-GEMM conv incl. its LayerNorm-epilogue form; every launch worth >= 192 tiles of "
-                     "128x128, in whichever tile shape the dispatcher picks)" if args.precision == "f32" else
-                     "gemm_nt_f16x3w_kernel<256|128> (+ gemm_nt_f16x3_kernel<128,128> where B is not a constant weight)")
-            line["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": g["tflops"], "peak": pk, "unit": "TFLOP/s", "frac": g["tflops"] / pk,
-                                # HBM bytes need rocprofv3 --pmc passes, which cannot run inside this process: not a live figure -> null;
-                                # the per-launch counters of the dominant launch shape are in the file named below
-                                "traffic": None,
-                                "traffic_ref": TRAFFIC_REF_GEMM,
-                                "launches": g["launches_timed"], "launches_timed": g["launches_timed"], "launches_total": g["launches_total"],
-                                "avg_launch_us": g["avg_us"],
-                                "sampled": "an event pair around every %d-th qualifying launch of the timed region (a pair per launch costs the region 1.2 %%): "
-                                           "launches_timed of launches_total" % meter.stride,
-                                "note": "timed region: launches overlap with the clip-stream and tracker-stream kernels"}
-            if g_iso:
-                line["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": g_iso["tflops"], "peak": pk,
-                                             "unit": "TFLOP/s", "frac": g_iso["tflops"] / pk, "launches": g_iso["launches_timed"],
-                                             "avg_launch_us": g_iso["avg_us"],
-                                             "note": "same launches, one extra untimed step with all stages on one stream"}
-        if m_timed:
-            def entry(kind, kernel, m, iso):
-                e = {"bound": "hbm", "kernel": kernel, "achieved": m["tbps"], "achieved_TBps": m["tbps"], "peak": HBM_PEAK_TBPS, "unit": "TB/s",
-                     "frac": m["tbps"] / HBM_PEAK_TBPS, "avg_launch_us": m["avg_us"], "algorithmic_MB_per_launch": m["avg_mbytes"],
-                     "launches_timed": m["launches_timed"], "launches_total": m["launches_total"]}
-                if iso:
-                    e.update(frac_isolated=iso["tbps"] / HBM_PEAK_TBPS, achieved_isolated_TBps=iso["tbps"], avg_launch_us_isolated=iso["avg_us"])
-                return e
-            iso = m_iso or {}
-            if "encoder" in m_timed:
-                rm = entry("encoder", "msda_fused_v3_kernel (mdqe_msda_fused_f32 mode 0: the encoder's multi-scale deformable gather, offsets + softmax + "
-                                      "bilinear gather fused, the coarse levels staged in LDS)", m_timed["encoder"], iso.get("encoder"))
-                rm["traffic"] = None
-                rm["traffic_ref"] = TRAFFIC_REF_MSDA
-                rm["bytes"] = ("algorithmic = SURVEY §8(d): value + sampling offsets + attention logits + output, fp32 = 18.3 MB per frame and layer "
-                               "at 360p, x the frames of the launch")
-                rm["sampled"] = "an event pair around every %d-th launch of the timed region" % meter.msda_stride
-                for k2, kn in (("decoder_box", "msda_fused_v3_kernel<832> (mode 1: the decoder's box-level launch, a clip-frame's map per batch element)"),
-                               ("decoder_temporal", "msda_fused_tp_kernel (the decoder's instance-level launch: 4 frames x 4 levels per clip)")):
-                    if k2 in m_timed:
-                        rm[k2] = entry(k2, kn, m_timed[k2], iso.get(k2))
-                        rm[k2]["bytes"] = ("SURVEY §8(d)'s per-clip figure: every clip(-frame) counts its frames' whole value maps, though overlapping "
-                                           "stride-1 clips share them (a frame belongs to 4 clips: unique bytes are ~4x fewer)")
-                line["roofline_msda"] = rm
+        line.update(roofline_keys(g_timed, g_iso, m_timed, m_iso, args.precision))
         if clip_stage:
             line["clip_stage"] = clip_stage
         line.update(extra)
-        if not sharded and not args.no_cpu_baseline:
-            if args.config == "R50_ovis_360":
-                line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
-            else:
-                # the CPU leg is BASELINE.json's configs[0] -- R50_ovis_360, 4 frames on the host cores -- and is quoted on the metric's
-                # config only (the oracle's Swin-L / 640p passes take minutes per frame on a CPU)
-                line["cpu_baseline"] = None
+
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
+        if args.config == "R50_ovis_360":
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4])   # rank 0 at N=1: its shard starts at frame 0
+        else:
+            # the CPU leg is BASELINE.json's configs[0] -- R50_ovis_360, 4 frames on the host cores -- and is quoted on the metric's
+            # config only (the oracle's Swin-L / 640p passes take minutes per frame on a CPU)
+            line["cpu_baseline"] = None
+
+    # ---- optional legs: each may be cut short by the soft deadline; the headline above is complete -------------------------------------
+    emitted = EmitOnce(emit)
+
+    def give_up(what, budget):
+        def fn():
+            if rank == 0 and line is not None:
+                line.setdefault("degraded", True)
+                line.setdefault("degraded_legs", []).append("%s did not finish within %g s (soft deadline); the headline is unaffected" % (what, budget))
+                emitted(json.dumps(line))
+        return fn
+
+    side = os.environ.get("MDQE_BENCH_SIDE_CONFIGS", "")            # "1": always, "0": never, unset: with the other extras of the headline config
+    if (not sharded and rank == 0 and args.config == "R50_ovis_360" and args.precision == "f32"
+            and (side == "1" or (side != "0" and not args.no_fast_mode))):
+        # BASELINE.json configs[2] and configs[3] as extra keys of the driver's line (round 4's were builder-run only)
+        sf, ss = os.environ.get("MDQE_BENCH_SIDE_FRAMES"), int(os.environ.get("MDQE_BENCH_SIDE_STEPS", "4"))     # (tests: reduced sizes)
+        for key, name, frames_, steps_ in (("config_R50_ovis_720", "R50_ovis_720", int(sf or 60), ss), ("config_swinl_ovis", "swinl_ovis", int(sf or 40), ss)):
+            budget = float(os.environ.get("MDQE_BENCH_SIDE_S", "90"))
+            with Deadline(budget, give_up(key, budget), emitted):
+                try:
+                    line[key] = side_config(name, frames_, steps_)
+                except Exception as e:                                   # an extra must not take the headline down
+                    line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        ops.set_gemm_precision("f32")
+
+    rl = os.environ.get("MDQE_BENCH_ROOT_LOAD_LEG", "")             # "W": that world, "0": never, unset: 8 with the other extras
+    rl_w = int(rl) if rl else (8 if not args.no_fast_mode else 0)
+    if not sharded and rank == 0 and rl_w > 1 and args.config == "R50_ovis_360" and args.precision == "f32":
+        budget = float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "90"))
+        with Deadline(budget, give_up("root_load", budget), emitted):
+            try:
+                line["root_load"] = root_load_leg(rl_w, max(3, min(args.steps, 5)))
+            except Exception as e:
+                line["root_load"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if rank == 0:
+        line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
 
     # N > 1: the halo-exchange form of the same job as an extra key of the same line, so that one multi-GPU run decides the default.
     # It has never run over RCCL with more than one rank, so it runs LAST and under a soft deadline: if it has not finished in time,
-    # rank 0 prints the line it already has (with the reason) and every rank leaves with exit code 0.
+    # rank 0 prints the line it already has (with `degraded`) and every rank leaves at once, without the process group's shutdown.
     halo_ab = os.environ.get("MDQE_BENCH_HALO_AB", "")             # "1": always, "0": never, unset: with the other extras of the line
-    if sharded and world > 1 and not args.halo_exchange and (halo_ab == "1" or (halo_ab != "0" and not args.no_fast_mode)):
+    if sharded and world > 1 and not vworld and not args.halo_exchange and (halo_ab == "1" or (halo_ab != "0" and not args.no_fast_mode)):
         budget = float(os.environ.get("MDQE_BENCH_HALO_AB_S", "75"))
 
-        def give_up():
+        def halo_gave_up():
             if rank == 0:
                 line["halo_exchange"] = {"error": "did not finish within %g s (soft deadline); the headline above is unaffected" % budget}
-                emit(json.dumps(line))
+            give_up("halo_exchange", budget)()
         sync()
-        with Deadline(budget, give_up):
+        with Deadline(budget, halo_gave_up, emitted):
             shards[True] = shard(True)
             ok, vinfo = verify_sharded(True)
             res = {"verified": bool(ok)}
             if ok:
                 st_h = []
-                d, _ = timed(args.precision, False, halo=True, stats=st_h)
+                d, _ = timed(args.precision, False, key=True, stats=st_h)
                 res.update(rate(d), per_rank_ms=rank_stats(st_h), halo_frac=round(sharding.halo_recompute_frac(shards[True][0], L), 4),
                            what="the same steps with the halo exchange: chunks partition the frames, a chunk's first T-1 clips read the left "
                                 "neighbour's last T-1 frames from shipped encoder tokens + mask features (one grouped send/recv per rank and round)")
         if rank == 0:
             line["halo_exchange"] = res
     if rank == 0:
-        emit(json.dumps(line))
+        emitted(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+FRAME_SIZES = {"R50_ovis_360": (360, 640), "R50_ovis_720": (640, 1138), "swinl_ovis": (480, 853)}
 
 
 TRAFFIC_REF_GEMM = ("profiles/r03_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: "

@@ -164,6 +164,8 @@ int mdqe_debug_gemm_fast_epilogue(int v); /* K-step-16 kernel (tools/ A/B): 1 (d
 int mdqe_debug_gemm_stagger(int v);  /* K-step-16 kernel: start offset between the blocks of a CU's first round, 10-ns ticks; 0 = off */
 int mdqe_debug_gemm_stages(int v);   /* K-step-16 kernel, 64x64 and smaller tiles: LDS stages 2 / 4; 0 = by grid size (default) */
 int mdqe_debug_msda_dec_stage_kb(int kb);   /* tools/ only: LDS staging budget of the decoder's box-level deformable launch (default 72: two blocks per CU) */
+int mdqe_debug_trk_fast(int on);            /* tests / tools: 1 (default; env MDQE_TRK_FAST) = a tracker update takes its counts through mdqe_trk_siou_host_f32, 0 = memset + kernel + copy + synchronize */
+int mdqe_debug_trk_spin_us(int us);         /* how long the tracker polls the counts' flag before falling back to a stream synchronize (default 2000; env MDQE_TRK_SPIN_US) */
 int mdqe_debug_trk_siou_blocks(int blocks);   /* tools/ only: blocks the tracker's sign-intersection launch aims at (0 = default 512) */
 int mdqe_debug_gemm_lds_pad(int bytes);   /* tools/ only: extra dynamic LDS per block of the K-step-16 GEMM launches (caps the blocks per CU) */
 /* tools/ only: window attention kernel form, 1 = MFMA where it applies (default), 0 = scalar everywhere. */
@@ -254,6 +256,16 @@ int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_saved, const 
 int mdqe_trk_accumulate_f32(float* sum, long sum_stride, float* cnt, long cnt_stride, const float* src,
                             long src_stride, long n, int nf, const int* r_host, const int* c_host, int count,
                             void* stream);
+/* siou_host (round 5): the same counts delivered to the HOST by the kernel itself -- one launch instead of memset + kernel +
+ * device->host copy + synchronize on the tracker's per-clip critical path (the `.cpu()` of OverTracker.py:159).  acc: device scratch
+ * of >= n_saved*n_in*3 floats, ZERO on entry and left zero; ticket: one device unsigned, zero on entry and left zero; out_host /
+ * flag_host: host-coherent pinned memory (hipHostMallocCoherent).  The block that finishes last copies the counts to out_host and
+ * stores `seq` in *flag_host with a system-scope release.  wait_flag: polls *flag_host == seq for at most spin_us microseconds, then
+ * falls back to a stream synchronize (kernel completion makes the stores visible in any case); MDQE_ELAUNCH if the flag never arrives. */
+int mdqe_trk_siou_host_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
+                           int n_in, long n, float* acc, unsigned* ticket, float* out_host, unsigned* flag_host,
+                           unsigned seq, void* stream);
+int mdqe_trk_wait_flag(const unsigned* flag_host, unsigned seq, int spin_us, void* stream);
 
 /* window flush, device half (OverTracker.get_result :195-225): window_mean: out[i,f,:] = sum[i,f0+f,:] / max(cnt[i,f0+f],1)
  * for i < n, f < nf (rows of `out` are nf frames apart).  carry: frames [src0, src0+k) of rows < n become frames [0,k) as
@@ -277,7 +289,8 @@ int mdqe_trk_carry_f32(float* sum, float* cnt, long hw, int mem_len, int n, int 
  *   overlap) -> pairs (bank row r_idx[k] <- clip instance c_idx[k]) and the frame range (s0, a, nf) of the memory write;
  *   result: window class scores out_cls [n,K], n, ln (frames emitted) and, unless is_last, re-bases the host state
  *   (carry_valid [n, mem_len-win] optional).  A stand-in bank (CPU tests) drives these three.
- * update: overlap + siou kernel + D2H + sync + decide + accumulate kernel for one clip.  bank_sum [max_inst, win+T, hw],
+ * update: overlap + counts (mdqe_trk_siou_host_f32 into buffers the object owns, then the flag wait; with MDQE_TRK_FAST=0 /
+ *   mdqe_debug_trk_fast(0): siou kernel + D2H + sync through counts_dev / counts_host) + decide + accumulate kernel for one clip.  bank_sum [max_inst, win+T, hw],
  *   bank_cnt [max_inst, win+T]; masks [n_in, frames, hw] rows inst_stride floats apart; counts_dev / counts_host (pinned):
  *   scratch of max_inst*n_in*3 floats.  update_many: the same for a run of clips (clip i: host rows row0[i].. of
  *   scores/cls_probs/embeds, masks[i] = HOST array of device pointers).

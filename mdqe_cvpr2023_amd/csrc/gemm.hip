@@ -357,7 +357,8 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   // K-step 16 (4+ blocks per CU) wins almost everywhere.  (Rounds 1-3: very deep-K convs on few rows kept the 32-wide step; with the
   // round-4 K loop and epilogue the K-step-16 kernel is ahead there too -- res5's 3x3 convs 419 against 460 us -- except on the one
   // narrow, few-row shape below: 139 against 146 us.)
-  if (g_gemm_variant == 1 || (g_gemm_variant == 2 && !(p.conv && p.K >= 2048 && p.K < 4096 && p.M <= 16384 && p.N <= 256))) {
+  // (the window-order A map of mdqe_gemm_nt_swin_f32 exists in the K-step-16 kernel only: never the K-step-32 form, whatever the debug variant)
+  if (p.swin_ws > 0 || g_gemm_variant == 1 || (g_gemm_variant == 2 && !(p.conv && p.K >= 2048 && p.K < 4096 && p.M <= 16384 && p.N <= 256))) {
     int rc = mdqe_launch_gemm_k16(p, tile, st);
     if (rc || p.ksplit <= 1) return rc;
     long nb = ((long)p.M * p.N + 255) / 256; if (nb > 2048) nb = 2048;

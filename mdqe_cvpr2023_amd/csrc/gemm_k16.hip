@@ -301,7 +301,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
       for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + rsub;
         f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * 32 + c4 * 4) + bv;
-        if (p.residual != nullptr) {
+        if (p.residual != nullptr && m0 + i * 32 + it * 8 < p.M) {  // (wave-uniform; a group wholly past M is never addressed, see the stores)
           const int so = (int)((((long)m0 + i * 32 + it * 8) * p.ldr + wn * 64 + j * 32) * 4);
           v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vR, so, 0));
         }
@@ -356,6 +356,11 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           vv[i][j][it] = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
+          // Rows past M: the scalar offset `so` carries the 8-row group's base, the lane offset vC the row within the group, and the buffer
+          // range check is `vC >= num_records - so` in unsigned arithmetic -- sound only while so < num_records.  A group that starts at or
+          // past row M (last tile of a ragged M) is therefore skipped by this wave-uniform branch instead of being left to the check; a
+          // group that straddles M has so < num_records and its lanes past M are dropped by the hardware.
+          if (m0 + i * 32 + it * 8 >= p.M) continue;
           const int so = (int)((((long)m0 + i * 32 + it * 8) * p.ldc + n - c4 * 4) * 4);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, vv[i][j][it]), rsC, vC, so, 0);
           __builtin_amdgcn_sched_barrier(0);                       // (store-data hazard, see the fast epilogue)
@@ -412,6 +417,7 @@ gemm_nt_f32_k16_kernel(const GemmParams p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
+            if (m0 + i * 32 + it * 8 >= p.M) continue;              // (as above: never rely on the range check with so >= num_records)
             const f32x4 y2 = (vv[i][j][it] - mean[i][it]) * rstd[i][it] * g + b;
             const int so = (int)((((long)m0 + i * 32 + it * 8) * p.ldc2 + n - c4 * 4) * 4);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y2), rsC2, vC2, so, 0);

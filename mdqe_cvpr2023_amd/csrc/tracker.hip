@@ -3,6 +3,7 @@
 // overlapping frame is sigmoid(sum/n_present) > 0.5 <=> sum > 0, so the hard-mask IoU of
 // OverTracker._get_siou (:92-113) only needs sign tests -- no 0/1 matrices are materialised.
 #include "common.h"
+#include <time.h>
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
 #pragma unroll
@@ -64,6 +65,100 @@ extern "C" int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_sa
   hipLaunchKernelGGL(trk_siou_kernel, dim3(n_in, n_saved, chunks), dim3(256), 0, st, saved, saved_stride, inp,
                      inp_stride, n, out3, n_in);
   return mdqe_launch_status();
+}
+
+// ---- the same counts, delivered to the HOST by the kernel itself (round 5) ---------------------------------------------------------
+// A tracker update is a chain of dependent steps on one stream -- counts -> host decision -> accumulate -> the next clip's counts -- and
+// on rank 0 of a sharded video that chain is the replay of every rank's clips (sharding.ReplayThread): its per-clip latency decides
+// how many ranks one root can serve.  Rounds 1-4 spent four stream operations per clip on the counts (memset, kernel, device->host copy,
+// stream synchronize).  Here it is ONE kernel: partial counts are added into `acc` (device, all zeros on entry) as before; the block
+// that finishes last (a ticket counter) moves the finished counts into `out_host` -- pinned, host-coherent memory -- leaves `acc` and
+// the ticket at zero for the next launch, and publishes `seq` in `flag_host` with a system-scope release.  The host polls the flag
+// (mdqe_trk_wait_flag: a bounded spin, then a stream synchronize, which makes the kernel's stores visible in any case).
+__global__ void __launch_bounds__(256)
+trk_siou_host_kernel(const float* __restrict__ saved, long saved_stride, const float* __restrict__ inp, long inp_stride,
+                     long n, float* __restrict__ acc, unsigned* __restrict__ ticket, float* __restrict__ out_host,
+                     unsigned* __restrict__ flag_host, unsigned seq, int n_in, int n_out) {
+  __shared__ float sh[4];
+  __shared__ int is_last;
+  const int i = blockIdx.y, j = blockIdx.x;
+  const long per = ((n / 4 + gridDim.z - 1) / gridDim.z) * 4;
+  const long k0 = (long)blockIdx.z * per, k1 = min(n, k0 + per);
+  const float* a = saved + (long)i * saved_stride;
+  const float* b = inp + (long)j * inp_stride;
+  float ci = 0.f, ca = 0.f, cb = 0.f;
+  for (long k = k0 + (long)threadIdx.x * 4; k < k1; k += 1024) {
+    const f32x4 va = *reinterpret_cast<const f32x4*>(a + k);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(b + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool pa = va[e] > 0.f, pb = vb[e] > 0.f;
+      ci += (pa && pb) ? 1.f : 0.f; ca += pa ? 1.f : 0.f; cb += pb ? 1.f : 0.f;
+    }
+  }
+  ci = block_sum(ci, sh); ca = block_sum(ca, sh); cb = block_sum(cb, sh);
+  if (threadIdx.x == 0) {
+    float* o = acc + ((long)i * n_in + j) * 3;
+    atomicAdd(o, ci); atomicAdd(o + 1, ca); atomicAdd(o + 2, cb);
+    __threadfence();                                               // the three adds are at the L2 before the ticket is
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    is_last = atomicAdd(ticket, 1u) == total - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  for (int k = threadIdx.x; k < n_out; k += blockDim.x) {
+    const float v = __hip_atomic_load(acc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (past the non-coherent L1)
+    out_host[k] = v;
+    acc[k] = 0.f;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *ticket = 0u;
+    __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// acc: >= n_saved*n_in*3 floats, ZERO on entry (left zero); ticket: one zero unsigned (left zero); out_host / flag_host: host-coherent
+// pinned memory.  After the launch `*flag_host == seq` means out_host holds the counts of this launch.
+extern "C" int mdqe_trk_siou_host_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
+                                      int n_in, long n, float* acc, unsigned* ticket, float* out_host, unsigned* flag_host,
+                                      unsigned seq, void* stream) {
+  MDQE_REQUIRE(n_saved > 0 && n_in > 0 && n > 0 && n % 4 == 0 && saved_stride % 4 == 0 && inp_stride % 4 == 0);
+  MDQE_CHECK_PTR(saved); MDQE_CHECK_PTR(inp); MDQE_CHECK_PTR(acc); MDQE_CHECK_PTR(ticket); MDQE_CHECK_PTR(out_host); MDQE_CHECK_PTR(flag_host);
+  MDQE_REQUIRE((((uintptr_t)saved | (uintptr_t)inp) & 15) == 0);
+  mdqe_clear_error();
+  int chunks = 1;
+  const long pairs = (long)n_saved * n_in;
+  const long target = g_trk_siou_blocks > 0 ? g_trk_siou_blocks : 512;
+  if (pairs < target) { chunks = (int)(target / pairs); const long maxc = (n / 4 + 1023) / 1024; if (chunks > maxc) chunks = (int)maxc; if (chunks < 1) chunks = 1; }
+  hipLaunchKernelGGL(trk_siou_host_kernel, dim3(n_in, n_saved, chunks), dim3(256), 0, (hipStream_t)stream, saved, saved_stride, inp,
+                     inp_stride, n, acc, ticket, out_host, flag_host, seq, n_in, (int)(pairs * 3));
+  return mdqe_launch_status();
+}
+
+// Wait until *flag_host == seq: poll for at most `spin_us` microseconds (the kernel's own release makes the counts visible), then fall
+// back to a stream synchronize (kernel completion makes every store visible whatever the memory's coherence mode).
+extern "C" int mdqe_trk_wait_flag(const unsigned* flag_host, unsigned seq, int spin_us, void* stream) {
+  MDQE_CHECK_PTR(flag_host);
+  const volatile unsigned* f = flag_host;
+  if (spin_us > 0) {
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long it = 0;; ++it) {
+      if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return MDQE_OK;
+      if ((it & 63) == 63) {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000 > spin_us) break;
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MDQE_ELAUNCH;
+  return __atomic_load_n(f, __ATOMIC_ACQUIRE) == seq ? MDQE_OK : MDQE_ELAUNCH;
 }
 
 struct TrkIdx { int r[128]; int c[128]; };

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <set>
 #include <vector>
@@ -159,6 +160,44 @@ struct Tracker {
     untracked.assign(max_inst, 0.f);
     embed_mem.assign((size_t)max_inst * E, 0.f);
   }
+
+  // ---- the counts' fast path (round 5, tracker.hip trk_siou_host_kernel): device accumulator + ticket (kept zero between launches) and
+  // host-coherent pinned memory for the finished counts + a sequence flag, owned by the object and created on the first update that
+  // needs counts (mdqe_tracker_create makes no HIP call: the CPU tests drive the host half alone).  MDQE_TRK_FAST=0 in the
+  // environment (or mdqe_debug_trk_fast(0)) keeps the four-step form (memset, kernel, copy, synchronize) -- same counts, same decisions.
+  float* acc_dev = nullptr;
+  unsigned* ticket_dev = nullptr;
+  float* counts_pin = nullptr;
+  unsigned* flag_pin = nullptr;
+  long acc_cap = 0;
+  unsigned seq = 0;
+
+  int ensure_fast(long need, hipStream_t st) {
+    if (need <= acc_cap) return MDQE_OK;
+    if (acc_dev != nullptr && hipStreamSynchronize(st) != hipSuccess) return MDQE_ELAUNCH;     // (a kernel may still use the old buffers)
+    release_fast();
+    long cap = 4096;
+    while (cap < need) cap *= 2;
+    if (hipMalloc((void**)&acc_dev, (size_t)cap * sizeof(float)) != hipSuccess) { acc_dev = nullptr; return MDQE_ELAUNCH; }
+    if (hipMalloc((void**)&ticket_dev, 64) != hipSuccess) { release_fast(); return MDQE_ELAUNCH; }
+    if (hipHostMalloc((void**)&counts_pin, (size_t)cap * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { counts_pin = nullptr; release_fast(); return MDQE_ELAUNCH; }
+    if (hipHostMalloc((void**)&flag_pin, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { flag_pin = nullptr; release_fast(); return MDQE_ELAUNCH; }
+    if (hipMemsetAsync(acc_dev, 0, (size_t)cap * sizeof(float), st) != hipSuccess || hipMemsetAsync(ticket_dev, 0, 64, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { release_fast(); return MDQE_ELAUNCH; }
+    *flag_pin = 0u;
+    acc_cap = cap;
+    return MDQE_OK;
+  }
+
+  void release_fast() {
+    if (acc_dev) (void)hipFree(acc_dev);
+    if (ticket_dev) (void)hipFree(ticket_dev);
+    if (counts_pin) (void)hipHostFree(counts_pin);
+    if (flag_pin) (void)hipHostFree(flag_pin);
+    acc_dev = nullptr; ticket_dev = nullptr; counts_pin = nullptr; flag_pin = nullptr; acc_cap = 0;
+  }
+
+  ~Tracker() { release_fast(); }
 
   // frames of the clip [f0, f0+nf_clip) already saved in this window: bank frame s0, clip frame a, count
   // set when a call failed AFTER part of its work reached the device bank (a kernel / copy error in the middle of an update or
@@ -362,6 +401,8 @@ struct Tracker {
 
 // device half (tracker.hip)
 extern "C" int mdqe_trk_siou_f32(const float*, long, int, const float*, long, int, long, float*, void*);
+extern "C" int mdqe_trk_siou_host_f32(const float*, long, int, const float*, long, int, long, float*, unsigned*, float*, unsigned*, unsigned, void*);
+extern "C" int mdqe_trk_wait_flag(const unsigned*, unsigned, int, void*);
 extern "C" int mdqe_trk_accumulate_f32(float*, long, float*, long, const float*, long, long, int, const int*, const int*, int, void*);
 extern "C" int mdqe_trk_window_mean_f32(const float*, const float*, long, int, int, int, long, float*, void*);
 extern "C" int mdqe_trk_carry_f32(float*, float*, long, int, int, int, long, float*, void*);
@@ -429,6 +470,12 @@ extern "C" int mdqe_tracker_result(void* handle, int is_last, float* out_cls, in
 // one small D2H + a stream sync: the assignment needs them), the decisions, the indexed accumulate.
 // bank_sum [max_inst, mem_len, hw], bank_cnt [max_inst, mem_len] (device); masks [n_in, mask_frames, hw] device fp32, rows
 // inst_stride floats apart; counts_dev / counts_host: scratch of >= max_inst*n_in*3 floats (device / pinned host).
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+static int g_trk_fast = env_int("MDQE_TRK_FAST", 1);          // 0: the counts by memset + kernel + copy + synchronize (rounds 1-4)
+static int g_trk_spin_us = env_int("MDQE_TRK_SPIN_US", 2000);  // how long the host polls the flag before it falls back to a stream synchronize
+extern "C" int mdqe_debug_trk_fast(int v) { g_trk_fast = v; return MDQE_OK; }
+extern "C" int mdqe_debug_trk_spin_us(int v) { g_trk_spin_us = v; return MDQE_OK; }
+
 static int tracker_update_one(Tracker* t, float* bank_sum, float* bank_cnt, long hw, int f0, int n_frames, int n_in,
                               const float* scores, const float* cls_probs, const float* embeds, const float* masks,
                               long inst_stride, float* counts_dev, float* counts_host, hipStream_t st) {
@@ -440,13 +487,26 @@ static int tracker_update_one(Tracker* t, float* bank_sum, float* bank_cnt, long
     if (rc != MDQE_OK) return rc;
     if (nf > 0 && n_in > 0) {
       const long bank_stride = (long)t->mem_len * hw;
-      int rc2 = mdqe_trk_siou_f32(bank_sum + (long)s0 * hw, bank_stride, ni, masks + (long)a * hw, inst_stride, n_in, (long)nf * hw,
-                                  counts_dev, st);
-      if (rc2 != MDQE_OK) return rc2;                                    // (read-only so far: the tracker is still consistent)
-      if (hipMemcpyAsync(counts_host, counts_dev, (size_t)ni * n_in * 3 * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess)
-        return MDQE_ELAUNCH;
-      if (hipStreamSynchronize(st) != hipSuccess) return MDQE_ELAUNCH;     // the one host sync of an update
-      c3 = counts_host;
+      if (g_trk_fast) {
+        // one kernel: counts -> host-coherent memory + a sequence flag; the host polls the flag (tracker.hip)
+        int rc2 = t->ensure_fast((long)ni * n_in * 3, st);
+        if (rc2 != MDQE_OK) return rc2;
+        const unsigned seq = ++t->seq;
+        rc2 = mdqe_trk_siou_host_f32(bank_sum + (long)s0 * hw, bank_stride, ni, masks + (long)a * hw, inst_stride, n_in, (long)nf * hw,
+                                     t->acc_dev, t->ticket_dev, t->counts_pin, t->flag_pin, seq, st);
+        if (rc2 != MDQE_OK) return rc2;                                  // (read-only so far: the tracker is still consistent)
+        rc2 = mdqe_trk_wait_flag(t->flag_pin, seq, g_trk_spin_us, st);    // the one host wait of an update
+        if (rc2 != MDQE_OK) { t->poisoned = true; return rc2; }          // (the accumulator / ticket may be left dirty)
+        c3 = t->counts_pin;
+      } else {
+        int rc2 = mdqe_trk_siou_f32(bank_sum + (long)s0 * hw, bank_stride, ni, masks + (long)a * hw, inst_stride, n_in, (long)nf * hw,
+                                    counts_dev, st);
+        if (rc2 != MDQE_OK) return rc2;                                  // (read-only so far: the tracker is still consistent)
+        if (hipMemcpyAsync(counts_host, counts_dev, (size_t)ni * n_in * 3 * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess)
+          return MDQE_ELAUNCH;
+        if (hipStreamSynchronize(st) != hipSuccess) return MDQE_ELAUNCH;   // the one host sync of an update
+        c3 = counts_host;
+      }
     }
   }
   const int rc = t->decide(f0, n_frames, n_in, scores, cls_probs, embeds, c3, c3 != nullptr, &s0, &a, &nf);

@@ -547,12 +547,18 @@ class Engine:
         return ops.layernorm(x2, *P.enc_norm).view(NI, N, C)
 
     # ---- a10: mask-feature head -------------------------------------------------------------------
-    def mask_features(self, enc, geo):
-        """models/mdqe.py:107-117 + segmentation.py:42-63 -> [NI, Hm, Wm, M] (channels-last)."""
+    def mask_features(self, enc, geo, out=None):
+        """models/mdqe.py:107-117 + segmentation.py:42-63 -> [NI, Hm, Wm, M] (channels-last).  out: a contiguous [NI, Hm, Wm, M] view (rows of
+        the frame cache) that the head's last product stores into directly -- no copy of the result."""
         with self.amp():
-            return self._mask_features(enc, geo)
+            return self._mask_features(enc, geo, out)
 
-    def _mask_features(self, enc, geo):
+    def mask_feature_shape(self, geo):
+        """(Hm, Wm, M) of one frame's mask features: the stride-8 level up-sampled x2 by the transposed depthwise conv."""
+        H, W = geo.shapes[0]
+        return 2 * H, 2 * W, int(self.P.mh.out_lay2.pw.shape[0])
+
+    def _mask_features(self, enc, geo, out=None):
         mh, cfg = self.P.mh, self.cfg
         NI, N, C = enc.shape
         lv = [enc[:, geo.starts[l]:geo.starts[l] + geo.hw[l]].view(NI, geo.shapes[l][0], geo.shapes[l][1], C) for l in range(3)]
@@ -569,29 +575,43 @@ class Engine:
         y = ops.groupnorm_nhwc(y, 32, o1.g, o1.beta, act="relu", out=y).view(x.shape)
         z = ops.dwconv5x5(y, o2.dw, o2.db, up2=True, tw=mh.tw, tb=mh.tb)
         Md = o2.pw.shape[0]
-        z2 = ops.linear(z.view(-1, C), o2.pw, o2.pb).view(NI, z.shape[1], z.shape[2], Md)
+        if out is not None and (tuple(out.shape) != (NI, z.shape[1], z.shape[2], Md) or not out.is_contiguous()):
+            raise RuntimeError("mask_features: out must be a contiguous [NI, Hm, Wm, M] tensor")
+        z2 = ops.linear(z.view(-1, C), o2.pw, o2.pb, out=None if out is None else out.view(-1, Md)).view(NI, z.shape[1], z.shape[2], Md)
         return ops.groupnorm_nhwc(z2, 32 if Md % 32 == 0 else 24, o2.g, o2.beta, act="relu", out=z2).view(z2.shape)
 
     # ---- a11 (per-frame part): grid-guided query selection + content sampling ---------------------
-    def _mlp(self, x, layers, last_act=None):
+    def _mlp(self, x, layers, last_act=None, out=None):
         n = len(layers)
         for i, (w, b) in enumerate(layers):
-            x = ops.linear(x, w, b, act="gelu" if i < n - 1 else last_act)
+            x = ops.linear(x, w, b, act="gelu" if i < n - 1 else last_act, out=out if i == n - 1 else None)
         return x
 
-    def frame_queries(self, enc, geo):
-        """transformer_dec.py:81-109,156-182 (everything before inter-frame association is per frame)."""
+    def frame_queries(self, enc, geo, out=None):
+        """transformer_dec.py:81-109,156-182 (everything before inter-frame association is per frame).  out: (coords [NI,Q,2], content
+        [NI,Q,C], emb [NI,Q,E]) contiguous views (rows of the frame cache) the three results are stored into directly."""
         cfg = self.cfg
         NI, N, C = enc.shape
         H, W = geo.shapes[0]
         nb = cfg.n_bins
+        o_coords, o_content, o_emb = out if out is not None else (None, None, None)
         with self.amp():
             conf = self._mlp(enc[:, :H * W].reshape(-1, C), self.P.rpn_cls).view(NI, H, W, -1)
-        coords = ops.query_select(conf, nb)                      # sigmoid-max, bilinear resize, per-cell first argmax
-        content = ops.sample_levels_mean(enc, coords, geo.shapes, geo.starts)               # [NI,Q,C]
+        coords = ops.query_select(conf, nb, out=o_coords)        # sigmoid-max, bilinear resize, per-cell first argmax
+        content = ops.sample_levels_mean(enc, coords, geo.shapes, geo.starts, out=o_content)               # [NI,Q,C]
         with self.amp():
-            emb = self._mlp(content.view(-1, C), self.P.track_embed).view(NI, nb * nb, -1)
+            emb = self._mlp(content.view(-1, C), self.P.track_embed, out=None if o_emb is None else o_emb.view(NI * nb * nb, -1)).view(NI, nb * nb, -1)
         return coords, content, emb
+
+    def cache_shapes(self, geo, keep_enc=False):
+        """Per-frame shapes of the frame cache (what a clip's decoder and inference_clip read of a frame): name -> shape."""
+        cfg, P = self.cfg, self.P
+        C, Q = cfg.hidden_dim, cfg.n_bins * cfg.n_bins
+        sh = {"vals": (geo.N, int(P.dec_vw.shape[0])), "coords": (Q, 2), "content": (Q, C), "emb": (Q, int(P.track_embed[-1][0].shape[0])),
+              "mf": self.mask_feature_shape(geo)}
+        if keep_enc:
+            sh["enc"] = (geo.N, C)
+        return sh
 
     def dec_values(self, enc, geo, out=None):
         """All decoder value_proj's (cross_attn + temp_attn_inst of every layer) for each frame, once:

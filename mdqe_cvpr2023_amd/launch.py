@@ -55,10 +55,16 @@ def main(argv=None):
         import signal
         import subprocess
         env = prepare_environment(dict(os.environ))
-        proc = subprocess.Popen([sys.executable, argv[0]] + argv[1:], env=env)
-        for sig in (signal.SIGINT, signal.SIGTERM):
-            signal.signal(sig, lambda s, f, p=proc: p.send_signal(s))
-        return proc.wait()
+        # The child is the script's own process tree (detectron2 `launch` / mp.spawn ranks below it).  It stays in the terminal's foreground
+        # process group, so a Ctrl-C reaches it ONCE, from the terminal; this parent ignores SIGINT and only forwards SIGTERM (which a
+        # supervisor sends to this pid alone).  Handlers are in place BEFORE the child exists: no window in which a signal kills the
+        # parent and orphans the ranks.
+        holder = {}
+        signal.signal(signal.SIGINT, signal.SIG_IGN)
+        signal.signal(signal.SIGTERM, lambda s, f: holder["p"].send_signal(s) if "p" in holder else sys.exit(128 + s))
+        proc = holder["p"] = subprocess.Popen([sys.executable, argv[0]] + argv[1:], env=env)
+        rc = proc.wait()
+        return 128 - rc if rc < 0 else rc                  # died by signal n: the shell convention 128 + n (sys.exit(-15) would be 241)
     prepare_environment()
     for p in (ROOT, SHIM):
         if p not in sys.path:

@@ -15,6 +15,7 @@ import contextlib
 import os
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -63,6 +64,8 @@ class MDQE(nn.Module):
         # frames per pass of the per-frame stages: 0 = by resolution (~300k encoder tokens per pass: at most 40 frames: 40 at 360p, 20 at 640p)
         self.frame_batch = int(os.environ.get("MDQE_FRAME_BATCH", "0"))
         self._trk_stream = None
+        # priority of the tracker's stream (0 normal, -1 high): its kernels are small and sit on the per-clip critical path of the replay
+        self.trk_priority = int(os.environ.get("MDQE_TRK_PRIORITY", "0"))
         self._frame_stream = None
         self._copy_stream = None
         self.resize_on_device = False               # True: frames arrive at native size and get the mapper's ResizeShortestEdge here
@@ -83,7 +86,10 @@ class MDQE(nn.Module):
         self.stage_times = None
         self.taper_passes = os.environ.get("MDQE_TAPER_PASSES", "1") != "0"   # half-size first / last frame pass (pipeline fill / drain)
         self.taper_tail = int(os.environ.get("MDQE_TAPER_TAIL", "0"))          # frames of the last pass (0: half a pass)
-        self.lookahead = max(1, int(os.environ.get("MDQE_LOOKAHEAD", "2")))   # frame passes queued ahead of the group being decoded
+        self.lookahead = max(1, int(os.environ.get("MDQE_LOOKAHEAD", "2")))   # groups whose frame passes are queued ahead of the one being decoded
+        # clips per decoder batch the planner waits for before it fixes a group (0: the clips ONE frame pass completes, rounds 2-4): the
+        # cache is per frame and the decoder reads it through index tables, so its batch is independent of the pass size
+        self.dec_batch = int(os.environ.get("MDQE_DEC_BATCH", "0"))
 
     # ---- checkpoint contract ---------------------------------------------------------------------
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -143,7 +149,7 @@ class MDQE(nn.Module):
         if self._frame_stream is None:
             self._frame_stream = torch.cuda.Stream(self.device)
         if self._trk_stream is None:
-            self._trk_stream = torch.cuda.Stream(self.device)
+            self._trk_stream = torch.cuda.Stream(self.device, priority=self.trk_priority)
         # a stream gets its hardware queue when it is first USED, not when it is created (unused foreign streams change nothing,
         # tools/stream_pad_ab.sh).  The pipeline's natural first-use order (copy, frame, tracker, between the high-priority streams'
         # first uses) is the best deal measured; MDQE_STREAM_TOUCH=1 instead touches [pads,] copy, frame, tracker here, in that order --
@@ -204,45 +210,50 @@ class MDQE(nn.Module):
                 return self.inference_image(batched_inputs)
             return self.inference_vis(batched_inputs)
 
+    def alloc_cache(self, frames, geo, keep_enc=False):
+        """An empty frame cache for `frames` frames: name -> [frames, ...] device buffer (engine.cache_shapes)."""
+        return {k: torch.empty((int(frames),) + tuple(sh), dtype=torch.float32, device=self.device)
+                for k, sh in self.engine.cache_shapes(geo, keep_enc).items()}
+
     def _frame_cache(self, frames, geo, ring=None, at=0, keep_enc=False, dec_ready=None):
-        """Per-frame stages a1-a11 for a batch of frames: everything a clip needs, computed once.  With `ring`
-        (preallocated per-frame buffers) the results land in ring[k][at:at+n] -- the 63 MB/frame decoder value
-        cache is written there directly by its GEMM.  keep_enc: the encoder tokens stay in the cache too (5.2 MB per frame;
-        a sharded video ships the tokens of a chunk's last T-1 frames to the neighbour, sharding._Halo).
+        """Per-frame stages a1-a11 for a batch of frames: everything a clip needs, computed once, stored IN PLACE into rows
+        [at, at+n) of the frame cache `ring` (name -> [capacity, ...] buffer; None: a cache of exactly these frames is allocated and
+        returned) -- the 63 MB/frame decoder value cache by its GEMM, the mask features by the mask head's last product, the query
+        coordinates / contents / embeddings by their kernels: no device-to-device copy of any result (round 5; rounds 2-4 copied the
+        mask features and the small tensors into the ring and carried T-1 frames from ring to ring).  keep_enc: the encoder tokens go
+        into the cache too (5.2 MB per frame; a sharded video ships the tokens of a chunk's last T-1 frames to the neighbour,
+        sharding._Halo).
         Order (round 4): what the DECODER reads -- query selection / content / embeddings and the value projections -- comes first and
         `dec_ready` (an event) is recorded behind it; the mask-feature head, which only `inference_clip` reads, runs after.  The decoder
         of a group can then start while the mask head of its last frame pass is still running: at the end of a video that pass has
         nothing else to overlap with, and the decoder's chain of small dependent launches is latency-bound."""
         eng = self.engine
         n = frames.shape[0]
+        ret = ring is None
+        if ring is None:
+            ring, at = self.alloc_cache(n, geo, keep_enc), 0
         feats = eng.backbone(frames, geo)
         enc = eng.encode(feats, geo)
         del feats
-        coords, content, emb = eng.frame_queries(enc, geo)
-        extra = (("enc", enc),) if keep_enc else ()
-        if ring is None:
-            vals = eng.dec_values(enc, geo)
-            if dec_ready is not None:
-                dec_ready.record(torch.cuda.current_stream(self.device))
-            return dict({"mf": eng.mask_features(enc, geo), "coords": coords, "content": content, "emb": emb, "vals": vals}, **dict(extra))
+        eng.frame_queries(enc, geo, out=(ring["coords"][at:at + n], ring["content"][at:at + n], ring["emb"][at:at + n]))
         eng.dec_values(enc, geo, out=ring["vals"][at:at + n])
-        for k, v in (("coords", coords), ("content", content), ("emb", emb)) + extra:
-            ring[k][at:at + n].copy_(v)
+        if "enc" in ring:
+            ring["enc"][at:at + n].copy_(enc)
         if dec_ready is not None:
             dec_ready.record(torch.cuda.current_stream(self.device))
-        ring["mf"][at:at + n].copy_(eng.mask_features(enc, geo))
-        return None
+        eng.mask_features(enc, geo, out=ring["mf"][at:at + n])
+        return ring if ret else None
 
     def _cache_from_tokens(self, enc, mf, geo, ring, at):
         """Cache entries of frames whose encoder tokens and mask features were computed elsewhere (a neighbour rank's halo):
         only query selection / content sampling and the decoder value projections are redone here."""
         eng = self.engine
         n = enc.shape[0]
-        coords, content, emb = eng.frame_queries(enc, geo)
+        eng.frame_queries(enc, geo, out=(ring["coords"][at:at + n], ring["content"][at:at + n], ring["emb"][at:at + n]))
         eng.dec_values(enc, geo, out=ring["vals"][at:at + n])
-        for k, v in (("mf", mf), ("coords", coords), ("content", content), ("emb", emb), ("enc", enc)):
-            if k in ring:
-                ring[k][at:at + n].copy_(v)
+        ring["mf"][at:at + n].copy_(mf)
+        if "enc" in ring:
+            ring["enc"][at:at + n].copy_(enc)
 
     @staticmethod
     def pass_bounds(n_frames, fbatch, taper=True, tail=0):
@@ -294,114 +305,115 @@ class MDQE(nn.Module):
                 break
         return clips
 
+    CACHE_GB = float(os.environ.get("MDQE_CACHE_GB", "24"))       # HBM budget of ONE frame-cache buffer (a long video uses two)
+
     def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None, h2d=None,
                           halo=None, side_streams=True, prime_all=True):
-        """Per-frame features (computed once, streamed in chunks of `frame_batch`) + decoder + inference_clip for
+        """Per-frame features (computed once, streamed in passes of `frame_batch` frames) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
         Two HIP streams: the per-frame stages (backbone .. decoder value cache: large GEMMs) of the next passes run on a frame
         stream while the decoder + inference_clip of group k (small kernels and two host syncs) run on the caller's
-        stream, so the matrix cores stay fed through the data-dependent part.  The frame cache is a ring of `lookahead + 1`
-        buffers (T-1 carried + frame_batch new frames each); events order their reuse."""
-        eng = self.engine
+        stream, so the matrix cores stay fed through the data-dependent part.
+
+        The frame cache (round 5) is ONE linear buffer per kind, row = frame: every pass stores its results in place at the rows of its
+        frames (`_frame_cache`) and a group of clips reads them through index tables (`starts`), so nothing is copied from buffer to
+        buffer -- no carried T-1 frames, no first fill -- and the decoder batch is free of the pass size (`dec_batch`).  A video
+        longer than the cache budget (MDQE_CACHE_GB per buffer, 24 GB = 360 frames at 360p) continues in a second buffer, to which the
+        frames still to be read are copied once per segment; the buffers then alternate, events order their reuse."""
+        eng, cfg = self.engine, self.cfg
         h, w = int(frames_dev.shape[-2]), int(frames_dev.shape[-1])
         geo = eng.geometry(h, w)
         n_local = frames_dev.shape[0]
         Tmax = max((c[1] - c[0] for c in clips), default=1)
+        Tn = cfg.n_frames_test
         fbatch = self.frame_batch if self.frame_batch > 0 else max(8, min(40, 306000 // max(geo.N, 1)))
-        cap = Tmax - 1 + fbatch
         # halo exchange (sharded videos, sharding._Halo): `clips` may START up to T-1 frames before this chunk; those clips read
-        # the LEFT neighbour's last T-1 frames, which arrive as encoder tokens + mask features and get their cache entries
-        # (with a copy of this chunk's first T-1) behind the frames of the last full-length group; in return the tokens of this
-        # chunk's last T-1 frames are handed to `halo.on_tail` as soon as the last pass is queued.
-        strad = []
+        # the LEFT neighbour's last T-1 frames, which arrive as encoder tokens + mask features and get their cache entries in the
+        # `lead` rows IN FRONT of this chunk's first frame (so a straddling clip's frames are consecutive rows); in return the tokens
+        # of this chunk's last T-1 frames are handed to `halo.on_tail` as soon as the last pass is queued.
+        strad, lead = [], 0
         if halo is not None:
-            Tn = self.cfg.n_frames_test
             strad = [c for c in clips if c[0] < frame_offset]
             clips = [c for c in clips if c[0] >= frame_offset]
             if any(c[1] - c[0] != Tn or c[0] < frame_offset - (Tn - 1) for c in strad) or not clips:
                 raise RuntimeError("halo exchange: a chunk must hold at least one whole clip and its straddling clips T frames")
-            cap += 2 * (Tn - 1)
-            own_first = {}
+            lead = Tn - 1 if strad else 0
         bounds = self.pass_bounds(n_local, fbatch, self.taper_passes, self.taper_tail)
-        if strad and bounds[0] < self.cfg.n_frames_test - 1:
-            raise RuntimeError("halo exchange: the first frame pass must cover the chunk's first T-1 frames")
         cuda = frames_dev.is_cuda
         clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
         if cuda and self._frame_stream is None:
             self._frame_stream = torch.cuda.Stream(frames_dev.device)
         fstream = (self._frame_stream if self.overlap_streams else clip_stream) if cuda else None
-        NR = max(2, self.lookahead + 1)           # rings: the group being decoded + `lookahead` frame passes queued behind it
-        rings = [None] * NR                       # slot -> {name: [cap, ...] buffer}
-        free_ev = [None] * NR                     # slot -> event: the clip work that read this ring has finished
+        fctx = (lambda: torch.cuda.stream(fstream)) if cuda else contextlib.nullcontext
+        dec_batch = max(0, int(self.dec_batch))   # clips per decoder batch the planner waits for (0: whatever one frame pass completes)
+        NR = max(2, self.lookahead + 1)           # groups prepared (their frame passes queued) ahead of the one being decoded + 1
+        # ---- cache capacity (frames): the whole chunk if the budget allows, else segments in two alternating buffers
+        shapes = eng.cache_shapes(geo, keep_enc=halo is not None)
+        per_frame = 4 * sum(int(np.prod(sh)) for sh in shapes.values())
+        forced = int(os.environ.get("MDQE_CACHE_FRAMES", "0"))                 # (tests / A-B: force short segments)
+        gframes = max(fbatch, dec_batch) + Tmax - 1 + fbatch                    # frames one group can span, passes rounded up
+        floor = lead + (NR + 1) * gframes                                       # what the groups in flight need at the very least
+        budget = forced if forced > 0 else int(self.CACHE_GB * 2 ** 30 // max(per_frame, 1))
+        want = n_local + lead
+        capf = min(want, max(budget, floor))
+        single = capf >= want
+        if single:
+            capf = -(-capf // 8) * 8              # (rounded: videos of similar length reuse the allocator's blocks)
+        elif halo is not None:
+            raise RuntimeError("halo exchange: a chunk (%d frames) must fit one frame-cache buffer (%d frames; MDQE_CACHE_GB)" % (n_local, capf))
+        bufs = [self.alloc_cache(capf, geo, keep_enc=halo is not None), None]
+        readers = [[], []]                        # buffer -> group states that read it
+        seg = {"b": 0, "base": 0, "lead": lead}   # row of local frame f in buffer b: f - base + lead
         nxt = 0                                   # local frames [0, nxt) have been through the per-frame stages
+        started = False
 
-        def prepare(ci, slot, prev):
-            """Frame cache for the clips starting at index ci, built in ring `slot` from the carried tail of `prev` (the
-            state of the other ring) + new frames; asynchronous on the frame stream.  Returns the state dict."""
-            nonlocal nxt
-            ls, le = clips[ci][0] - frame_offset, clips[ci][1] - frame_offset
-            ctx = torch.cuda.stream(fstream) if cuda else contextlib.nullcontext()
-            with ctx:
+        def switch_segment(ls):
+            """Continue in the other buffer, whose row 0 becomes local frame `ls` (the first frame a clip not yet planned reads):
+            frames [ls, nxt) are copied over once; the groups that read that buffer two segments ago have finished (events)."""
+            nb = 1 - seg["b"]
+            if bufs[nb] is None:
+                bufs[nb] = self.alloc_cache(capf, geo)
+            keep = nxt - ls
+            with fctx():
+                for st in readers[nb]:
+                    if "done" not in st:
+                        raise RuntimeError("frame cache: a buffer is needed again while a group still reads it (capacity %d frames)" % capf)
+                    if cuda and st["done"] is not None:
+                        fstream.wait_event(st["done"])
+                readers[nb] = []
+                if keep > 0:
+                    o = ls - seg["base"] + seg["lead"]
+                    for k, v in bufs[nb].items():
+                        v[:keep].copy_(bufs[seg["b"]][k][o:o + keep])
+            seg.update(b=nb, base=ls, lead=0)
+
+        def queue_pass():
+            """The next frame pass, asynchronous on the frame stream, stored in place at the rows of its frames."""
+            nonlocal nxt, started
+            c1 = next(b for b in bounds if b > nxt)
+            row = nxt - seg["base"] + seg["lead"]
+            with fctx():
                 if cuda:
-                    if prev is None and fstream is not clip_stream:
-                        fstream.wait_stream(clip_stream)           # the frames (and weights) were produced on the caller's stream
-                    if free_ev[slot] is not None:
-                        fstream.wait_event(free_ev[slot])
-                base, count = ls, 0
-                nxt_before = nxt
-                # what the DECODER reads of this state is complete (the mask features may still be on their way); not with the halo exchange,
-                # whose straddling clips rebuild cache rows on the clip stream
-                dec_ready = torch.cuda.Event() if cuda and self.early_decode and halo is None else None
-                if prev is not None:                               # carry frames [ls, prev end) -- never more than T-1
-                    keep = prev["base"] + prev["count"] - ls
-                    if keep > 0:
-                        if rings[slot] is None:
-                            rings[slot] = {k: torch.empty_like(v) for k, v in rings[prev["slot"]].items()}
-                        o = ls - prev["base"]
-                        for k, v in rings[slot].items():
-                            v[:keep].copy_(rings[prev["slot"]][k][o:o + keep])
-                        count = keep
-                if count == 0:
-                    nxt = max(nxt, ls)                             # CLIP_STRIDE > clip length: the frames between two clips are never read
-                while nxt < le:
-                    c1 = next(b for b in bounds if b > nxt)
-                    n_new = c1 - nxt
-                    if h2d:                                        # the upload chunks this pass reads (upload_frames)
+                    if not started and fstream is not clip_stream:
+                        fstream.wait_stream(clip_stream)               # the frames (and weights) were produced on the caller's stream
+                    if h2d:                                            # the upload chunks this pass reads (upload_frames)
                         for end, ev in h2d:
                             if end > nxt:
                                 fstream.wait_event(ev)
                             if end >= c1:
                                 break
-                    if rings[slot] is None:
-                        first = self._frame_cache(frames_dev[nxt:c1], geo, keep_enc=halo is not None)
-                        rings[slot] = {k: torch.empty((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for k, v in first.items()}
-                        for k, v in first.items():
-                            rings[slot][k][count:count + n_new].copy_(v)
-                        del first
-                        if dec_ready is not None:                  # (a ring's first fill copies everything at the end: nothing is early)
-                            dec_ready.record(fstream)
-                    else:
-                        self._frame_cache(frames_dev[nxt:c1], geo, ring=rings[slot], at=count, keep_enc=halo is not None, dec_ready=dec_ready)
-                    if halo is not None and strad and nxt == 0:        # this chunk's first T-1 frames: the straddling clips read them
-                        for k, v in rings[slot].items():
-                            own_first[k] = v[count:count + Tn - 1].clone()
-                    count += n_new
-                    nxt = c1
-                if halo is not None and nxt >= n_local and tail_state["views"] is None and not halo.tail_sent:
-                    k_t = min(Tn - 1, count)
-                    tail_state["views"] = (rings[slot]["enc"][count - k_t:count], rings[slot]["mf"][count - k_t:count])
-                    tail_state["ev"] = torch.cuda.Event() if cuda else None
-                    if cuda:
-                        tail_state["ev"].record(fstream)
+                started = True
+                # what the DECODER reads of this pass is complete (the mask features may still be on their way); not with the halo exchange,
+                # whose straddling clips write cache rows on the clip stream
+                dr = torch.cuda.Event() if cuda and self.early_decode and halo is None else None
+                self._frame_cache(frames_dev[nxt:c1], geo, ring=bufs[seg["b"]], at=row, dec_ready=dr)
                 ready = None
                 if cuda:
                     ready = torch.cuda.Event()
                     ready.record(fstream)
-                    if dec_ready is not None and nxt == nxt_before:   # no new frame pass (carried rows only): the copies above are all there is
-                        dec_ready = None
-            return {"slot": slot, "base": base, "count": count, "ready": ready, "dec_ready": dec_ready, "covered": nxt, "new_frames": nxt - nxt_before,
-                    "cache": {k: v[:count] for k, v in rings[slot].items()}}
+            nxt = c1
+            return {"end": c1, "ready": ready, "dec_ready": dr}
 
         def frames_queued():
             """Once, when the LAST frame of this video has been queued on the frame stream: a caller that streams videos
@@ -420,36 +432,73 @@ class MDQE(nn.Module):
             a rank's operations in issue order, would deadlock against a rank that queued it after."""
             if halo is None or halo.tail_sent or tail_state["views"] is None:
                 return
-            if not tail_state["consuming"]:       # (guard for future edits: calling this from plan_next / prepare / the priming loop hangs ranks)
+            if not tail_state["consuming"]:       # (guard for future edits: calling this from plan_next / the priming loop hangs ranks)
                 raise RuntimeError("halo exchange: send_tail() while the generator is being primed -- the grouped send/recv must be "
                                    "issued between the gathers of two rounds on every rank")
-            ctx = torch.cuda.stream(fstream) if cuda else contextlib.nullcontext()
-            with ctx:
+            with fctx():
                 if cuda:
                     fstream.wait_event(tail_state["ev"])
                 halo.on_tail(*tail_state["views"])
 
         from collections import deque
-        states = deque()                          # prepared (queued on the frame stream) and not yet decoded, in clip order
-        plan = {"ci": 0, "k": 0, "last": None}
+        states = deque()                          # prepared (their frames queued on the frame stream) and not yet decoded, in clip order
+        plan = {"ci": 0}
 
         def plan_next():
-            """Queue the frame passes of the next group of clips (ring k mod NR) and fix the group: every further clip of the
-            same length whose frames are then cached joins the batch -- clips are independent through the decoder, so they run
-            as ONE pass (M = clips*T*Q rows)."""
+            """Fix the next group of clips and queue the frame passes it still needs: the group starts at the first clip not yet
+            planned, the planner queues passes until `dec_batch` clips (at least one) are complete, and every further clip of the same
+            length whose frames are then cached joins the batch -- clips are independent through the decoder, so they run as ONE pass
+            (M = clips*T*Q rows)."""
+            nonlocal nxt
             ci = plan["ci"]
             if ci >= len(clips):
                 return False
-            st = prepare(ci, plan["k"] % NR, plan["last"])
+            off = frame_offset
             T = clips[ci][1] - clips[ci][0]
+            ls = clips[ci][0] - off
+            if ls > nxt:
+                nxt = ls                          # CLIP_STRIDE > clip length: the frames between two clips are never read
+            k = ci
+            while k + 1 < len(clips) and k + 1 - ci < max(dec_batch, 1) and clips[k + 1][1] - clips[k + 1][0] == T:
+                k += 1
+            target = clips[k][1] - off
+            end = nxt
+            while end < target:
+                end = next(b for b in bounds if b > end)
+            if end - seg["base"] + seg["lead"] > capf:
+                switch_segment(ls)
+            nxt_before = nxt
+            passes = []
+            while nxt < end:
+                passes.append(queue_pass())
+            rows = nxt - seg["base"] + seg["lead"]
+            b = seg["b"]
+            if halo is not None and nxt >= n_local and tail_state["views"] is None and not halo.tail_sent:
+                k_t = min(Tn - 1, n_local)
+                tail_state["views"] = (bufs[b]["enc"][rows - k_t:rows], bufs[b]["mf"][rows - k_t:rows])
+                tail_state["ev"] = passes[-1]["ready"] if passes else None
+                if cuda and tail_state["ev"] is None:
+                    tail_state["ev"] = torch.cuda.Event()
+                    tail_state["ev"].record(fstream)
             j = ci
-            while j < len(clips) and clips[j][1] - frame_offset <= st["covered"] and clips[j][1] - clips[j][0] == T:
+            while j < len(clips) and clips[j][1] - off <= nxt and clips[j][1] - clips[j][0] == T:
                 j += 1
-            st["i"], st["j"], st["T"] = ci, j, T
-            plan["ci"], plan["k"], plan["last"] = j, plan["k"] + 1, st
+            ready = passes[-1]["ready"] if passes else None
+            if cuda and ready is None:            # no new pass (rows of earlier passes, maybe copied by a segment switch): all that is queued so far
+                ready = torch.cuda.Event()
+                with fctx():
+                    ready.record(fstream)
+            st = {"b": b, "base": seg["base"], "lead": seg["lead"], "i": ci, "j": j, "T": T, "ready": ready,
+                  "dec_ready": passes[-1]["dec_ready"] if passes else None, "new_frames": nxt - nxt_before, "rows": rows,
+                  "cache": {k_: v[:rows] for k_, v in bufs[b].items()}}
+            readers[b].append(st)
+            plan["ci"] = j
             states.append(st)
             frames_queued()
             return True
+
+        def rows_of(st, group):
+            return [c[0] - frame_offset - st["base"] + st["lead"] for c in group]
 
         plan_next()
         if primed:
@@ -462,7 +511,7 @@ class MDQE(nn.Module):
             yield None                            # per-frame work of the first passes is queued; the caller resumes later
         tail_state["consuming"] = True            # from here on the caller has gathered the previous round: the exchange may be issued
         while states:
-            # `lookahead` passes are queued BEFORE this group's clip work: with one, the frame stream ran dry at every group
+            # `lookahead` groups' passes are queued BEFORE this group's clip work: with one, the frame stream ran dry at every group
             # boundary -- the clip kernels share the chip with the pass queued behind them and finish together with it, and
             # the next pass was only queued after the host had consumed the group (2-3 ms of whole-GPU idle per boundary in
             # the HIP trace, tools/trace_gaps.py)
@@ -470,22 +519,18 @@ class MDQE(nn.Module):
                 pass
             send_tail()
             cur = states.popleft()
-            cache, base, T = cur["cache"], cur["base"], cur["T"]
+            cache, T = cur["cache"], cur["T"]
             group = clips[cur["i"]:cur["j"]]
             dr = cur.get("dec_ready") if cuda else None
             if cuda:
                 clip_stream.wait_event(dr if dr is not None else cur["ready"])
-            starts = [c[0] - frame_offset - base for c in group]
+            starts = rows_of(cur, group)
             if strad and T == Tn and (cur["j"] >= len(clips) or clips[cur["j"]][1] - clips[cur["j"]][0] != Tn):
-                # the last full-length group of the chunk: the straddling clips join it.  Cache rows [count, count + 2(T-1)) of
-                # its ring = [the left neighbour's last T-1 frames | this chunk's first T-1 frames]
-                ring, cnt = rings[cur["slot"]], cur["count"]
+                # the last full-length group of the chunk: the straddling clips join it.  Cache rows [0, T-1) = the left neighbour's
+                # last T-1 frames, directly in front of this chunk's first frame
                 enc_h, mf_h = halo.head()                      # (waits for the neighbour's message on this stream)
-                self._cache_from_tokens(enc_h, mf_h, geo, ring, cnt)
-                for k, v in own_first.items():
-                    ring[k][cnt + Tn - 1:cnt + 2 * (Tn - 1)].copy_(v)
-                cache = {k: v[:cnt + 2 * (Tn - 1)] for k, v in ring.items()}
-                starts = starts + [cnt + c[0] - (frame_offset - (Tn - 1)) for c in strad]
+                self._cache_from_tokens(enc_h, mf_h, geo, bufs[cur["b"]], 0)
+                starts = starts + rows_of(cur, strad)
                 group = group + strad
                 strad = []
             outs = cur.pop("outs", None)
@@ -510,10 +555,9 @@ class MDQE(nn.Module):
                 if self._ahead_stream is None:
                     self._ahead_stream = torch.cuda.Stream(frames_dev.device, priority=-1)
                 aux = self._ahead_stream
-                aux.wait_event(nx["ready"])                        # its frames (the pass this group waits for too) + its ring's carried rows
+                aux.wait_event(nx["ready"])                        # its frames (the pass this group waits for too)
                 with torch.cuda.stream(aux):
-                    g2 = clips[nx["i"]:nx["j"]]
-                    nx["outs"] = eng.decode_clips(nx["cache"], [c[0] - frame_offset - nx["base"] for c in g2], nx["T"], geo)
+                    nx["outs"] = eng.decode_clips(nx["cache"], rows_of(nx, clips[nx["i"]:nx["j"]]), nx["T"], geo)
             if dr is not None:
                 clip_stream.wait_event(cur["ready"])               # the mask features of the group's last pass (inference_clip reads them)
             ress = eng.inference_clips(outs, cache["mf"], starts, T)
@@ -521,7 +565,7 @@ class MDQE(nn.Module):
             if cuda:
                 ready = torch.cuda.Event()
                 ready.record(clip_stream)         # the clip results are complete once this event fires
-                free_ev[cur["slot"]] = ready      # ... and ring `slot` may be overwritten
+            cur["done"] = ready                   # ... and the group no longer reads its buffer
             for gi, ((start, end, last), res) in enumerate(zip(group, ress)):
                 if trace is not None:
                     trace.append({k_: v.clone() for k_, v in res.items() if torch.is_tensor(v)})
@@ -852,7 +896,7 @@ class ClipMerger:
         self.use_side = self.dev.type == "cuda"
         self.main = torch.cuda.current_stream(self.dev) if self.use_side else None
         if self.use_side and model._trk_stream is None:
-            model._trk_stream = torch.cuda.Stream(self.dev)
+            model._trk_stream = torch.cuda.Stream(self.dev, priority=getattr(model, "trk_priority", 0))
         self.side = model._trk_stream if self.use_side else None
         self.side_is_current = False                # set by sharding.ReplayThread in its own thread
         self.saved, self.tracker = 0, None

@@ -430,25 +430,34 @@ def mha_small(qk, v, B, Q, C, nh, out=None):
     return out
 
 
-def query_select(conf, nb):
-    """conf [NI,H,W,K] -> coords [NI, nb*nb, 2]."""
+def query_select(conf, nb, out=None):
+    """conf [NI,H,W,K] -> coords [NI, nb*nb, 2] (out: a contiguous tensor of that shape to store into)."""
     _chk(conf, "conf")
     NI, H, W, K = conf.shape
     ws = torch.empty(NI * H * W, dtype=torch.float32, device=conf.device)
-    coords = torch.empty(NI, nb * nb, 2, dtype=torch.float32, device=conf.device)
+    if out is not None:
+        _chk(out, "out")
+        if tuple(out.shape) != (NI, nb * nb, 2):
+            raise RuntimeError("query_select: out must be [NI, nb*nb, 2]")
+    coords = out if out is not None else torch.empty(NI, nb * nb, 2, dtype=torch.float32, device=conf.device)
     check(lib.mdqe_query_select_f32(ptr(conf), NI, H, W, K, nb, ptr(ws), ptr(coords), cur_stream()), "query_select")
     return coords
 
 
-def sample_levels_mean(tokens, coords, shapes, starts):
-    """tokens [NI,N,C], coords [NI,Q,2] -> [NI,Q,C]."""
+def sample_levels_mean(tokens, coords, shapes, starts, out=None):
+    """tokens [NI,N,C], coords [NI,Q,2] -> [NI,Q,C] (out: a contiguous tensor of that shape to store into)."""
     import ctypes
     _chk(tokens, "tokens"); _chk(coords, "coords")
     NI, N, C = tokens.shape
     Qn = coords.shape[1]
     n = len(shapes)
     arr = lambda v: (ctypes.c_int * n)(*[int(x) for x in v])
-    out = torch.empty(NI, Qn, C, dtype=torch.float32, device=tokens.device)
+    if out is None:
+        out = torch.empty(NI, Qn, C, dtype=torch.float32, device=tokens.device)
+    else:
+        _chk(out, "out")
+        if tuple(out.shape) != (NI, Qn, C):
+            raise RuntimeError("sample_levels_mean: out must be [NI, Q, C]")
     check(lib.mdqe_sample_levels_mean_f32(ptr(tokens), NI, N, C, ptr(coords), Qn, arr([s[0] for s in shapes]), arr([s[1] for s in shapes]),
                                           arr(starts), n, ptr(out), cur_stream()), "sample_levels_mean")
     return out

@@ -163,6 +163,7 @@ class ReplayThread:
         if device.type == "cuda":
             self.dev_index = device.index if device.index is not None else torch.cuda.current_device()
         self.q = queue.Queue()
+        self.busy_s = 0.0                          # host seconds this worker spent replaying (tracker + window flushes), for `stats`
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
@@ -179,12 +180,14 @@ class ReplayThread:
                     items = self.q.get()
                     if items is None:
                         return
+                    t0 = time.perf_counter()
                     fm = getattr(self.merger, "feed_many", None)
                     if fm is not None:
                         fm(items)                  # runs of clips between window flushes: one native tracker call each
                     else:
                         for it in items:
                             self.merger.feed(*it)
+                    self.busy_s += time.perf_counter() - t0
         except BaseException as e:                     # surfaced by finish()
             self.err = e
 
@@ -206,6 +209,34 @@ class ReplayThread:
         """The producer failed: stop the worker, keep the producer's exception."""
         self.q.put(None)
         self.t.join()
+
+
+def expand_root_load(merged, q, plan, vworld, T):
+    """The N = `vworld` ROOT LOAD on one GPU (bench.py MDQE_BENCH_ROOT_LOAD): `merged` holds the clip results of chunk q*vworld -- rank
+    0's own chunk of round q in the plan of a `vworld`-rank job -- and the return value is the round as rank 0 of that job would have
+    gathered it: the clips of chunks q*vworld .. q*vworld+vworld-1 in global clip order, where a foreign chunk repeats rank 0's own
+    results under its own frame indices (clip k of chunk g takes the instances of clip k of rank 0's chunk; a chunk at the end of the
+    video with fewer / shorter clips takes the first ones, trimmed in time).  The tracker replay, the bank updates, the window flushes,
+    the final-mask kernel and the device->host copies of the masks then carry the volume of the N-rank job while rank 0 computes its own
+    chunks; what the rehearsal cannot show is the wire (the foreign payloads never cross xGMI) and the other ranks' pace."""
+    g0 = q * vworld
+    own = {s: (s, e, l, r) for s, e, l, r in merged}
+    own_clips = plan[g0][0]
+    if [c[0] for c in own_clips] != sorted(own):
+        raise RuntimeError("expand_root_load: the gathered round is not rank 0's chunk %d of the plan" % g0)
+    out = []
+    for g in range(g0, min(g0 + vworld, len(plan))):
+        for k, (s, e, l) in enumerate(plan[g][0]):
+            src = own[own_clips[min(k, len(own_clips) - 1)][0]][3]
+            if g == g0:
+                out.append((s, e, l, src))
+                continue
+            r = dict(src)
+            if e - s != src["pred_masks"].shape[1]:
+                r["pred_masks"] = src["pred_masks"][:, :e - s].contiguous()
+            r.pop("rows", None)
+            out.append((s, e, bool(l), r))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -263,7 +294,7 @@ def owned_chunks(plan, world, rank):
 
 
 def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, like=None,
-                    stats=None):
+                    stats=None, vworld=None):
     """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
     Default: every rank all-gathers each round and replays the tracker (all ranks return the video result;
     emit_masks=False skips the mask production on ranks that only keep the tracker in step).
@@ -271,7 +302,7 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
     its main thread goes on with the next round; the other ranks only compute and send, and return None.
     `like`: any [.., h, w] tensor on the frames' device -- needed by a rank that owns NO chunk of this video (more ranks than chunks)."""
     return next(run_round_robin_stream(model, [(chunk_frames, plan, like) if like is not None else (chunk_frames, plan)], rank, world, dist, out_size,
-                                       emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange, stats=stats))
+                                       emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange, stats=stats, vworld=vworld))
 
 
 _HALO_GROUPS = {}
@@ -388,7 +419,8 @@ class _Job:
             if root_only:
                 self.replay = ReplayThread(self.merger, self.device)
         self.rounds = (len(plan) + world - 1) // world
-        self.tm = {"compute": 0.0, "pack": 0.0, "gather_wait": 0.0, "gather_payload": 0.0, "feed": 0.0, "replay_exposed": 0.0}
+        self.tm = {"compute": 0.0, "pack": 0.0, "gather_wait": 0.0, "gather_payload": 0.0, "feed": 0.0, "replay_exposed": 0.0, "replay_busy": 0.0}
+        self.replay_busy = 0.0
 
     def start(self, q):
         """Queue the per-frame work of this rank's chunk of round q (async); the returned generator yields its clip results."""
@@ -438,7 +470,9 @@ class _Job:
 
     def finish(self):
         if self.replay is not None:
-            return self.replay.finish()
+            out = self.replay.finish()
+            self.replay_busy = self.replay.busy_s
+            return out
         return self.merger.finish() if self.merger is not None else None
 
     def abort(self):
@@ -455,7 +489,8 @@ def halo_recompute_frac(plan, L):
     return sum(f1 - f0 for _, f0, f1 in plan) / float(max(L, 1)) - 1.0
 
 
-def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, stats=None):
+def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, stats=None,
+                           vworld=None):
     """Videos as a stream through the round-robin schedule.  jobs: iterable of (chunk_frames, plan[, like]) as for
     run_round_robin (`like`: any [.., h, w] tensor on the device, for a rank that owns no chunk of a short video); yields each video's result in order (None on the ranks that do not replay).  Within a video the next round's per-frame
     work is queued before this round's clip work; ACROSS videos the first round of video k+1 is queued before the last round's
@@ -465,13 +500,19 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     stats: a list; one dict of host milliseconds per video is appended on every rank -- `compute` (queueing a round's per-frame work +
     consuming its clip results: ends with the host sync behind the round's last clip kernel), `pack` / `gather_wait` / `gather_payload`
     (all_gather_clips: `gather_wait` is the wait for the slowest rank of a round), `feed` (handing the round to the tracker or its
-    replay thread), `replay_exposed` (joining the replay + the video merge after the last gather: what no later round hides), `rounds`."""
+    replay thread), `replay_exposed` (joining the replay + the video merge after the last gather: what no later round hides),
+    `replay_busy` (the replay worker's busy time: tracker + window flushes of every round), `rounds`.
+    vworld (one rank only): the root-load rehearsal -- `plan` is the plan of a `vworld`-rank job, this rank computes rank 0's chunks of it
+    and every gathered round is expanded to the `vworld` chunks rank 0 of that job would replay (expand_root_load)."""
+    if vworld is not None and (world != 1 or rank != 0 or halo_exchange):
+        raise ValueError("the root-load rehearsal runs on ONE rank, without the halo exchange")
+    pworld = vworld if vworld is not None else world   # the world the chunks are dealt to
     it = iter(jobs)
     ws = getattr(model, "work_stream", contextlib.nullcontext)      # the model's high-priority stream (no context is held across a yield)
 
     def open_next():
         j = next(it, None)
-        return None if j is None else _Job(model, j[0], j[1], rank, world, out_size, emit_masks, root_only,
+        return None if j is None else _Job(model, j[0], j[1], rank, pworld, out_size, emit_masks, root_only,
                                            like=j[2] if len(j) > 2 else None, dist=dist, halo_exchange=halo_exchange)
 
     def finish(j):
@@ -480,6 +521,7 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
             out = j.finish()
         if stats is not None:
             j.tm["replay_exposed"] = time.perf_counter() - t0
+            j.tm["replay_busy"] = j.replay_busy
             stats.append({k: 1e3 * v for k, v in j.tm.items() if k != "rounds"} | {"rounds": j.rounds})
         return out
 
@@ -502,6 +544,8 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
                     t_c = time.perf_counter()
                     tg = {}
                     merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank, timing=tg)
+                    if vworld is not None:
+                        merged = expand_root_load(merged, q, job.plan, vworld, job.T)
                     t_g = time.perf_counter()
                     job.feed(merged)
                     tm = job.tm

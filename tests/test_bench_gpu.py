@@ -36,7 +36,39 @@ def test_bench_line_contract():
     # 24 frames = one pass: 18.3 MB of algorithmic bytes per frame and layer at 360p
     assert abs(rm["algorithmic_MB_per_launch"] / 24 - 18.28) < 0.1
     for k in ("decoder_box", "decoder_temporal"):
-        assert 0.0 < rm[k]["frac"] < 1.0 and rm[k]["launches_timed"] >= 1
+        # on UNIQUE value bytes (a batch of stride-1 clips shares a frame's map T ways): nothing may exceed the HBM roof, in the pipeline or alone
+        assert 0.0 < rm[k]["frac"] < 1.0 and 0.0 < rm[k]["frac_isolated"] < 1.0 and rm[k]["launches_timed"] >= 1
+        pc = rm[k]["bytes_per_clip_convention"]
+        assert pc["MB_per_launch"] >= rm[k]["algorithmic_MB_per_launch"] and "frac" not in pc
+    # mean and median of the per-step times, and which one `value` is
+    assert d["value_median"] > 0 and abs(d["value_median"] / d["value"] - 1) < 0.25 and d["value_is"].startswith("mean")
+    assert d["bench_wall_s"] > 0 and "degraded" not in d
+
+
+def test_bench_side_configs_and_root_load_ride_in_the_same_line():
+    """The default invocation's extra legs at reduced size: BASELINE.json configs[2] / configs[3] (`config_R50_ovis_720`, `config_swinl_ovis`) and
+    the N = 8 root-load rehearsal (`root_load`) are keys of the SAME line as the headline, each with its own roofline objects / breakdown, and
+    the headline keeps its contract."""
+    env = dict(os.environ, MDQE_BENCH_SIDE_CONFIGS="1", MDQE_BENCH_ROOT_LOAD_LEG="8", MDQE_BENCH_SIDE_FRAMES="12", MDQE_BENCH_SIDE_STEPS="1",
+               MDQE_BENCH_SIDE_S="300", MDQE_BENCH_ROOT_LOAD_S="300")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "36", "--no-cpu-baseline", "--no-fast-mode"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert "degraded" not in d and abs(d["value"] - 36 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    for key, cfgname in (("config_R50_ovis_720", "R50_ovis_720"), ("config_swinl_ovis", "swinl_ovis")):
+        e = d[key]
+        assert "error" not in e, e
+        assert e["value"] > 0 and e["frames_per_step"] == 12 and e["steps"] == 1 and cfgname in e["workload"] and e["dtype"] == "f32"
+        assert abs(e["value"] - 12 * 1e3 / e["ms_per_step"]) < 1e-6 * e["value"]
+        assert 0.0 < e["roofline"]["frac"] < 1.0 and e["roofline"]["peak"] == 157.3 and 0.0 < e["roofline_msda"]["frac"] < 1.0
+        assert e["instances_out"] >= 1
+    rl = d["root_load"]
+    assert "error" not in rl, rl
+    assert rl["world"] == 8 and rl["frames_virtual"] == 8 * 36 and rl["ms_per_step"] > 0 and 0.0 < rl["predicted_efficiency"] <= 1.05
+    assert rl["replay_total_ms"] >= rl["sharded_world1"]["replay_total_ms"] and rl["compute"] > 0 and rl["tracked_instances"] >= 1
 
 
 def test_bench_gpus_2_runs_two_ranks_without_torchrun():

@@ -177,7 +177,7 @@ def test_encoder_msda_at_pass_size_equals_per_frame_launches(shapes, B):
 
 
 @pytest.mark.parametrize("tool,args", [("fuzz_msda.py", ["21"]), ("fuzz_msda_fused.py", ["20"]), ("fuzz_inference_clip.py", ["20"]),
-                                       ("fuzz_tracker.py", ["20", "--gpu"]), ("fuzz_pipeline.py", ["4"])])
+                                       ("fuzz_tracker.py", ["20", "--gpu"]), ("fuzz_pipeline.py", ["12"])])
 def test_fuzz_seeds(tool, args):
     """The first seeds of tools/fuzz_*.py (the long runs: profiles/r02_fuzz_*.txt): native MSDA op vs the oracle, fused MSDA forms vs each
     other, batched inference_clip vs the oracle's per-clip restatement, the tracker on the HIP bank vs the oracle's, the whole driver vs the

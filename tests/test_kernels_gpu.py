@@ -438,6 +438,47 @@ def test_linear_layernorm_fused():
         assert out2.data_ptr() == rc.data_ptr() and torch.equal(out2, out)
 
 
+def test_linear_layernorm_never_touches_rows_past_m():
+    """The LayerNorm epilogue stores through buffer resources whose scalar offset carries the row group: with a ragged M the last tile's
+    groups past row M must not be written (or read) at all -- the engine passes `out=x2`, ring views and C2 buffers whose neighbours are
+    live tensors.  out, residual and C2 are `[:M]` views of larger canary-filled buffers, M % 64 in {1, 27, 37, 63}: the canary rows
+    behind M stay bit for bit what they were, rows below M equal the launch on exact-size tensors."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(77)
+    CANARY = 12345.678
+    for M, K in ((16384 + 27, 256), (16384 + 37, 1024), (16384 * 2 + 1, 256), (16384 + 63, 256)):
+        pad = 192                                              # three tiles of canary rows behind M
+        x = torch.randn(M, K, device="cuda", generator=g); w = torch.randn(256, K, device="cuda", generator=g) / K ** 0.5
+        b = torch.randn(256, device="cuda", generator=g)
+        g1, b1 = torch.randn(256, device="cuda", generator=g), torch.randn(256, device="cuda", generator=g)
+        g2, b2 = torch.rand(256, device="cuda", generator=g) + 0.5, torch.randn(256, device="cuda", generator=g)
+        r_exact = torch.randn(M, 256, device="cuda", generator=g)
+        want1, want2 = ops.linear_ln(x, w, b, r_exact.clone(), g1, b1, second=(g2, b2))
+        for second in (None, (g2, b2)):
+            big_r = torch.full((M + pad, 256), CANARY, device="cuda"); big_r[:M] = r_exact
+            big_o = torch.full((M + pad, 256), CANARY, device="cuda")
+            res = ops.linear_ln(x, w, b, big_r[:M], g1, b1, out=big_o[:M], second=second)
+            o1 = res if second is None else res[0]
+            assert torch.equal(o1, want1) and bool((big_o[M:] == CANARY).all()) and bool((big_r[M:] == CANARY).all()), (M, K, second is not None)
+            if second is not None:
+                assert torch.equal(res[1], want2)
+            # in place over the residual view (the encoder's `out=x2`)
+            res = ops.linear_ln(x, w, b, big_r[:M], g1, b1, out=big_r[:M], second=second)
+            o1 = res if second is None else res[0]
+            assert torch.equal(o1, want1) and bool((big_r[M:] == CANARY).all()), (M, K, "in place")
+    # C2 as a view of a canary buffer: through the C ABI (ops.linear_ln allocates C2 itself)
+    from mdqe_cvpr2023_amd._lib import check, cur_stream, lib, ptr
+    M, K = 16384 + 27, 256
+    x = torch.randn(M, K, device="cuda", generator=g); w = torch.randn(256, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(256, device="cuda", generator=g); r = torch.randn(M, 256, device="cuda", generator=g)
+    want1, want2 = ops.linear_ln(x, w, b, r.clone(), g1, b1, second=(g2, b2))
+    big_o = torch.full((M + 192, 256), CANARY, device="cuda"); big_2 = torch.full((M + 192, 256), CANARY, device="cuda")
+    check(lib.mdqe_gemm_ln2_f32(ptr(x), K, ptr(w), ptr(b), ptr(big_o), 256, M, 256, K, ptr(r), 256, ptr(g1), ptr(b1), ptr(g2), ptr(b2),
+                                ptr(big_2), 256, 1e-5, cur_stream()), "gemm_ln2_f32")
+    assert torch.equal(big_o[:M], want1) and torch.equal(big_2[:M], want2)
+    assert bool((big_o[M:] == CANARY).all()) and bool((big_2[M:] == CANARY).all())
+
+
 def test_linear_layernorm_with_a_second_layernorm_in_the_epilogue():
     """mdqe_gemm_ln2_f32 (round 4): `x = norm3(x + ffn(x))` and the shared `decoder_norm(x)` that feeds the box head
     (transformer_dec.py:352-358,492-495) from ONE epilogue.  The first output equals mdqe_gemm_ln_f32's and the second equals

@@ -52,6 +52,36 @@ def test_two_stream_schedule_is_bit_identical_to_single_stream(frame_batch):
     assert len(a["pred_masks"]) > 0 and a["pred_masks"][0].shape == (17, 96, 160)
 
 
+@pytest.mark.parametrize("frame_batch,dec_batch,cache_frames", [(3, 0, 0), (3, 0, 1), (2, 7, 1), (6, 20, 0), (0, 40, 0), (4, 1, 1)])
+def test_linear_frame_cache_segments_and_decoder_batch_do_not_change_a_bit(frame_batch, dec_batch, cache_frames, monkeypatch):
+    """Round 5's frame cache: one linear buffer per kind, results stored in place, the decoder batch independent of the pass size
+    (`dec_batch` clips per batch).  A video longer than the cache continues in a second buffer (segments; MDQE_CACHE_FRAMES=1 forces the
+    smallest capacity the schedule allows, so a 41-frame video switches buffers several times).  Same kernels on the same rows whatever
+    the grouping: every output bit equals the default schedule's, and the clip results equal it clip by clip."""
+    cfg, model = _small_model()
+    frames = _video(41).cuda()
+    inp = [{"image": frames, "height": 96, "width": 160}]
+    ref = model(inp)
+    clips = model.clip_schedule(41, cfg.n_frames_test, cfg.clip_stride)
+    with torch.no_grad():
+        ref_clips = [(s, e, l, {k: v.clone() for k, v in r.items() if torch.is_tensor(v)}) for s, e, l, r in model.iter_clip_results(frames, clips, 0)]
+    model.frame_batch, model.dec_batch = frame_batch, dec_batch
+    if cache_frames:
+        monkeypatch.setenv("MDQE_CACHE_FRAMES", str(cache_frames))
+    out = model(inp)
+    _same(ref, out)
+    _same(out, model(inp))
+    with torch.no_grad():
+        got = list(model.iter_clip_results(frames, clips, 0))
+    assert [(s, e, l) for s, e, l, _ in got] == [(s, e, l) for s, e, l, _ in ref_clips]
+    for (_, _, _, a), (_, _, _, b) in zip(ref_clips, got):
+        for k in ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks"):
+            assert torch.equal(a[k], b[k]), k
+    if dec_batch:                                       # the planner waited for dec_batch clips: the first batch holds at least that many
+        first = next(i for i, (_, _, _, r) in enumerate(got) if r["batch_end"]) + 1
+        assert first >= min(dec_batch, len(clips) - 1)
+
+
 def test_early_masks_equal_the_direct_path():
     """ClipMerger with n_frames (masks produced per window into pinned memory) vs without (one pass at the end)."""
     cfg, model = _small_model()

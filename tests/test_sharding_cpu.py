@@ -250,7 +250,7 @@ def stream_worker(rank, world, port, outdir, root_only, lengths=None):
     # the per-video timing breakdown bench.py gathers into `scaling_breakdown`: one entry per video on EVERY rank
     assert len(stats) == len(jobs)
     for st, (_, plan, _) in zip(stats, jobs):
-        assert set(st) == {"compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed", "rounds"}
+        assert set(st) == {"compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed", "replay_busy", "rounds"}
         assert st["rounds"] == -(-len(plan) // world) and all(v >= 0 for v in st.values())
     torch.save((outs, order, log), os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
@@ -436,3 +436,33 @@ def test_halo_ring_on_its_own_process_group(tmp_path):
     assert sorted(seen) == [1, 2, 3, 4, 5]
     for g, (e, m, es, ms_) in seen.items():
         assert e == float(g - 1) and m == float(g - 1) + 0.5 and es == (3, 5, 4) and ms_ == (3, 2, 3, 2), (g, e, m)
+
+
+def test_root_load_expansion_is_the_round_rank_0_of_an_n_rank_job_would_gather():
+    """sharding.expand_root_load (bench.py MDQE_BENCH_ROOT_LOAD / the line's `root_load`): rank 0's own chunk of round q of an 8-rank plan is
+    expanded to the 8 chunks of that round -- every clip of the plan exactly once, in global order, with the plan's frame ranges and `last`
+    flags; foreign clips carry rank 0's instances (the short clips at the end of the video trimmed in time); replayed by the tracker core,
+    the expanded rounds consume the whole virtual video."""
+    T, W, per = CFG.n_frames_test, 8, 12
+    sizes = sharding.round_sizes(per, T, smallest=3)
+    assert len(sizes) >= 2 and sum(sizes) == per
+    Lv = per * W
+    plan = sharding.chunk_plan(Lv, T, 1, sizes, world=W)
+    rounds = -(-len(plan) // W)
+    seen = []
+    for q in range(rounds):
+        g0 = q * W
+        own = [(s, e, l, fake_result(s, e)) for s, e, l in plan[g0][0]]
+        out = sharding.expand_root_load(own, q, plan, W, T)
+        want = [c for g in range(g0, min(g0 + W, len(plan))) for c in plan[g][0]]
+        assert [(s, e, l) for s, e, l, _ in out] == want
+        for (s, e, l, r), k in zip(out, range(len(out))):
+            assert r["pred_masks"].shape[1] == e - s and r["pred_masks"].shape[0] == len(r["scores"])
+        assert all(a[3] is b[3] for a, b in zip(out, own))            # rank 0's own clips are handed on untouched
+        seen += out
+    assert [(s, e, l) for s, e, l, _ in seen] == clip_schedule(Lv, T, 1)
+    outs = replay(seen)
+    assert sum(m.shape[1] for _, m in outs) == Lv                      # every frame of the virtual video came out of a window flush
+    import pytest
+    with pytest.raises(RuntimeError):
+        sharding.expand_root_load([(1, 4, False, fake_result(1, 4))], 0, plan, W, T)

@@ -81,3 +81,39 @@ def test_hip_tracker_equals_the_oracle_on_random_sequences(many):
     import fuzz_tracker
     for seed in (82, 99, 284, 286, 0, 1, 2, 3, 4, 5, 6, 7):
         assert fuzz_tracker.run(seed, gpu=True, many=many) is None, seed
+
+
+@pytest.mark.parametrize("fast,spin_us", [(1, 2000), (1, 0), (0, 0)])
+def test_counts_fast_path_classic_path_and_sync_fallback_agree(fast, spin_us):
+    """Round 5: an update takes its sign-intersection counts through ONE kernel that delivers them to host-coherent memory and raises a
+    flag the host polls (mdqe_trk_siou_host_f32 / mdqe_trk_wait_flag) instead of memset + kernel + copy + synchronize.  The same recorded
+    reference sequence and random sequences through (a) the fast path, (b) the fast path with a zero spin budget -- the wait falls back to
+    a stream synchronize at once -- and (c) the classic path: identical decisions and window results; and the counts themselves equal the
+    classic kernel's on a crafted pair of banks, launch after launch on the same accumulator (left zero by the kernel)."""
+    import os, sys
+    import ctypes
+    from mdqe_cvpr2023_amd._lib import check, cur_stream, lib, ptr
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_tracker
+    lib.mdqe_debug_trk_fast(fast); lib.mdqe_debug_trk_spin_us(spin_us)
+    try:
+        for mode in ("per_clip", "runs"):
+            test_hip_tracker_matches_reference_sequence(mode)
+        for seed in (82, 284, 0, 1, 2):
+            assert fuzz_tracker.run(seed, gpu=True, many=True) is None, seed
+    finally:
+        lib.mdqe_debug_trk_fast(1); lib.mdqe_debug_trk_spin_us(2000)
+    if fast and spin_us:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        acc = torch.zeros(4096, device="cuda"); ticket = torch.zeros(16, dtype=torch.int32, device="cuda")
+        out_h = torch.zeros(4096, pin_memory=True); flag = torch.zeros(16, dtype=torch.int32, pin_memory=True)
+        for seq, (ns, ni, n) in enumerate([(3, 5, 4 * 96 * 160), (7, 7, 3 * 96 * 160), (1, 1, 1024), (12, 2, 4 * 1000)], start=1):
+            a = torch.randn(ns, n, device="cuda", generator=g); b = torch.randn(ni, n, device="cuda", generator=g)
+            want = torch.zeros(ns * ni * 3, device="cuda")
+            check(lib.mdqe_trk_siou_f32(ptr(a), n, ns, ptr(b), n, ni, n, ptr(want), cur_stream()), "siou")
+            check(lib.mdqe_trk_siou_host_f32(ptr(a), n, ns, ptr(b), n, ni, n, ptr(acc), ptr(ticket), out_h.data_ptr(), flag.data_ptr(), seq, cur_stream()),
+                  "siou_host")
+            check(lib.mdqe_trk_wait_flag(flag.data_ptr(), seq, 100000, cur_stream()), "wait_flag")
+            assert int(flag[0]) == seq and torch.equal(out_h[:ns * ni * 3], want.cpu())
+            torch.cuda.synchronize()
+            assert not bool(acc.any()) and int(ticket[0]) == 0          # left clean for the next launch

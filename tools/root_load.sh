@@ -1,0 +1,21 @@
+#!/bin/bash
+# The N = 2 / 4 / 8 ROOT-LOAD rehearsal on one GPU (bench.py MDQE_BENCH_ROOT_LOAD, sharding.expand_root_load): rank 0 of an N-rank job computes its
+# own 120 frames per step while its replay thread is fed the clips of all N ranks.  One bench line per N -> gpurun_out/root_load_N.json (the
+# summaries judged are copied to profiles/r05_root_load_N.json).      bash tools/root_load.sh [worlds...]
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+for w in "${@:-1 2 4 8}"; do
+  for ww in $w; do
+    MDQE_BENCH_ROOT_LOAD=$ww python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-fast-mode > gpurun_out/root_load_$ww.json 2> gpurun_out/root_load_$ww.err
+    python - "$ww" <<'P'
+import json, sys
+w = sys.argv[1]
+d = json.load(open("gpurun_out/root_load_%s.json" % w))
+sb = d["scaling_breakdown"]["per_rank_ms"]
+print("root load %s: %.1f frames/s per rank, %.1f ms/step; compute %.1f replay_busy %.1f replay_exposed %.1f gather %.1f tracks %s" % (
+    w, d["value"], d["ms_per_step"], sb["compute"][0], sb["replay_busy"][0], sb["replay_exposed"][0], sb["gather_wait"][0] + sb["gather_payload"][0],
+    d["config"]["tracked_instances"]), flush=True)
+P
+  done
+done
