@@ -367,6 +367,14 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def round_ratio(world):
+    """Chunk-size ratio of consecutive rounds (sharding.round_sizes): rank 0 replays round q -- world x the clips of a chunk, ~0.1 ms each in
+    the pipeline -- under the compute of round q+1 -- ~1.25 ms per frame -- so a round may shrink to 0.08 x world of the one before and
+    still hide its replay; the fewer ranks, the steeper the decrease (and the fewer rounds).  MDQE_BENCH_ROUND_RATIO overrides."""
+    v = os.environ.get("MDQE_BENCH_ROUND_RATIO")
+    return float(v) if v else min(0.7, max(0.3, 0.08 * world))
+
+
 class EmitOnce:
     """The ONE JSON line of a run: whoever calls first -- the main thread at the end, or a soft deadline's timer thread -- prints it; a
     second call is a no-op (a deadline that fires while the main thread is already printing must not produce a second line)."""
@@ -520,6 +528,12 @@ def main():
         print("bench.py: MDQE_BENCH_ROOT_LOAD is a one-rank rehearsal (WORLD_SIZE=%d)" % world, file=sys.stderr)
         sys.exit(2)
     sharded = world > 1 or os.environ.get("MDQE_BENCH_FORCE_SHARDED") == "1" or root_load > 0
+    # HIP deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue is served in order.  The pipeline runs
+    # seven streams (frame, clip, instance chain, decode-ahead, copy, tracker, + RCCL's when sharded): with 4 queues the tracker's per-clip
+    # kernels of rank 0's replay sit behind the frame stream's GEMMs (N = 8 root-load rehearsal: 188.7 -> 177.4 ms per step with 8 queues,
+    # profiles/r05_ab_hw_queues.txt); the single-GPU path is unchanged within noise (818 / 807 vs 824 / 806 frames/s).  Set before the HIP
+    # runtime starts; an explicit value in the environment wins.  mdqe_cvpr2023_amd.launch sets the same default for the reference's scripts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if one_dev:
         local = 0
     if not probe:
@@ -594,7 +608,7 @@ def main():
     chunk = None
     if sharded or vworld:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
-        chunk = sharding.round_sizes(args.frames, T) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
+        chunk = sharding.round_sizes(args.frames, T, ratio=round_ratio(pworld)) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
 
     def shard(halo, n_frames=None, chunk_=None, seed=0, vw=None):
         pw = vw or world
@@ -737,7 +751,17 @@ def main():
 
     st_main = [] if sharded else None
     steps_ms = []
+    import ctypes
+    trk_times = (ctypes.c_double * 5)()
+    trk_timing = rank == 0 and (sharded or os.environ.get("MDQE_BENCH_TRK_TIMES") == "1")
+    if trk_timing:
+        _lib.load_library().mdqe_debug_trk_times(None, 1)          # host seconds inside the native tracker updates of the timed steps
     dt, out = timed(args.precision, True, step_ms=steps_ms, **({"stats": st_main} if sharded else {}))
+    if trk_timing:
+        _lib.load_library().mdqe_debug_trk_times(trk_times, 0)
+        if not sharded:
+            print("tracker native ms per step: counts launch %.2f, counts wait %.2f, decision %.2f, accumulate launch %.2f; %d updates"
+                  % tuple([1e3 * trk_times[i] / args.steps for i in range(4)] + [int(trk_times[4] / args.steps)]), file=sys.stderr, flush=True)
     g_timed, m_timed = meter.summary(), meter.msda_summary()
     breakdown = None
     if sharded:
@@ -751,6 +775,10 @@ def main():
                              "the replay worker's busy time over the whole video (tracker, window flushes, final masks); halo_frac = per-frame work "
                              "done twice"}
         pr = breakdown["per_rank_ms"]
+        if rank == 0 and trk_times[4] > 0:
+            breakdown["tracker_native_ms_per_step"] = {k: round(1e3 * trk_times[i] / args.steps, 2) for i, k in
+                                                       enumerate(("counts_launch", "counts_wait", "decision", "accumulate_launch"))}
+            breakdown["tracker_native_ms_per_step"]["updates_per_step"] = int(trk_times[4] / args.steps)
         breakdown["replay_exposed_ms"] = pr["replay_exposed"][0]
         breakdown["gather_ms"] = round(max(a + b for a, b in zip(pr["gather_wait"], pr["gather_payload"])), 2)
     # The same launches with the streams serialized (one extra UNTIMED step): in the timed region the dominant GEMM shares
@@ -794,6 +822,17 @@ def main():
                                                     "fp32) with its fp16 regions on the f16x3 split-precision kernels (operand error 2^-21, fp32 accumulate / in / "
                                                     "out) and its fp32 regions exact; same 1e-3 bars against the fp32 CPU oracle (tests/test_fullsize_gpu.py). "
                                                     "The headline stays exact fp32 EVERYWHERE, i.e. stricter than the reference's GPU path")
+        if args.precision == "f32" and not sharded:
+            model.precision_map = "autocast_f16"
+            d, _ = timed("f32", False)
+            model.precision_map = ""
+            extra["autocast_f16"] = dict(rate(d), what="the reference's GPU arithmetic, measured (never the headline): the regions its harness runs under fp16 "
+                                                       "autocast (train_net.py:207: backbone, input_proj, the embed MLPs, the mask head) on ONE f16 MFMA pass -- operands "
+                                                       "rounded to nearest f16, fp32 accumulation, fp32 results (the reference stores fp16 there) -- where the constant "
+                                                       "weight has planes and the product fills the 128-row tile, exact fp32 elsewhere; encoder, decoder and MSDA exact fp32",
+                                         margins_ref="profiles/r05_parity_margins.txt, group 'R50_ovis_360 6x360x640 autocast f16 ...': per-stage error against the "
+                                                     "fp32 CPU oracle at full size (tests/test_fullsize_gpu.py::test_r50_ovis_360_full_size_autocast_f16_margins); NOT "
+                                                     "held to the 1e-3 bar")
         if not sharded:
             res = torch.stack(host_frames).cuda()
             d, _ = timed(args.precision, False, resident=res)
@@ -912,7 +951,7 @@ def main():
                                   timeout=datetime.timedelta(seconds=60), **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
             dist, made = d_, True
         try:
-            chunk_ = sharding.round_sizes(args.frames, T)
+            chunk_ = sharding.round_sizes(args.frames, T, ratio=round_ratio(W))
             res = {"world": W, "frames_per_rank": args.frames, "frames_virtual": args.frames * W, "chunk_frames_per_round": chunk_}
             base = {}
             for key, vw in (("w1", None), ("wN", W)):
@@ -967,6 +1006,7 @@ def main():
                        "merge_on_cpu": bool(cfg.merge_on_cpu), "early_masks": bool(model.early_masks),
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "ranks_seen": ranks_seen, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
                        "parallelism": ("%d ranks counted by all-reduce; 1 process/GPU;" % ranks_seen + " %s-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
                                        "clip results to rank 0, whose native tracker replay runs on a worker thread under the next round"

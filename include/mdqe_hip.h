@@ -137,16 +137,21 @@ int mdqe_gemm_nt_side_f32(const float* A, long lda, const float* W, const float*
                           const float* side, const float* side_w, int side_cols, const void* w_split, void* stream);
 
 /* GEMM arithmetic of the 128x128 tile (process-wide): 0 = exact fp32 MFMA (default), 1 = "f16x3": operands split
- * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752). */
+ * in-kernel into f16 hi + scaled f16 lo, three f16 MFMAs with fp32 accumulation (~1e-6 relative to fp32; |x| < 32752);
+ * 2 = "f16" (round 5): ONE f16 MFMA pass -- both operands rounded to nearest f16, fp32 accumulation, fp32 result -- on the
+ * products whose constant weight has planes (mdqe_f16x3_split_f32) and that fill the 128-row tile, exact fp32 everywhere
+ * else: the arithmetic of the reference's fp16-autocast regions on a GPU (train_net.py:207) with an fp32 instead of an fp16
+ * result (operand error 2^-11 relative; |x| < 65504).  Never the default and never the headline mode. */
 int mdqe_set_gemm_precision(int mode);
 int mdqe_get_gemm_precision(void);   /* the mode the CALLING thread's launches use (its override if set, else the process-wide one) */
-/* The calling host thread's override of the mode: 0 / 1, or -1 = none (follow the process-wide mode).  Lets one region of the model --
+/* The calling host thread's override of the mode: 0 / 1 / 2, or -1 = none (follow the process-wide mode).  Lets one region of the model --
  * the regions the reference's harness runs under fp16 autocast (train_net.py:207) -- take the split-precision kernels
  * while another host thread's launches (the sharded schedule's tracker replay) keep theirs. */
 int mdqe_set_gemm_precision_thread(int mode);
 
 /* One-time split of a CONSTANT weight tensor W (n = N*K fp32 values, row-major [N][K]) into the two f16 planes the
- * f16x3 mode consumes: planes = { hi[n], lo[n] } (4*n bytes), hi = f16_rtz(w), lo = f16_rtz((w - hi) * 2048).
+ * f16x3 mode consumes + the one mode 2 consumes: planes = { hi[n], lo[n], rn[n] } (6*n bytes), hi = f16_rtz(w),
+ * lo = f16_rtz((w - hi) * 2048), rn = f16_rne(w).
  * Passing the planes as `w_split` to mdqe_gemm_nt_f32 / mdqe_conv2d_nhwc_f32 (NULL = none) lets mode 1 stream them
  * straight into LDS (gemm_f16x3w.hip: 128 x 256 tiles, no in-kernel weight conversion); requires K % 32 == 0 and
  * max|w| < 32752 (f16 range, caller-checked).  Ignored in mode 0.  Weights are constants of the eval path (nn.Linear / conv
@@ -166,6 +171,7 @@ int mdqe_debug_gemm_stages(int v);   /* K-step-16 kernel, 64x64 and smaller tile
 int mdqe_debug_msda_dec_stage_kb(int kb);   /* tools/ only: LDS staging budget of the decoder's box-level deformable launch (default 72: two blocks per CU) */
 int mdqe_debug_trk_fast(int on);            /* tests / tools: 1 (default; env MDQE_TRK_FAST) = a tracker update takes its counts through mdqe_trk_siou_host_f32, 0 = memset + kernel + copy + synchronize */
 int mdqe_debug_trk_spin_us(int us);         /* how long the tracker polls the counts' flag before falling back to a stream synchronize (default 2000; env MDQE_TRK_SPIN_US) */
+int mdqe_debug_trk_times(double* out5, int on);   /* tools: host seconds of the tracker updates since the last call -- counts launch, counts wait, decision, accumulate launch, updates -- then reset; on != 0 keeps timing */
 int mdqe_debug_trk_siou_blocks(int blocks);   /* tools/ only: blocks the tracker's sign-intersection launch aims at (0 = default 512) */
 int mdqe_debug_gemm_lds_pad(int bytes);   /* tools/ only: extra dynamic LDS per block of the K-step-16 GEMM launches (caps the blocks per CU) */
 /* tools/ only: window attention kernel form, 1 = MFMA where it applies (default), 0 = scalar everywhere. */
@@ -258,14 +264,14 @@ int mdqe_trk_accumulate_f32(float* sum, long sum_stride, float* cnt, long cnt_st
                             void* stream);
 /* siou_host (round 5): the same counts delivered to the HOST by the kernel itself -- one launch instead of memset + kernel +
  * device->host copy + synchronize on the tracker's per-clip critical path (the `.cpu()` of OverTracker.py:159).  acc: device scratch
- * of >= n_saved*n_in*3 floats, ZERO on entry and left zero; ticket: one device unsigned, zero on entry and left zero; out_host /
- * flag_host: host-coherent pinned memory (hipHostMallocCoherent).  The block that finishes last copies the counts to out_host and
- * stores `seq` in *flag_host with a system-scope release.  wait_flag: polls *flag_host == seq for at most spin_us microseconds, then
- * falls back to a stream synchronize (kernel completion makes the stores visible in any case); MDQE_ELAUNCH if the flag never arrives. */
+ * of >= n_saved*n_in*3 floats, ZERO on entry and left zero; ticket: one device unsigned, zero on entry and left zero; out_host:
+ * >= n_saved*n_in*3 64-bit words of host-coherent pinned memory (hipHostMallocCoherent).  The block that finishes last stores word k =
+ * (seq << 32 | float bits of count k), seq != 0.  wait_counts: polls until every word carries seq (at most spin_us microseconds, then a
+ * stream synchronize: kernel completion makes the stores visible in any case) and unpacks the counts; MDQE_ELAUNCH if they never arrive. */
 int mdqe_trk_siou_host_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
-                           int n_in, long n, float* acc, unsigned* ticket, float* out_host, unsigned* flag_host,
+                           int n_in, long n, float* acc, unsigned* ticket, unsigned long long* out_host,
                            unsigned seq, void* stream);
-int mdqe_trk_wait_flag(const unsigned* flag_host, unsigned seq, int spin_us, void* stream);
+int mdqe_trk_wait_counts(const unsigned long long* out_host, int n_out, unsigned seq, int spin_us, float* counts, void* stream);
 
 /* window flush, device half (OverTracker.get_result :195-225): window_mean: out[i,f,:] = sum[i,f0+f,:] / max(cnt[i,f0+f],1)
  * for i < n, f < nf (rows of `out` are nf frames apart).  carry: frames [src0, src0+k) of rows < n become frames [0,k) as

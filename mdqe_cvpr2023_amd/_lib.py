@@ -69,8 +69,9 @@ SIGNATURES = {
     "mdqe_debug_gemm_stages": [i],
     "mdqe_debug_gemm_lds_pad": [i],
     "mdqe_debug_trk_siou_blocks": [i],
-    "mdqe_trk_siou_host_f32": [p, l, i, p, l, i, l, p, p, p, p, i, p],
-    "mdqe_trk_wait_flag": [p, i, i, p],
+    "mdqe_trk_siou_host_f32": [p, l, i, p, l, i, l, p, p, p, i, p],
+    "mdqe_trk_wait_counts": [p, i, i, i, p, p],
+    "mdqe_debug_trk_times": [p, i],
     "mdqe_debug_trk_fast": [i],
     "mdqe_debug_trk_spin_us": [i],
     "mdqe_debug_msda_dec_stage_kb": [i],

@@ -291,19 +291,19 @@ extern "C" int mdqe_debug_gemm_rows_dot(int v) { g_gemm_rows_dot = v; return MDQ
 static int g_gemm_variant = 2;         // fp32 kernel form: 0 = K-step 32 (gemm.hip), 1 = K-step 16 (gemm_k16.hip), 2 = by shape
 extern "C" int mdqe_debug_gemm_variant(int v) { g_gemm_variant = v; return MDQE_OK; }
 
-static int g_gemm_precision_all = 0;  // 0: exact fp32 MFMA; 1: f16x3 split on the 128-row tiles (gemm_f16x3.hip) -- process-wide
+static int g_gemm_precision_all = 0;  // 0: exact fp32 MFMA; 1: f16x3 split on the 128-row tiles (gemm_f16x3.hip); 2: ONE f16 pass where the weight has planes -- process-wide
 // The calling THREAD's override (-1 = none): a region of the model (the reference's autocast regions, engine.Engine.amp) switches
 // the mode for its own launches without changing what another host thread -- the sharded schedule's tracker replay -- launches
 // meanwhile.  Every reader below goes through the macro.
 static thread_local int tl_gemm_precision = -1;
 #define g_gemm_precision (tl_gemm_precision >= 0 ? tl_gemm_precision : g_gemm_precision_all)
 extern "C" int mdqe_set_gemm_precision(int mode) {
-  if (mode != 0 && mode != 1) return MDQE_EINVAL;
+  if (mode != 0 && mode != 1 && mode != 2) return MDQE_EINVAL;
   g_gemm_precision_all = mode;
   return MDQE_OK;
 }
 extern "C" int mdqe_set_gemm_precision_thread(int mode) {
-  if (mode != -1 && mode != 0 && mode != 1) return MDQE_EINVAL;
+  if (mode != -1 && mode != 0 && mode != 1 && mode != 2) return MDQE_EINVAL;
   tl_gemm_precision = mode;
   return MDQE_OK;
 }
@@ -318,7 +318,7 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   // problems -- the decoder's 21168-row GEMMs, res4/res5 3x3 convs -- run 15-30 % faster on 64x64 tiles (8 waves/SIMD).
   if (tile == 0) {
     const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (g_gemm_precision == 1 && p.Wh != nullptr && b128 >= 192 && p.N > 64) tile = 1;      // f16x3w has its own tiling
+    if (g_gemm_precision != 0 && p.Wh != nullptr && b128 >= 192 && p.N > 64) tile = 1;      // f16x3w / f16w have their own tiling
     else if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
     else if ((g_gemm_tile_rule & 1) && b128 >= 2000 && p.N >= 1024 && p.N < 2048 && p.K <= 256 && !p.conv) tile = 9;   // short K, wide N -> 64x128
     else if ((g_gemm_tile_rule & 2) && p.conv && p.KH == 3 && b128 < 2000 && b128 >= 400 && p.N >= 256 && p.K < 4096) tile = 9;   // mid-grid 3x3 convs
@@ -326,6 +326,15 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
     else if (b128 >= 2000 && (p.N > 256 || p.K > 256)) tile = 2;
     else if (b128 >= 2000 && p.N >= 128 && !p.conv) tile = 2;               // (round 4, with the few-instruction epilogue: [153000,256]x[256,256] 167 vs 174 us,
     else tile = 3;                                                           //  Swin-L's [907200,192]x[192,192] 590 vs 616 us; before it 64x64 won: 288 vs 329 us)
+  }
+  if (tile == 1 && g_gemm_precision == 2 && p.Wh != nullptr && p.K % 32 == 0 && p.N >= 128 && p.N % 4 == 0 && p.vec_ok && p.ksplit <= 1) {
+    // mode 2 ("f16"): ONE f16 MFMA pass on the round-to-nearest plane of a constant weight (the third plane of mdqe_f16x3_split_f32);
+    // every product without planes, or too small / ragged for the 128-row tile, stays exact fp32 below (more accurate, never less)
+    GemmParams q = p;
+    q.Wh = (const char*)p.Wh + (long)p.N * p.K * 4;                      // planes: hi | lo | rn, N*K halves each
+    const int n256 = (p.N + 255) / 256 * 256, n128 = (p.N + 127) / 128 * 128;
+    const int bn = (n256 > n128 || (long)((p.M + 127) / 128) * (n256 / 256) < 400) ? 128 : 256;
+    return mdqe_launch_gemm_f16w(q, bn, st);
   }
   if (tile == 1 && g_gemm_precision == 1 && p.Wh != nullptr && p.K % 32 == 0 && p.N >= 128 && p.N % 4 == 0 &&
       p.vec_ok && p.ksplit <= 1) {

@@ -28,13 +28,13 @@ __device__ __forceinline__ h2 pkrtz2(float a, float b) { return __builtin_bit_ca
 
 // ---- one-time weight split ------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-f16x3_split_kernel(const float* __restrict__ w, long n, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+f16x3_split_kernel(const float* __restrict__ w, long n, _Float16* __restrict__ hi, _Float16* __restrict__ lo, _Float16* __restrict__ rn) {
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += (long)gridDim.x * blockDim.x * 2) {
     const float a = w[i], b = (i + 1 < n) ? w[i + 1] : 0.f;
     const h2 h = pkrtz2(a, b);
     const h2 l = pkrtz2((a - (float)h[0]) * 2048.f, (b - (float)h[1]) * 2048.f);
-    hi[i] = h[0]; lo[i] = l[0];
-    if (i + 1 < n) { hi[i + 1] = h[1]; lo[i + 1] = l[1]; }
+    hi[i] = h[0]; lo[i] = l[0]; rn[i] = (_Float16)a;                   // rn: round-to-nearest-even, what `.half()` gives (mode 2)
+    if (i + 1 < n) { hi[i + 1] = h[1]; lo[i + 1] = l[1]; rn[i + 1] = (_Float16)b; }
   }
 }
 
@@ -44,7 +44,7 @@ extern "C" int mdqe_f16x3_split_f32(const float* w, long n, void* planes, void* 
   long nb = (n / 2 + 255) / 256; if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
   mdqe_clear_error();
   hipLaunchKernelGGL(f16x3_split_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, n,
-                     (_Float16*)planes, (_Float16*)planes + n);
+                     (_Float16*)planes, (_Float16*)planes + n, (_Float16*)planes + 2 * n);
   return mdqe_launch_status();
 }
 
@@ -56,7 +56,10 @@ extern "C" int mdqe_f16x3_split_f32(const float* w, long n, void* planes, void* 
 // The MFMAs are issued with the operands swapped (weights as A, activations as B): D[n][m] puts four consecutive n of one
 // row m in each lane's accumulator quad, i.e. a 16-B piece of a C row -- the epilogue needs no LDS restage.
 // Requires K % 32 == 0 (conv: Cin % 32 == 0), N % 4 == 0 and 16-B aligned C / bias / residual (vec_ok), no split-K.
-template <int BN, bool CONV>
+// SINGLE (mode 2, "f16"): ONE f16 MFMA pass -- operands rounded to nearest f16 (the activations in registers, the weights from their
+// pre-rounded plane), fp32 accumulation, fp32 out: the arithmetic of the reference's fp16-autocast regions on a GPU (train_net.py:207) with
+// an fp32 instead of an fp16 result.  Same pipeline; a stage holds one A and one B plane (72 instead of 144 KB at BN = 256: two blocks per CU).
+template <int BN, bool CONV, bool SINGLE = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_nt_f16x3w_kernel(const GemmParams p) {
   constexpr int BM = 128, BK = 32, NW = 8;
@@ -64,7 +67,8 @@ gemm_nt_f16x3w_kernel(const GemmParams p) {
   constexpr int MT = 2, NT = WTN / 32;
   constexpr int A_PLANE = BM * BK * 2;           // bytes
   constexpr int B_PLANE = BN * BK * 2;
-  constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+  constexpr int NP = SINGLE ? 1 : 2;             // planes per operand and stage
+  constexpr int STAGE = NP * A_PLANE + NP * B_PLANE;
   constexpr int IB = BN / 16 / NW;               // 1-KiB LDS-DMA instructions per wave per B plane
   static_assert(BN % 128 == 0, "BN");
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -162,12 +166,13 @@ gemm_nt_f16x3w_kernel(const GemmParams p) {
   };
   auto issue_b = [&](int buf) __attribute__((always_inline)) {          // 2*IB LDS-DMA instructions for the K-step under the B cursor, then advances it
     const int so = ktB * (BK * 2);
-    char* base = lds + buf * STAGE + 2 * A_PLANE;
+    char* base = lds + buf * STAGE + NP * A_PLANE;
 #pragma unroll
     for (int j = 0; j < IB; ++j) {
       const unsigned off = wrow[j];      // (a local: passing the captured array element straight to the builtin loses the host stub, hipcc 7.2)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (__attribute__((address_space(3))) void*)(base + (wave * IB + j) * 1024), 16, off, so, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (__attribute__((address_space(3))) void*)(base + B_PLANE + (wave * IB + j) * 1024), 16, off, so, 0, 0);
+      if constexpr (!SINGLE)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (__attribute__((address_space(3))) void*)(base + B_PLANE + (wave * IB + j) * 1024), 16, off, so, 0, 0);
     }
     if (ktB + 1 < nk) ++ktB;
     else if (itB + 1 < my_tiles) { ktB = 0; ++itB; setup_b(itB); }
@@ -183,6 +188,14 @@ gemm_nt_f16x3w_kernel(const GemmParams p) {
     constexpr int slot = decltype(slot_)::value;
     _Float16* hi = reinterpret_cast<_Float16*>(lds + buf * STAGE);
     _Float16* lo = hi + BM * BK;
+    if constexpr (SINGLE) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 v = stg[slot][j];
+        *reinterpret_cast<h4*>(hi + apos[j]) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};     // round to nearest even
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const f32x4 v = stg[slot][j];
@@ -226,7 +239,7 @@ gemm_nt_f16x3w_kernel(const GemmParams p) {
           if (!mok || n >= p.N) continue;
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + acx[i][j][4 * g + e] * inv;
+          for (int e = 0; e < 4; ++e) v[e] = SINGLE ? acc[i][j][4 * g + e] : acc[i][j][4 * g + e] + acx[i][j][4 * g + e] * inv;
           if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
           f32x4 rv = {0.f, 0.f, 0.f, 0.f};
           if (p.residual != nullptr) rv = *reinterpret_cast<const f32x4*>(p.residual + rrow * p.ldr + n);
@@ -262,8 +275,31 @@ gemm_nt_f16x3w_kernel(const GemmParams p) {
     issue_b(S2);                                         // stage S2 was last read in step s-1 (barrier since)
     const _Float16* sAh = reinterpret_cast<const _Float16*>(lds + S * STAGE);
     const _Float16* sAl = sAh + BM * BK;
-    const _Float16* sBh = sAl + BM * BK;
+    const _Float16* sBh = sAh + NP * BM * BK;
     const _Float16* sBl = sBh + BN * BK;
+    if constexpr (SINGLE) {
+      h8 a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { a0[i] = *reinterpret_cast<const h8*>(sAh + fa[i]); a1[i] = *reinterpret_cast<const h8*>(sAh + (fa[i] ^ 16)); }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { b0[j] = *reinterpret_cast<const h8*>(sBh + fb[j]); b1[j] = *reinterpret_cast<const h8*>(sBh + (fb[j] ^ 16)); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+      split_store(std::integral_constant<int, S1>{}, S1);
+      load_a(S_);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IB + 4) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (++ktC == nk) { ktC = 0; ++itC; }
+      return;
+    }
     // LDS fragment reads run one half K-step ahead of their MFMAs: all of half 0 and the hi planes of half 1 up front,
     // the lo planes of half 1 once half 0 has retired some registers (48 fragment VGPRs instead of 64).
     h8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
@@ -321,7 +357,7 @@ gemm_nt_f16x3w_kernel(const GemmParams p) {
   split_store(I0{}, 0);
   issue_b(1);
   load_a(I2{});
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * IB + 2) : "memory");     // B(0) landed; B(1), A(2) may be in flight
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP * IB + 2) : "memory");    // B(0) landed; B(1), A(2) may be in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
@@ -340,11 +376,11 @@ gemm_nt_f16x3w_kernel(const GemmParams p) {
 
 static int g_num_cus = 0;
 
-template <int BN, bool CONV>
+template <int BN, bool CONV, bool SINGLE = false>
 static int launch_f16x3w(const GemmParams& p, hipStream_t st) {
   const int nbm = (p.M + 127) / 128, nbn = (p.N + BN - 1) / BN;
-  const size_t smem = (size_t)3 * (2 * 128 * 32 * 2 + 2 * BN * 32 * 2);       // 3 stages x (A hi, A lo, B hi, B lo)
-  auto kern = gemm_nt_f16x3w_kernel<BN, CONV>;
+  const size_t smem = (size_t)3 * (SINGLE ? 1 : 2) * (128 * 32 * 2 + BN * 32 * 2);       // 3 stages x (A hi[, A lo], B hi[, B lo])
+  auto kern = gemm_nt_f16x3w_kernel<BN, CONV, SINGLE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -363,6 +399,12 @@ static int launch_f16x3w(const GemmParams& p, hipStream_t st) {
 }
 
 // bn: 256 or 128.  Caller guarantees K % 32 == 0, N % 4 == 0, vec_ok, ksplit <= 1 and Wh/Wl set.
+// mode 2: one f16 pass; p.Wh must point at the round-to-nearest plane (the third plane of mdqe_f16x3_split_f32).
+int mdqe_launch_gemm_f16w(const GemmParams& p, int bn, hipStream_t st) {
+  if (p.conv) return bn == 256 ? launch_f16x3w<256, true, true>(p, st) : launch_f16x3w<128, true, true>(p, st);
+  return bn == 256 ? launch_f16x3w<256, false, true>(p, st) : launch_f16x3w<128, false, true>(p, st);
+}
+
 int mdqe_launch_gemm_f16x3w(const GemmParams& p, int bn, hipStream_t st) {
   if (p.conv) return bn == 256 ? launch_f16x3w<256, true>(p, st) : launch_f16x3w<128, true>(p, st);
   return bn == 256 ? launch_f16x3w<256, false>(p, st) : launch_f16x3w<128, false>(p, st);

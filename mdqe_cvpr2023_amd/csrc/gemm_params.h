@@ -47,3 +47,4 @@ int mdqe_launch_gemm_f16x3(const GemmParams& p, int tile, hipStream_t st);
 int mdqe_launch_gemm_k16(const GemmParams& p, int tile, hipStream_t st);
 // defined in gemm_f16x3w.hip (bn = 256 or 128)
 int mdqe_launch_gemm_f16x3w(const GemmParams& p, int bn, hipStream_t st);
+int mdqe_launch_gemm_f16w(const GemmParams& p, int bn, hipStream_t st);    // mode 2: one f16 pass, p.Wh = the round-to-nearest plane

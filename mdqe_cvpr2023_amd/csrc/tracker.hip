@@ -4,6 +4,7 @@
 // OverTracker._get_siou (:92-113) only needs sign tests -- no 0/1 matrices are materialised.
 #include "common.h"
 #include <time.h>
+#include <stdlib.h>
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
 #pragma unroll
@@ -46,7 +47,8 @@ trk_siou_kernel(const float* __restrict__ saved, long saved_stride, const float*
   }
 }
 
-static int g_trk_siou_blocks = 0;
+static int trk_env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+static int g_trk_siou_blocks = trk_env_int("MDQE_TRK_SIOU_BLOCKS", 0);
 extern "C" int mdqe_debug_trk_siou_blocks(int v) { g_trk_siou_blocks = v; return MDQE_OK; }
 
 extern "C" int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
@@ -72,13 +74,19 @@ extern "C" int mdqe_trk_siou_f32(const float* saved, long saved_stride, int n_sa
 // on rank 0 of a sharded video that chain is the replay of every rank's clips (sharding.ReplayThread): its per-clip latency decides
 // how many ranks one root can serve.  Rounds 1-4 spent four stream operations per clip on the counts (memset, kernel, device->host copy,
 // stream synchronize).  Here it is ONE kernel: partial counts are added into `acc` (device, all zeros on entry) as before; the block
-// that finishes last (a ticket counter) moves the finished counts into `out_host` -- pinned, host-coherent memory -- leaves `acc` and
-// the ticket at zero for the next launch, and publishes `seq` in `flag_host` with a system-scope release.  The host polls the flag
-// (mdqe_trk_wait_flag: a bounded spin, then a stream synchronize, which makes the kernel's stores visible in any case).
+// that finishes last (a ticket counter) moves the finished counts into `out_host` -- pinned, host-coherent memory -- as 64-bit words
+// (launch sequence number << 32 | float bits), one system-scope store each, and leaves `acc` and the ticket at zero for the next launch.
+// The host polls the words (mdqe_trk_wait_counts: every word must carry this launch's sequence number; a bounded spin, then a stream
+// synchronize, which makes the kernel's stores visible in any case).
+// NO FENCES: a release fence at agent or system scope writes the XCD's whole L2 back (buffer_wbl2) -- with the frame stream's GEMMs
+// running beside the tracker that cost the pipeline 2 % (measured: the first form of this kernel, `__threadfence()` before the ticket and
+// `__threadfence_system()` before a flag).  Ordering comes from completion instead: the three count atomics are device-scope
+// read-modify-writes performed at the memory side, `s_waitcnt vmcnt(0)` holds the ticket back until they have been acknowledged, and
+// the last block reads the sums with device-scope atomic loads (past the non-coherent L1 / XCD L2).
 __global__ void __launch_bounds__(256)
 trk_siou_host_kernel(const float* __restrict__ saved, long saved_stride, const float* __restrict__ inp, long inp_stride,
-                     long n, float* __restrict__ acc, unsigned* __restrict__ ticket, float* __restrict__ out_host,
-                     unsigned* __restrict__ flag_host, unsigned seq, int n_in, int n_out) {
+                     long n, float* __restrict__ acc, unsigned* __restrict__ ticket, unsigned long long* __restrict__ out_host,
+                     unsigned seq, int n_in, int n_out) {
   __shared__ float sh[4];
   __shared__ int is_last;
   const int i = blockIdx.y, j = blockIdx.x;
@@ -99,55 +107,61 @@ trk_siou_host_kernel(const float* __restrict__ saved, long saved_stride, const f
   ci = block_sum(ci, sh); ca = block_sum(ca, sh); cb = block_sum(cb, sh);
   if (threadIdx.x == 0) {
     float* o = acc + ((long)i * n_in + j) * 3;
-    atomicAdd(o, ci); atomicAdd(o + 1, ca); atomicAdd(o + 2, cb);
-    __threadfence();                                               // the three adds are at the L2 before the ticket is
+    __hip_atomic_fetch_add(o, ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(o + 1, ca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(o + 2, cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the three adds have been performed before the ticket is drawn
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-    is_last = atomicAdd(ticket, 1u) == total - 1;
+    is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
   }
   __syncthreads();
   if (!is_last) return;
-  __threadfence();
   for (int k = threadIdx.x; k < n_out; k += blockDim.x) {
-    const float v = __hip_atomic_load(acc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (past the non-coherent L1)
-    out_host[k] = v;
-    acc[k] = 0.f;
+    const float v = __hip_atomic_load(acc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(acc + k, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out_host + k, ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    *ticket = 0u;
-    __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// acc: >= n_saved*n_in*3 floats, ZERO on entry (left zero); ticket: one zero unsigned (left zero); out_host / flag_host: host-coherent
-// pinned memory.  After the launch `*flag_host == seq` means out_host holds the counts of this launch.
+// acc: >= n_saved*n_in*3 floats, ZERO on entry (left zero); ticket: one zero unsigned (left zero); out_host: >= n_saved*n_in*3 64-bit
+// words of host-coherent pinned memory.  After the launch, word k == (seq << 32 | bits of count k) for every k means the counts are in.
 extern "C" int mdqe_trk_siou_host_f32(const float* saved, long saved_stride, int n_saved, const float* inp, long inp_stride,
-                                      int n_in, long n, float* acc, unsigned* ticket, float* out_host, unsigned* flag_host,
+                                      int n_in, long n, float* acc, unsigned* ticket, unsigned long long* out_host,
                                       unsigned seq, void* stream) {
-  MDQE_REQUIRE(n_saved > 0 && n_in > 0 && n > 0 && n % 4 == 0 && saved_stride % 4 == 0 && inp_stride % 4 == 0);
-  MDQE_CHECK_PTR(saved); MDQE_CHECK_PTR(inp); MDQE_CHECK_PTR(acc); MDQE_CHECK_PTR(ticket); MDQE_CHECK_PTR(out_host); MDQE_CHECK_PTR(flag_host);
-  MDQE_REQUIRE((((uintptr_t)saved | (uintptr_t)inp) & 15) == 0);
+  MDQE_REQUIRE(n_saved > 0 && n_in > 0 && n > 0 && n % 4 == 0 && saved_stride % 4 == 0 && inp_stride % 4 == 0 && seq != 0);
+  MDQE_CHECK_PTR(saved); MDQE_CHECK_PTR(inp); MDQE_CHECK_PTR(acc); MDQE_CHECK_PTR(ticket); MDQE_CHECK_PTR(out_host);
+  MDQE_REQUIRE((((uintptr_t)saved | (uintptr_t)inp) & 15) == 0 && ((uintptr_t)out_host & 7) == 0);
   mdqe_clear_error();
   int chunks = 1;
   const long pairs = (long)n_saved * n_in;
   const long target = g_trk_siou_blocks > 0 ? g_trk_siou_blocks : 512;
   if (pairs < target) { chunks = (int)(target / pairs); const long maxc = (n / 4 + 1023) / 1024; if (chunks > maxc) chunks = (int)maxc; if (chunks < 1) chunks = 1; }
   hipLaunchKernelGGL(trk_siou_host_kernel, dim3(n_in, n_saved, chunks), dim3(256), 0, (hipStream_t)stream, saved, saved_stride, inp,
-                     inp_stride, n, acc, ticket, out_host, flag_host, seq, n_in, (int)(pairs * 3));
+                     inp_stride, n, acc, ticket, out_host, seq, n_in, (int)(pairs * 3));
   return mdqe_launch_status();
 }
 
-// Wait until *flag_host == seq: poll for at most `spin_us` microseconds (the kernel's own release makes the counts visible), then fall
-// back to a stream synchronize (kernel completion makes every store visible whatever the memory's coherence mode).
-extern "C" int mdqe_trk_wait_flag(const unsigned* flag_host, unsigned seq, int spin_us, void* stream) {
-  MDQE_CHECK_PTR(flag_host);
-  const volatile unsigned* f = flag_host;
+// Wait until the n_out words of `out_host` all carry `seq`, then unpack the counts into counts[n_out]: polls for at most `spin_us`
+// microseconds, then falls back to a stream synchronize (kernel completion makes every store visible whatever the memory's coherence
+// mode).  MDQE_ELAUNCH if the words are still not there after the synchronize.
+extern "C" int mdqe_trk_wait_counts(const unsigned long long* out_host, int n_out, unsigned seq, int spin_us, float* counts, void* stream) {
+  MDQE_CHECK_PTR(out_host); MDQE_CHECK_PTR(counts);
+  MDQE_REQUIRE(n_out > 0);
+  const volatile unsigned long long* w = out_host;
+  auto all_in = [&]() {
+    for (int k = n_out - 1; k >= 0; --k)
+      if ((unsigned)(__atomic_load_n(w + k, __ATOMIC_ACQUIRE) >> 32) != seq) return false;
+    return true;
+  };
+  bool ok = false;
   if (spin_us > 0) {
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (long it = 0;; ++it) {
-      if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return MDQE_OK;
+    for (long it = 0; !ok; ++it) {
+      ok = all_in();
+      if (ok) break;
       if ((it & 63) == 63) {
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000 > spin_us) break;
@@ -157,8 +171,15 @@ extern "C" int mdqe_trk_wait_flag(const unsigned* flag_host, unsigned seq, int s
 #endif
     }
   }
-  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MDQE_ELAUNCH;
-  return __atomic_load_n(f, __ATOMIC_ACQUIRE) == seq ? MDQE_OK : MDQE_ELAUNCH;
+  if (!ok) {
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MDQE_ELAUNCH;
+    if (!all_in()) return MDQE_ELAUNCH;
+  }
+  for (int k = 0; k < n_out; ++k) {
+    const unsigned bits = (unsigned)(w[k] & 0xFFFFFFFFull);
+    __builtin_memcpy(counts + k, &bits, 4);
+  }
+  return MDQE_OK;
 }
 
 struct TrkIdx { int r[128]; int c[128]; };

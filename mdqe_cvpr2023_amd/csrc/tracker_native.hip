@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <time.h>
 #include <cstdlib>
 #include <limits>
 #include <set>
@@ -167,8 +168,8 @@ struct Tracker {
   // environment (or mdqe_debug_trk_fast(0)) keeps the four-step form (memset, kernel, copy, synchronize) -- same counts, same decisions.
   float* acc_dev = nullptr;
   unsigned* ticket_dev = nullptr;
-  float* counts_pin = nullptr;
-  unsigned* flag_pin = nullptr;
+  unsigned long long* words_pin = nullptr;   // (launch sequence number << 32 | count bits), written by the kernel
+  std::vector<float> counts_fast;            // the unpacked counts of the last launch
   long acc_cap = 0;
   unsigned seq = 0;
 
@@ -180,11 +181,11 @@ struct Tracker {
     while (cap < need) cap *= 2;
     if (hipMalloc((void**)&acc_dev, (size_t)cap * sizeof(float)) != hipSuccess) { acc_dev = nullptr; return MDQE_ELAUNCH; }
     if (hipMalloc((void**)&ticket_dev, 64) != hipSuccess) { release_fast(); return MDQE_ELAUNCH; }
-    if (hipHostMalloc((void**)&counts_pin, (size_t)cap * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { counts_pin = nullptr; release_fast(); return MDQE_ELAUNCH; }
-    if (hipHostMalloc((void**)&flag_pin, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { flag_pin = nullptr; release_fast(); return MDQE_ELAUNCH; }
+    if (hipHostMalloc((void**)&words_pin, (size_t)cap * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { words_pin = nullptr; release_fast(); return MDQE_ELAUNCH; }
     if (hipMemsetAsync(acc_dev, 0, (size_t)cap * sizeof(float), st) != hipSuccess || hipMemsetAsync(ticket_dev, 0, 64, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { release_fast(); return MDQE_ELAUNCH; }
-    *flag_pin = 0u;
+    for (long k = 0; k < cap; ++k) words_pin[k] = 0ull;
+    counts_fast.assign((size_t)cap, 0.f);
     acc_cap = cap;
     return MDQE_OK;
   }
@@ -192,9 +193,8 @@ struct Tracker {
   void release_fast() {
     if (acc_dev) (void)hipFree(acc_dev);
     if (ticket_dev) (void)hipFree(ticket_dev);
-    if (counts_pin) (void)hipHostFree(counts_pin);
-    if (flag_pin) (void)hipHostFree(flag_pin);
-    acc_dev = nullptr; ticket_dev = nullptr; counts_pin = nullptr; flag_pin = nullptr; acc_cap = 0;
+    if (words_pin) (void)hipHostFree(words_pin);
+    acc_dev = nullptr; ticket_dev = nullptr; words_pin = nullptr; acc_cap = 0;
   }
 
   ~Tracker() { release_fast(); }
@@ -401,8 +401,8 @@ struct Tracker {
 
 // device half (tracker.hip)
 extern "C" int mdqe_trk_siou_f32(const float*, long, int, const float*, long, int, long, float*, void*);
-extern "C" int mdqe_trk_siou_host_f32(const float*, long, int, const float*, long, int, long, float*, unsigned*, float*, unsigned*, unsigned, void*);
-extern "C" int mdqe_trk_wait_flag(const unsigned*, unsigned, int, void*);
+extern "C" int mdqe_trk_siou_host_f32(const float*, long, int, const float*, long, int, long, float*, unsigned*, unsigned long long*, unsigned, void*);
+extern "C" int mdqe_trk_wait_counts(const unsigned long long*, int, unsigned, int, float*, void*);
 extern "C" int mdqe_trk_accumulate_f32(float*, long, float*, long, const float*, long, long, int, const int*, const int*, int, void*);
 extern "C" int mdqe_trk_window_mean_f32(const float*, const float*, long, int, int, int, long, float*, void*);
 extern "C" int mdqe_trk_carry_f32(float*, float*, long, int, int, int, long, float*, void*);
@@ -476,6 +476,20 @@ static int g_trk_spin_us = env_int("MDQE_TRK_SPIN_US", 2000);  // how long the h
 extern "C" int mdqe_debug_trk_fast(int v) { g_trk_fast = v; return MDQE_OK; }
 extern "C" int mdqe_debug_trk_spin_us(int v) { g_trk_spin_us = v; return MDQE_OK; }
 
+// tools/replay_profile.py: where the host time of an update goes -- [0] launching the counts kernel, [1] waiting for the counts, [2] the host
+// decision, [3] launching the accumulate kernel, [4] updates; seconds, accumulated while mdqe_debug_trk_times(..., reset) has switched it on
+static int g_trk_timing = 0;
+static double g_trk_t[5] = {0, 0, 0, 0, 0};
+static inline double trk_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+#define TRK_T0() double trk_t_ = g_trk_timing ? trk_now() : 0.0
+#define TRK_T(k) do { if (g_trk_timing) { const double n_ = trk_now(); g_trk_t[k] += n_ - trk_t_; trk_t_ = n_; } } while (0)
+extern "C" int mdqe_debug_trk_times(double* out5, int on) {
+  if (out5) for (int k = 0; k < 5; ++k) out5[k] = g_trk_t[k];
+  for (int k = 0; k < 5; ++k) g_trk_t[k] = 0;
+  g_trk_timing = on;
+  return MDQE_OK;
+}
+
 static int tracker_update_one(Tracker* t, float* bank_sum, float* bank_cnt, long hw, int f0, int n_frames, int n_in,
                               const float* scores, const float* cls_probs, const float* embeds, const float* masks,
                               long inst_stride, float* counts_dev, float* counts_host, hipStream_t st) {
@@ -491,30 +505,41 @@ static int tracker_update_one(Tracker* t, float* bank_sum, float* bank_cnt, long
         // one kernel: counts -> host-coherent memory + a sequence flag; the host polls the flag (tracker.hip)
         int rc2 = t->ensure_fast((long)ni * n_in * 3, st);
         if (rc2 != MDQE_OK) return rc2;
-        const unsigned seq = ++t->seq;
+        if (++t->seq == 0) t->seq = 1;                                   // (0 marks a word that was never written)
+        const unsigned seq = t->seq;
+        TRK_T0();
         rc2 = mdqe_trk_siou_host_f32(bank_sum + (long)s0 * hw, bank_stride, ni, masks + (long)a * hw, inst_stride, n_in, (long)nf * hw,
-                                     t->acc_dev, t->ticket_dev, t->counts_pin, t->flag_pin, seq, st);
+                                     t->acc_dev, t->ticket_dev, t->words_pin, seq, st);
         if (rc2 != MDQE_OK) return rc2;                                  // (read-only so far: the tracker is still consistent)
-        rc2 = mdqe_trk_wait_flag(t->flag_pin, seq, g_trk_spin_us, st);    // the one host wait of an update
+        TRK_T(0);
+        rc2 = mdqe_trk_wait_counts(t->words_pin, ni * n_in * 3, seq, g_trk_spin_us, t->counts_fast.data(), st);    // the one host wait of an update
         if (rc2 != MDQE_OK) { t->poisoned = true; return rc2; }          // (the accumulator / ticket may be left dirty)
-        c3 = t->counts_pin;
+        TRK_T(1);
+        c3 = t->counts_fast.data();
       } else {
+        TRK_T0();
         int rc2 = mdqe_trk_siou_f32(bank_sum + (long)s0 * hw, bank_stride, ni, masks + (long)a * hw, inst_stride, n_in, (long)nf * hw,
                                     counts_dev, st);
         if (rc2 != MDQE_OK) return rc2;                                  // (read-only so far: the tracker is still consistent)
         if (hipMemcpyAsync(counts_host, counts_dev, (size_t)ni * n_in * 3 * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess)
           return MDQE_ELAUNCH;
+        TRK_T(0);
         if (hipStreamSynchronize(st) != hipSuccess) return MDQE_ELAUNCH;   // the one host sync of an update
+        TRK_T(1);
         c3 = counts_host;
       }
     }
   }
+  double trk_t_ = g_trk_timing ? trk_now() : 0.0;
   const int rc = t->decide(f0, n_frames, n_in, scores, cls_probs, embeds, c3, c3 != nullptr, &s0, &a, &nf);
   if (rc != MDQE_OK) return rc;                                          // (decide validates before it commits)
+  TRK_T(2);
+  if (g_trk_timing) g_trk_t[4] += 1;
   if (!t->r_idx.empty()) {
     const int rc3 = mdqe_trk_accumulate_f32(bank_sum + (long)s0 * hw, (long)t->mem_len * hw, bank_cnt + s0, t->mem_len, masks + (long)a * hw,
                                             inst_stride, (long)nf * hw, nf, t->r_idx.data(), t->c_idx.data(), (int)t->r_idx.size(), st);
     if (rc3 != MDQE_OK) t->poisoned = true;                              // host half committed, device half not
+    TRK_T(3);
     return rc3;
   }
   return MDQE_OK;

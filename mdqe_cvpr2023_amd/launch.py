@@ -36,6 +36,9 @@ def prepare_environment(environ=None):
         parts.insert(0, p)
     env["PYTHONPATH"] = os.pathsep.join(parts)
     env["MDQE_MI355X_AUTOREGISTER"] = "1"
+    # the pipeline's streams on 8 hardware queues instead of HIP's default 4 (bench.py: what the sharded schedule's tracker replay needs;
+    # neutral for one GPU); an explicit value wins
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
     return env
 
 

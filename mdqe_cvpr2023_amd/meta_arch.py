@@ -131,8 +131,8 @@ class MDQE(nn.Module):
 
     @precision_map.setter
     def precision_map(self, v):
-        if v not in ("", "reference"):
-            raise ValueError("precision_map: '' or 'reference'")
+        if v not in ("", "reference", "autocast_f16"):
+            raise ValueError("precision_map: '', 'reference' or 'autocast_f16'")
         self.engine.precision_map = v
 
     # ---- forward (mdqe/mdqe.py:194-242) ------------------------------------------------------------
@@ -196,6 +196,26 @@ class MDQE(nn.Module):
                 yield
         finally:
             cur.wait_stream(ws)
+
+    PIN_POOL_GB = float(os.environ.get("MDQE_PIN_POOL_GB", "8"))       # pinned host memory the model keeps for mask read-back between calls
+
+    def pinned_mask_buffer(self, shape):
+        """A pinned uint8 host buffer for one track's final masks.  A video's result hands VIEWS of these buffers to the caller, so a
+        buffer is free again when the caller has dropped that result: the pool keeps the buffers it has made (up to PIN_POOL_GB) and
+        re-issues one as soon as nothing but the pool references its storage.  A fresh pinned allocation costs ~75 us per MB (7 tracks of a
+        960-frame 360p video: 120 ms; tools/pinned_probe.py), and the framework's own host allocator recycles only every other video."""
+        use_count = getattr(torch._C, "_storage_Use_Count", None)
+        pool = self.__dict__.setdefault("_pin_pool", {})
+        free = pool.setdefault(tuple(shape), [])
+        if use_count is not None:
+            for t in free:
+                if use_count(t.untyped_storage()._cdata) <= 2:         # the pool's tensor + the temporary wrapper of this very query
+                    return t
+        t = torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True)
+        held = sum(b.numel() for bufs in pool.values() for b in bufs)
+        if use_count is not None and held + t.numel() <= self.PIN_POOL_GB * 2 ** 30:
+            free.append(t)
+        return t
 
     def _on_device(self):
         """Every ctypes launch goes to the CURRENT device's current stream: make the model's device current for the call."""
@@ -993,7 +1013,7 @@ class ClipMerger:
             return
         hosts = self.early["host"]
         while len(hosts) < n:                       # a new track: its own pinned [L, Ho, Wo] buffer, zero before its first window (:442)
-            hbuf = torch.empty(self.n_frames, Ho, Wo, dtype=torch.uint8, pin_memory=True)
+            hbuf = model.pinned_mask_buffer((int(self.n_frames), Ho, Wo))
             if self.f_off > 0:
                 hbuf[:self.f_off].zero_()
             hosts.append(hbuf)

@@ -34,14 +34,18 @@ if os.environ.get("MDQE_GEMM_LDS_PAD"):                # tools/ A/B: extra LDS b
 _ws = {}
 
 
+GEMM_MODES = {"f32": 0, "f16x3": 1, "f16": 2}
+
+
 def set_gemm_precision(mode):
-    """'f32' (exact fp32 MFMA) or 'f16x3' (split-precision f16 MFMA, ~1e-6 rel. to fp32) for the large-tile GEMM/conv."""
-    check(lib.mdqe_set_gemm_precision({"f32": 0, "f16x3": 1}[mode]), "set_gemm_precision")
+    """'f32' (exact fp32 MFMA), 'f16x3' (split-precision f16 MFMA, ~1e-6 rel. to fp32) or 'f16' (ONE f16 MFMA pass, operands rounded to
+    nearest f16, fp32 accumulate / out: the reference's autocast arithmetic) for the large-tile GEMM/conv."""
+    check(lib.mdqe_set_gemm_precision(GEMM_MODES[mode]), "set_gemm_precision")
 
 
 def get_gemm_precision():
     """The mode this thread's launches use (its `gemm_precision` region if inside one, else the process-wide mode)."""
-    return {0: "f32", 1: "f16x3"}[lib.mdqe_get_gemm_precision()]
+    return {v: k for k, v in GEMM_MODES.items()}[lib.mdqe_get_gemm_precision()]
 
 
 _tl_prec = threading.local()
@@ -52,7 +56,7 @@ def gemm_precision(mode):
     """`with gemm_precision("f16x3"):` -- the GEMM mode of the CALLING thread's launches inside the block (C ABI
     mdqe_set_gemm_precision_thread); nests; other host threads and the process-wide mode are untouched."""
     prev = getattr(_tl_prec, "v", -1)
-    cur = {"f32": 0, "f16x3": 1}[mode]
+    cur = GEMM_MODES[mode]
     check(lib.mdqe_set_gemm_precision_thread(cur), "set_gemm_precision_thread")
     _tl_prec.v = cur
     try:
@@ -76,7 +80,7 @@ def const_weight(w):
     K = w.numel() // max(N, 1)
     if N < 128 or K % 32 != 0 or float(w.abs().max()) >= 32752.0:
         return w
-    planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=w.device)
+    planes = torch.empty(3 * w.numel(), dtype=torch.float16, device=w.device)     # hi | lo (f16x3) | round-to-nearest (f16)
     check(lib.mdqe_f16x3_split_f32(ptr(w), w.numel(), ptr(planes), cur_stream()), "f16x3_split")
     key = w.data_ptr()
     _split[key] = (weakref.ref(w), w._version, planes)

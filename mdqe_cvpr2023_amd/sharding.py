@@ -18,6 +18,10 @@ import torch
 # for the driver's kill (bench.py gives the default group the same one).
 COLLECTIVE_TIMEOUT_S = float(os.environ.get("MDQE_COLLECTIVE_TIMEOUT_S", "120"))
 
+# the decoder's instance-chain side stream inside a sharded chunk (round 3: off -- with HIP's default 4 hardware queues it landed behind the
+# frame stream's GEMMs; tools A/B with GPU_MAX_HW_QUEUES=8)
+SHARD_SIDE_STREAMS = os.environ.get("MDQE_SHARD_SIDE_STREAMS", "0") == "1"
+
 FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
 
 
@@ -435,7 +439,7 @@ class _Job:
             kw["halo"] = self._halo(q, g)
         # (no side streams inside the decoder here: the sharded schedule already runs RCCL's stream and the replay thread's tracker
         # stream beside the frame / clip / copy streams, and HIP has 4 hardware queues for all of them -- meta_arch.iter_clip_results)
-        gen = self.model.iter_clip_results(fr, self.plan[g][0], self.plan[g][1], primed=True, side_streams=False, **kw)
+        gen = self.model.iter_clip_results(fr, self.plan[g][0], self.plan[g][1], primed=True, side_streams=SHARD_SIDE_STREAMS, **kw)
         next(gen)
         return gen
 

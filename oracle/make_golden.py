@@ -390,6 +390,66 @@ def gen_tracker():
     save("tracker_seq", n_clips=n_clip, n_windows=saved, T=T, WIN=WIN, K=K, E=E, HW=np.array(HW), MAXI=MAXI, THR=THR, **arrs)
 
 
+def gen_tracker_long():
+    """A LONG crafted clip sequence -> reference OverTracker (mdqe/tracking/OverTracker.py:65-90,115-225): 44 frames, 8-frame windows (six
+    window flushes, five re-basings of the bank), 4-frame clips.  Object 2 leaves the picture for 11 frames (longer than a window and longer
+    than the short memory of 5 clips, shorter than the long memory of 15) and RETURNS -- it must get its old ID back through the long-memory
+    similarity alone (no overlapping masks); object 3 leaves for 20 frames (longer than the long memory) and returns -- a NEW ID; object 5
+    appears late; a duplicate detection and a detection that drops below 2*thr are thrown in."""
+    trk = refshim.ref("mdqe.tracking.OverTracker")
+    g = torch.Generator().manual_seed(91)
+    T, WIN, K, E, HW, MAXI, THR, L = 4, 8, 5, 32, (12, 16), 16, 0.1, 44
+    base = torch.randn(6, E, generator=g) * 1.5
+    centers = torch.tensor([[3., 3.], [8., 11.], [5., 8.], [9., 3.], [2., 13.], [10., 8.]])
+    life = [[(0, 44)], [(0, 44)], [(0, 12), (23, 44)], [(0, 8), (28, 44)], [(0, 30)], [(17, 44)]]     # [first, last) frame intervals
+    alive = lambda o, f: any(a <= f < b for a, b in life[o])
+    yy, xx = torch.meshgrid(torch.arange(HW[0]).float(), torch.arange(HW[1]).float(), indexing="ij")
+
+    def blob(obj, f):
+        cy, cx = centers[obj] + 0.05 * f * torch.tensor([1.0, -1.0 if obj % 2 else 1.0])
+        return 4.0 - ((yy - cy) ** 2 + (xx - cx) ** 2) * 0.8
+
+    tracker = trk.OverTracker(MAXI, T, WIN, 1, K, 32, E, HW, "cpu", THR)
+    arrs, saved, n_clip = {}, 0, 0
+    for start in range(0, L):
+        end = min(start + T, L)
+        last = start + T > L
+        fi = list(range(start, end))
+        objs = [o for o in range(6) if any(alive(o, f) for f in fi)]
+        if start in (5, 26):
+            objs = objs + [objs[0]]                                  # duplicate detection of the first object
+        perm = torch.randperm(len(objs), generator=g).tolist()
+        objs = [objs[i] for i in perm]
+        masks = torch.stack([torch.stack([blob(o, f) if alive(o, f) else torch.full(HW, -3.0) for f in fi]) for o in objs]) \
+            + 0.05 * torch.randn(len(objs), len(fi), *HW, generator=g)
+        emb = torch.stack([base[o] for o in objs]) + 0.15 * torch.randn(len(objs), E, generator=g)
+        cls = torch.rand(len(objs), K, generator=g) * 0.5
+        for i, o in enumerate(objs):
+            cls[i, o % K] = 0.55 + 0.4 * torch.rand(1, generator=g)
+        if start == 33:
+            cls[0] *= 0.3                                            # a weak detection (score < 2*thr after the scaling of its row)
+        sc, lab = cls.max(-1)
+        order = sc.sort(descending=True)[1]
+        res = refshim.Instances(HW, scores=sc[order], pred_classes=lab[order], cls_probs=cls[order],
+                                pred_masks=masks[order], query_embeds=emb[order])
+        for k in ("scores", "pred_classes", "cls_probs", "pred_masks", "query_embeds"):
+            arrs[f"clip{n_clip}::{k}"] = getattr(res, k)
+        arrs[f"clip{n_clip}::frame_idx"] = np.array(fi)
+        arrs[f"clip{n_clip}::objects"] = np.array([objs[i] for i in order.tolist()])
+        tracker.update(trk.Clips(fi, res))
+        arrs[f"clip{n_clip}::num_inst_after"] = tracker.num_inst
+        n_clip += 1
+        if last or (start + 1 >= WIN * (saved + 1)):
+            c, m = tracker.get_result(is_last_clip=last)
+            arrs[f"win{saved}::cls"] = c.clone()
+            arrs[f"win{saved}::masks"] = m.clone()
+            saved += 1
+        if last:
+            break
+    print("tracker_long: clips", n_clip, "windows", saved, "num_inst", tracker.num_inst)
+    save("tracker_long", n_clips=n_clip, n_windows=saved, T=T, WIN=WIN, K=K, E=E, HW=np.array(HW), MAXI=MAXI, THR=THR, **arrs)
+
+
 def gen_swin():
     """Small SwinV2 (embed 32, heads 2/4/8/16 -> head dim 16, window 4 / last stage 2) on 2 x 64x96: exercises window
     padding (4x6 and 2x3 maps), cyclic shift masks, cosine attention with CPB bias, res-post-norm, patch merging."""
@@ -479,6 +539,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "msda_backward":
         gen_msda_backward()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tracker_long":
+        with torch.no_grad():
+            gen_tracker_long()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coco_image":
         with torch.no_grad():
             gen_coco_image()
@@ -492,5 +556,6 @@ if __name__ == "__main__":
         gen_layer256()
         gen_video()
         gen_tracker()
+        gen_tracker_long()
         gen_swin()
         gen_coco_image()

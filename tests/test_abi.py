@@ -51,7 +51,7 @@ def test_gemm_precision_override_is_per_thread():
     import threading
     from mdqe_cvpr2023_amd import _lib, ops
     h = _lib.load_library()
-    assert h.mdqe_set_gemm_precision_thread(2) != 0 and h.mdqe_set_gemm_precision_thread(-2) != 0       # EINVAL, nothing changed
+    assert h.mdqe_set_gemm_precision_thread(3) != 0 and h.mdqe_set_gemm_precision_thread(-2) != 0       # EINVAL, nothing changed
     assert ops.get_gemm_precision() == "f32"
     seen = {}
 

@@ -772,3 +772,39 @@ def test_gemm_fast_and_general_epilogue_give_equal_bits():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_epilogue_paths.py")], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "0 differing cases" in r.stdout
+
+
+def test_gemm_single_pass_f16_mode():
+    """Mode "f16" (round 5; the reference's fp16-autocast arithmetic, train_net.py:207): ONE f16 MFMA pass on the products whose constant
+    weight has planes -- operands rounded to nearest f16, fp32 accumulation, fp32 result.  Against float64 the error is that of the two
+    roundings (2^-11 relative per operand: ~1e-3 of the output scale at most, far above f16x3's 1e-6 and fp32's 1e-7); it equals the product
+    of the ROUNDED operands to fp32 accuracy (the mode really is one f16 pass with exact accumulation); products without planes, or too
+    small for the 128-row tile, stay exact fp32; GEMM and implicit-GEMM conv, with the fused epilogue."""
+    from mdqe_cvpr2023_amd import ops
+    g = torch.Generator().manual_seed(31)
+    try:
+        for (M, N, K) in ((40000, 256, 256), (30000, 1024, 256), (25000, 640, 1024)):
+            x = torch.randn(M, K, generator=g).cuda(); w = ops.const_weight((torch.randn(N, K, generator=g) / K ** 0.5).cuda()); b = torch.randn(N, generator=g).cuda()
+            r = torch.randn(M, N, generator=g).cuda()
+            ops.set_gemm_precision("f32")
+            exact = ops.linear(x, w, b, act="gelu", residual=r)
+            ops.set_gemm_precision("f16")
+            got = ops.linear(x, w, b, act="gelu", residual=r)
+            ref = F.gelu(x.double() @ w.double().t() + b.double()) + r.double()
+            rounded = F.gelu(x.half().double() @ w.half().double().t() + b.double()) + r.double()
+            scale = float(ref.abs().max())
+            e64, e_rounded, e32 = float((got.double() - ref).abs().max()) / scale, float((got.double() - rounded).abs().max()) / scale, float((exact.double() - ref).abs().max()) / scale
+            assert e32 < 2e-6 and 1e-5 < e64 < 2e-3 and e_rounded < 5e-6, (M, N, K, e32, e64, e_rounded)
+        # a weight without planes (N < 128) and a product below the tile rule stay exact fp32 in this mode
+        x = torch.randn(30000, 256, generator=g).cuda(); w = (torch.randn(64, 256, generator=g) / 16).cuda()
+        ops.set_gemm_precision("f32"); a = ops.linear(x, w)
+        ops.set_gemm_precision("f16"); c = ops.linear(x, w)
+        assert torch.equal(a, c)
+        # implicit-GEMM conv
+        xi = torch.randn(8, 48, 80, 128, generator=g).cuda(); wc = ops.const_weight((torch.randn(256, 3, 3, 128, generator=g) / 34).cuda()); bc = torch.randn(256, generator=g).cuda()
+        ops.set_gemm_precision("f16")
+        got = ops.conv2d_nhwc(xi, wc, bc, 1, 1, act="relu")
+        ref = F.relu(F.conv2d(xi.permute(0, 3, 1, 2).half().double(), wc.permute(0, 3, 1, 2).half().double(), bc.double(), 1, 1)).permute(0, 2, 3, 1)
+        assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 5e-6
+    finally:
+        ops.set_gemm_precision("f32")

@@ -141,8 +141,12 @@ def test_inference_clip():
             assert maxdiff(r[k], fx.t(f"clip{i}::{k}")) < TOL
 
 
-def test_tracker_sequence():
-    fx = Fixture("tracker_seq")
+@pytest.mark.parametrize("fixture", ["tracker_seq", "tracker_long"])
+def test_tracker_sequence(fixture):
+    """tracker_long (round 5): 44 frames, six window flushes; an object leaves for 11 frames -- longer than a window and than the short
+    memory -- and gets its OLD id back from the long memory alone, another leaves for longer than the long memory and returns as a NEW id
+    (mdqe/tracking/OverTracker.py:65-90,124-134)."""
+    fx = Fixture(fixture)
     hp = O.Hyper(hidden_dim=fx.i("E"), num_classes=fx.i("K"), n_frames_test=fx.i("T"), n_frames_window_test=fx.i("WIN"),
                  n_max_inst=fx.i("MAXI"), apply_cls_thres=fx.f("THR"), clip_stride=1)
     trk = O.Tracker(hp, tuple(int(v) for v in fx.z["HW"]))

@@ -1,14 +1,16 @@
 """CPU: the product tracker's native host core (decisions, bookkeeping, rectangular assignment; csrc/tracker_native.hip) with
 a torch stand-in for the device bank, against the reference OverTracker's recorded behaviour.  The HIP bank faces the
 same sequence in tests/test_tracker_gpu.py."""
+import pytest
 import torch
 
 from _golden import Fixture, maxdiff
 from _standins import Clips, TorchBankTracker as OverTracker
 
 
-def test_tracker_matches_reference_sequence():
-    fx = Fixture("tracker_seq")
+@pytest.mark.parametrize("fixture", ["tracker_seq", "tracker_long"])
+def test_tracker_matches_reference_sequence(fixture):
+    fx = Fixture(fixture)
     trk = OverTracker(fx.i("MAXI"), fx.i("T"), fx.i("WIN"), 1, fx.i("K"), 4, fx.i("E"), tuple(int(v) for v in fx.z["HW"]),
                       torch.device("cpu"), fx.f("THR"))
     saved, n = 0, fx.i("n_clips")

@@ -27,9 +27,12 @@ def _tracker(fx):
                        torch.device("cuda"), fx.f("THR"))
 
 
+@pytest.mark.parametrize("fixture", ["tracker_seq", "tracker_long"])
 @pytest.mark.parametrize("mode", ["per_clip", "runs"])
-def test_hip_tracker_matches_reference_sequence(mode):
-    fx = Fixture("tracker_seq")
+def test_hip_tracker_matches_reference_sequence(mode, fixture):
+    """tracker_long: 44 frames, six window flushes, an instance that leaves for longer than a window and returns under its old id, one
+    that returns under a new id (reference-run golden, oracle/make_golden.py gen_tracker_long)."""
+    fx = Fixture(fixture)
     trk = _tracker(fx)
     clips = _clips(fx)
     saved, n = 0, len(clips)
@@ -98,22 +101,24 @@ def test_counts_fast_path_classic_path_and_sync_fallback_agree(fast, spin_us):
     lib.mdqe_debug_trk_fast(fast); lib.mdqe_debug_trk_spin_us(spin_us)
     try:
         for mode in ("per_clip", "runs"):
-            test_hip_tracker_matches_reference_sequence(mode)
+            for fixture in ("tracker_seq", "tracker_long"):
+                test_hip_tracker_matches_reference_sequence(mode, fixture)
         for seed in (82, 284, 0, 1, 2):
             assert fuzz_tracker.run(seed, gpu=True, many=True) is None, seed
     finally:
         lib.mdqe_debug_trk_fast(1); lib.mdqe_debug_trk_spin_us(2000)
     if fast and spin_us:
+        import numpy as np
         g = torch.Generator(device="cuda").manual_seed(3)
         acc = torch.zeros(4096, device="cuda"); ticket = torch.zeros(16, dtype=torch.int32, device="cuda")
-        out_h = torch.zeros(4096, pin_memory=True); flag = torch.zeros(16, dtype=torch.int32, pin_memory=True)
+        words = torch.zeros(4096, dtype=torch.int64, pin_memory=True)
         for seq, (ns, ni, n) in enumerate([(3, 5, 4 * 96 * 160), (7, 7, 3 * 96 * 160), (1, 1, 1024), (12, 2, 4 * 1000)], start=1):
             a = torch.randn(ns, n, device="cuda", generator=g); b = torch.randn(ni, n, device="cuda", generator=g)
             want = torch.zeros(ns * ni * 3, device="cuda")
             check(lib.mdqe_trk_siou_f32(ptr(a), n, ns, ptr(b), n, ni, n, ptr(want), cur_stream()), "siou")
-            check(lib.mdqe_trk_siou_host_f32(ptr(a), n, ns, ptr(b), n, ni, n, ptr(acc), ptr(ticket), out_h.data_ptr(), flag.data_ptr(), seq, cur_stream()),
-                  "siou_host")
-            check(lib.mdqe_trk_wait_flag(flag.data_ptr(), seq, 100000, cur_stream()), "wait_flag")
-            assert int(flag[0]) == seq and torch.equal(out_h[:ns * ni * 3], want.cpu())
+            check(lib.mdqe_trk_siou_host_f32(ptr(a), n, ns, ptr(b), n, ni, n, ptr(acc), ptr(ticket), words.data_ptr(), seq, cur_stream()), "siou_host")
+            got = np.zeros(ns * ni * 3, dtype=np.float32)
+            check(lib.mdqe_trk_wait_counts(words.data_ptr(), ns * ni * 3, seq, 100000, got.ctypes.data, cur_stream()), "wait_counts")
+            assert np.array_equal(got, want.cpu().numpy())
             torch.cuda.synchronize()
             assert not bool(acc.any()) and int(ticket[0]) == 0          # left clean for the next launch
