@@ -207,14 +207,19 @@ class MDQE(nn.Module):
         use_count = getattr(torch._C, "_storage_Use_Count", None)
         pool = self.__dict__.setdefault("_pin_pool", {})
         free = pool.setdefault(tuple(shape), [])
+        # What is handed out is a VIEW (its own tensor object on the pooled storage): the storage's use count then stays above the pool's
+        # own for as long as a merger, or a result the caller still holds, references the buffer -- the pool's tensor itself is never
+        # given away (two Python references to ONE tensor object count once, and a second track of the same video would get the same
+        # buffer: tests/test_fullsize_gpu.py caught exactly that).
         if use_count is not None:
             for t in free:
                 if use_count(t.untyped_storage()._cdata) <= 2:         # the pool's tensor + the temporary wrapper of this very query
-                    return t
+                    return t[:]
         t = torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True)
         held = sum(b.numel() for bufs in pool.values() for b in bufs)
         if use_count is not None and held + t.numel() <= self.PIN_POOL_GB * 2 ** 30:
             free.append(t)
+            return t[:]
         return t
 
     def _on_device(self):

@@ -82,6 +82,36 @@ def test_linear_frame_cache_segments_and_decoder_batch_do_not_change_a_bit(frame
         assert first >= min(dec_batch, len(clips) - 1)
 
 
+def test_pinned_mask_buffers_are_pooled_but_never_shared():
+    """`MDQE.pinned_mask_buffer` (round 5): the per-track pinned read-back buffers of a video are kept by the model and re-issued once
+    nothing references them any more.  Two requests while the first is held give DIFFERENT storage (a video's tracks never share a
+    buffer); a buffer whose holders -- the merger and the result views handed to the caller -- are gone comes back; results of two
+    consecutive calls held at the same time do not alias."""
+    cfg, model = _small_model()
+    a = model.pinned_mask_buffer((5, 8, 12))
+    b = model.pinned_mask_buffer((5, 8, 12))
+    assert a.is_pinned() and b.is_pinned() and a.data_ptr() != b.data_ptr()
+    pa = a.data_ptr()
+    va = a.view(torch.bool)[:3]                        # what a result holds: a view
+    del a
+    c = model.pinned_mask_buffer((5, 8, 12))
+    assert c.data_ptr() not in (pa, b.data_ptr())      # `va` still holds the first buffer
+    del va
+    d = model.pinned_mask_buffer((5, 8, 12))
+    assert d.data_ptr() == pa                          # ... now it is free again
+    frames = _video(14).cuda()
+    inp = [{"image": frames, "height": 96, "width": 160}]
+    r1 = model(inp)
+    r2 = model(inp)                                    # r1 is still alive: r2 must not write into its buffers
+    _same(r1, r2)
+    assert len(r1["pred_masks"]) > 1
+    ptrs = [m.data_ptr() for m in r1["pred_masks"]] + [m.data_ptr() for m in r2["pred_masks"]]
+    assert len(set(ptrs)) >= len(set(m.data_ptr() for m in r1["pred_masks"])) * 2
+    del r2
+    r3 = model(inp)
+    _same(r1, r3)
+
+
 def test_early_masks_equal_the_direct_path():
     """ClipMerger with n_frames (masks produced per window into pinned memory) vs without (one pass at the end)."""
     cfg, model = _small_model()
