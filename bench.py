@@ -372,7 +372,12 @@ def round_ratio(world):
     the pipeline -- under the compute of round q+1 -- ~1.25 ms per frame -- so a round may shrink to 0.08 x world of the one before and
     still hide its replay; the fewer ranks, the steeper the decrease (and the fewer rounds).  MDQE_BENCH_ROUND_RATIO overrides."""
     v = os.environ.get("MDQE_BENCH_ROUND_RATIO")
-    return float(v) if v else min(0.7, max(0.3, 0.08 * world))
+    if v:
+        return float(v)
+    # Three rounds from three ranks up (ratio >= 0.5): the frame passes of round q+1 are queued BEFORE round q's clip work (the frame stream
+    # must not run dry), so round q's gather trails its frames by about one pass and a TWO-round plan hides next to nothing of round 0's
+    # replay (N = 4 rehearsal: 91 / 29 frames, 30 of 37 ms of replay exposed -- worse than N = 8 on three rounds)
+    return 0.3 if world <= 2 else min(0.7, max(0.5, 0.08 * world))
 
 
 class EmitOnce:
@@ -912,17 +917,17 @@ def main():
 
     def side_config(name, frames, steps):
         """BASELINE.json configs[2] / configs[3] in the SAME invocation as the headline (extra keys of the line): its own model and
-        synthetic video, one warm-up step, `steps` timed steps with the meter on, one isolated pass."""
+        synthetic video, two warm-up steps, `steps` timed steps with the meter on, one isolated pass."""
         t_in = time.perf_counter()
         w = build(name, "workload")
         vid = synth_video(0, frames, seed=0, h=w.fh, w=w.fw).pin_memory()
         fr = list(vid)
         sm = []
         meter.reset()
-        d, o = timed("f32", True, steps=steps, warmup=1, mdl=w.model, frames=fr, step_ms=sm)
+        d, o = timed("f32", True, steps=steps, warmup=2, mdl=w.model, frames=fr, step_ms=sm)      # (two warm-up steps: the first call sizes the frame cache and the pinned pool)
         g, m = meter.summary(), meter.msda_summary()
         gi, mi = isolated_pass(w.model, frames=fr)
-        e = dict(rate(d, frames, steps), steps=steps, warmup=1, frames_per_step=frames, dtype="f32",
+        e = dict(rate(d, frames, steps), steps=steps, warmup=2, frames_per_step=frames, dtype="f32",
                  value_median=frames * 1e3 / median(sm), value_is="mean over the timed steps; value_median = frames / median step time",
                  workload="%s eval-only, H2D included: %d synthetic %dx%d uint8 frames per step from pinned host memory, %d-frame clips stride 1, "
                           "%d-frame windows, one model(inputs) call per step, exact fp32" % (name, frames, w.fh, w.fw, w.cfg.n_frames_test, w.cfg.n_frames_window_test),
@@ -934,53 +939,51 @@ def main():
         e["wall_s"] = round(time.perf_counter() - t_in, 1)
         return e
 
-    def root_load_leg(W, steps):
-        """The N = W root load on this one GPU (sharding.expand_root_load): rank 0's own chunks of a W-rank job + the replay / final masks /
-        mask read-back of all W ranks' clips.  Needs a process group (one rank); `dist` of the enclosing scope is used when there is one."""
-        nonlocal dist
+    def root_load_child(W, budget):
+        """The N = W root load (sharding.expand_root_load: rank 0's own chunks of a W-rank job + the replay / final masks / mask read-back of
+        all W ranks' clips) measured in a CHILD process -- `MDQE_BENCH_ROOT_LOAD=W python bench.py`, a fresh HIP runtime whose streams are
+        created in the sharded job's own order (inside this process, after the single-GPU legs, the same leg lands on a different stream ->
+        hardware-queue map and its replay runs 30 % slower) -- and summarised against THIS run's single-GPU step time."""
+        import subprocess
         t_in = time.perf_counter()
-        made = False
-        if dist is None:
-            import datetime
-            import socket
-            import torch.distributed as d_
-            with socket.socket() as s_:
-                s_.bind(("127.0.0.1", 0))
-                port = s_.getsockname()[1]
-            d_.init_process_group("nccl" if backend == "nccl" else backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
-                                  timeout=datetime.timedelta(seconds=60), **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
-            dist, made = d_, True
+        env = dict(os.environ, MDQE_BENCH_ROOT_LOAD=str(W), MDQE_BENCH_SIDE_CONFIGS="0", MDQE_BENCH_ROOT_LOAD_LEG="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MDQE_BENCH_FORCE_SHARDED"):
+            env.pop(k, None)
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s_.getsockname()[1])
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--frames", str(args.frames), "--no-cpu-baseline", "--no-fast-mode"]
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         try:
-            chunk_ = sharding.round_sizes(args.frames, T, ratio=round_ratio(W))
-            res = {"world": W, "frames_per_rank": args.frames, "frames_virtual": args.frames * W, "chunk_frames_per_round": chunk_}
-            base = {}
-            for key, vw in (("w1", None), ("wN", W)):
-                shards[key] = shard(False, chunk_=chunk_, vw=vw) if vw else shard(False, n_frames=args.frames, chunk_=chunk_)
-                st, sm = [], []
-                d, o = timed("f32", False, steps=steps, warmup=1, key=key, stats=st, step_ms=sm)
-                mean = {k: round(sum(v.get(k, 0.0) for v in st) / max(len(st), 1), 2) for k in STAT_KEYS}
-                base[key] = dict(ms_per_step=1e3 * d / steps, ms_median=median(sm), tracks=getattr(model, "last_num_tracks", None), **mean)
-                del shards[key]
-            w1, wN = base["w1"], base["wN"]
-            res.update(ms_per_step=wN["ms_per_step"], ms_per_step_median=wN["ms_median"], compute=wN["compute"], replay_exposed_ms=wN["replay_exposed"],
-                       replay_total_ms=wN["replay_busy"], gather_ms=round(wN["gather_wait"] + wN["gather_payload"], 2), tracked_instances=wN["tracks"],
-                       d2h_MB_per_step=round((wN["tracks"] or 0) * args.frames * W * fh * fw / 1e6, 1),
-                       sharded_world1={"ms_per_step": w1["ms_per_step"], "compute": w1["compute"], "replay_exposed_ms": w1["replay_exposed"],
-                                       "replay_total_ms": w1["replay_busy"], "tracked_instances": w1["tracks"]},
-                       predicted_efficiency=w1["ms_per_step"] / wN["ms_per_step"],
-                       what="rank 0 of a %d-rank job on this one GPU: it computes its own %d frames per step (the same chunks as in the real job) "
-                            "while its replay thread is fed every gathered round %d times under shifted frame indices (a %d-frame video whose foreign "
-                            "chunks repeat rank 0's clip results): tracker replay, bank updates, window flushes, final_mask_kernel and the device->host "
-                            "copies of the masks carry the N = %d volume.  predicted_efficiency = step time of the same sharded schedule with the root "
-                            "load of ONE rank / with the load of %d (rank 0 is the only rank that does more than compute + send, so its step time is "
-                            "the job's); the wire and the other ranks' pace are not in it" % (W, args.frames, W, args.frames * W, W, W))
-            res["wall_s"] = round(time.perf_counter() - t_in, 1)
-            return res
-        finally:
-            if made:
-                torch.cuda.synchronize()
-                dist.destroy_process_group()
-                dist = None
+            so, se = proc.communicate(timeout=budget)
+        except subprocess.TimeoutExpired:
+            proc.kill()                                    # (this child's own pid)
+            proc.communicate()
+            return {"error": "the child did not finish within %g s" % budget}
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or len(lines) != 1:
+            return {"error": "child exit code %s: %s" % (proc.returncode, se[-400:])}
+        c = json.loads(lines[0])
+        sb = c["scaling_breakdown"]
+        pr = {k: v[0] for k, v in sb["per_rank_ms"].items()}
+        single_ms = 1e3 * dt / args.steps
+        return {"world": W, "frames_per_rank": args.frames, "frames_virtual": args.frames * W, "steps": c["steps"], "warmup": c["warmup"],
+                "chunk_frames_per_round": sharding.round_sizes(args.frames, T, ratio=round_ratio(W)), "verified": c.get("verified"),
+                "ms_per_step": c["ms_per_step"], "frames_per_s_per_rank": c["value"], "frames_per_s_per_rank_median": c.get("value_median"),
+                "compute": pr["compute"], "replay_exposed_ms": pr["replay_exposed"], "replay_total_ms": pr.get("replay_busy"),
+                "gather_ms": round(pr["gather_wait"] + pr["gather_payload"], 2), "halo_frac": sb["halo_frac"],
+                "tracker_native_ms_per_step": sb.get("tracker_native_ms_per_step"), "tracked_instances": c["config"]["tracked_instances"],
+                "d2h_MB_per_step": round((c["config"]["tracked_instances"] or 0) * args.frames * W * fh * fw / 1e6, 1),
+                "single_gpu_ms_per_step": single_ms, "predicted_efficiency": single_ms / c["ms_per_step"],
+                "what": "rank 0 of a %d-rank job on this one GPU, in a child process (`MDQE_BENCH_ROOT_LOAD=%d python bench.py`): it computes its own %d frames "
+                        "per step (the same chunks as in the real job) while its replay thread is fed every gathered round as rank 0 of that job would "
+                        "receive it (a %d-frame video whose foreign chunks repeat rank 0's clip results under their own frame indices): tracker replay, bank "
+                        "updates, window flushes, final_mask_kernel and the device->host copies of the masks carry the N = %d volume.  predicted_efficiency "
+                        "= this run's single-GPU step time / rank 0's step time there (rank 0 is the only rank that does more than compute + send, so its "
+                        "step is the job's); the wire and the other ranks' pace are not in it.  N = 1 / 2 / 4 / 8: profiles/r05_root_load_N.json"
+                        % (W, W, args.frames, args.frames * W, W),
+                "wall_s": round(time.perf_counter() - t_in, 1)}
 
     line = None
     if rank == 0:
@@ -1065,12 +1068,12 @@ def main():
     rl = os.environ.get("MDQE_BENCH_ROOT_LOAD_LEG", "")             # "W": that world, "0": never, unset: 8 with the other extras
     rl_w = int(rl) if rl else (8 if not args.no_fast_mode else 0)
     if not sharded and rank == 0 and rl_w > 1 and args.config == "R50_ovis_360" and args.precision == "f32":
-        budget = float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "90"))
-        with Deadline(budget, give_up("root_load", budget), emitted):
-            try:
-                line["root_load"] = root_load_leg(rl_w, max(3, min(args.steps, 5)))
-            except Exception as e:
-                line["root_load"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        budget = float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "150"))
+        try:
+            torch.cuda.empty_cache()
+            line["root_load"] = root_load_child(rl_w, budget)
+        except Exception as e:
+            line["root_load"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
@@ -1108,9 +1111,11 @@ def main():
 FRAME_SIZES = {"R50_ovis_360": (360, 640), "R50_ovis_720": (640, 1138), "swinl_ovis": (480, 853)}
 
 
-TRAFFIC_REF_GEMM = ("profiles/r03_pmc_gemm_ffn1_{FETCH,WRITE}_SIZE.csv (the largest launch shape of a 40-frame pass, M=204000 N=1024 K=256 +GELU: "
-                    "2 x FETCH_SIZE + WRITE_SIZE = 346 + 836 = 1182 MB per launch vs 1046 MB algorithmic = 1.13x; MFMA pipe busy 0.71 of the kernel's "
-                    "cycles, 0 LDS bank conflicts: r03_pmc_gemm_ffn1_SQ_BUSY_CYCLES.csv)")
+TRAFFIC_REF_GEMM = ("profiles/r05_pmc_gemm_p{1..4}.csv + r05_pmc_gemm_summary.txt (round 5's kernels, separate --pmc passes, tools/pmc_gemm_r05.sh; the largest launch "
+                    "shapes of a 40-frame pass).  128x128 tile, FFN1 M=204000 N=1024 K=256 + GELU: 2 x FETCH_SIZE + WRITE_SIZE = 247 + 836 = 1083 MB per launch vs "
+                    "1046 MB algorithmic = 1.04x; MFMA pipe busy 0.857 of the kernel's cycles.  64x256 tile + LayerNorm epilogue, FFN2 M=204000 N=256 K=1024 "
+                    "(+ residual, in place): 2 x FETCH_SIZE = 1155 MB vs 1046 MB algorithmic reads = 1.10x, WRITE_SIZE = the 209 MB output (418 MB with the "
+                    "second LayerNorm's output); MFMA pipe busy 0.861")
 TRAFFIC_REF_MSDA = ("profiles/r04_pmc_msda_v3_p{1..8}.csv + r04_pmc_msda_v3_summary.txt (eight separate --pmc passes over the round's final kernel, the 40-frame "
                     "360p encoder launch: 2 x FETCH_SIZE + WRITE_SIZE = 2 x 390 + 209 MB = 989 MB fetched + written vs 732 MB algorithmic = 1.35x; TA busy "
                     "0.59 of the kernel's cycles on average, 0.75 on the busiest CU; L1 hit 63 %, L2 hit 82 %; LDS conflicts 18 % of LDS-active cycles); "

@@ -281,12 +281,16 @@ class MDQE(nn.Module):
             ring["enc"][at:at + n].copy_(enc)
 
     @staticmethod
-    def pass_bounds(n_frames, fbatch, taper=True, tail=0):
+    def pass_bounds(n_frames, fbatch, taper=True, tail=0, split_small=False):
         """End frames of the passes of the per-frame stages over a chunk of `n_frames`: uniform passes of `fbatch` frames, or
         (taper) a half-size first pass -- the clip stream starts after half a pass instead of a whole one -- and a last pass of
         at most `tail` frames (0: half a pass) -- the tail that runs with an idle frame stream (last decoder batch, tracker,
         mask read-back) is shorter.  Measured: 20/40/40/20 at 360p +0.2-1.1 %; shorter tails lose to the extra pass."""
         bounds = list(range(fbatch, n_frames, fbatch)) + [n_frames]
+        if split_small and taper and 16 <= n_frames <= fbatch:
+            # a chunk of a sharded video that fits ONE pass goes in two: a round's clip work trails its frames by about the pass queued
+            # behind them (the next round's first), and the round is gathered -- and its tracker replay can start on rank 0 -- only then
+            return [n_frames // 2, n_frames]
         if taper and n_frames > fbatch:
             h = max(fbatch // 2, 1)
             t = max(min(tail, h), 1) if tail > 0 else h
@@ -333,7 +337,7 @@ class MDQE(nn.Module):
     CACHE_GB = float(os.environ.get("MDQE_CACHE_GB", "24"))       # HBM budget of ONE frame-cache buffer (a long video uses two)
 
     def iter_clip_results(self, frames_dev, clips, frame_offset=0, trace=None, primed=False, on_frames_queued=None, h2d=None,
-                          halo=None, side_streams=True, prime_all=True):
+                          halo=None, side_streams=True, prime_all=True, split_small=False):
         """Per-frame features (computed once, streamed in passes of `frame_batch` frames) + decoder + inference_clip for
         `clips` (global frame indices; frames_dev[0] is global frame `frame_offset`).  Yields (start, end, last, res).
 
@@ -364,7 +368,7 @@ class MDQE(nn.Module):
             if any(c[1] - c[0] != Tn or c[0] < frame_offset - (Tn - 1) for c in strad) or not clips:
                 raise RuntimeError("halo exchange: a chunk must hold at least one whole clip and its straddling clips T frames")
             lead = Tn - 1 if strad else 0
-        bounds = self.pass_bounds(n_local, fbatch, self.taper_passes, self.taper_tail)
+        bounds = self.pass_bounds(n_local, fbatch, self.taper_passes, self.taper_tail, split_small=split_small)
         cuda = frames_dev.is_cuda
         clip_stream = torch.cuda.current_stream(frames_dev.device) if cuda else None
         if cuda and self._frame_stream is None:

@@ -22,6 +22,12 @@ COLLECTIVE_TIMEOUT_S = float(os.environ.get("MDQE_COLLECTIVE_TIMEOUT_S", "120"))
 # frame stream's GEMMs; tools A/B with GPU_MAX_HW_QUEUES=8)
 SHARD_SIDE_STREAMS = os.environ.get("MDQE_SHARD_SIDE_STREAMS", "0") == "1"
 
+# MDQE_SHARD_SPLIT_PASS=1: a chunk of a round behind the first that fits one frame pass is run as two half passes (meta_arch.MDQE.pass_bounds
+# split_small) -- the previous round's clip work, and with it that round's gather and the start of its replay on rank 0, trails the pass
+# queued behind it.  Measured in the N = 8 / N = 4 root-load rehearsal: 179.2 against 177.3 ms, 169.6 against 166.5 ms per step -- no gain, so
+# off by default (profiles/r05_ab_split_pass.txt)
+SHARD_SPLIT_PASS = os.environ.get("MDQE_SHARD_SPLIT_PASS", "0") == "1"
+
 FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
 
 
@@ -439,6 +445,8 @@ class _Job:
             kw["halo"] = self._halo(q, g)
         # (no side streams inside the decoder here: the sharded schedule already runs RCCL's stream and the replay thread's tracker
         # stream beside the frame / clip / copy streams, and HIP has 4 hardware queues for all of them -- meta_arch.iter_clip_results)
+        if SHARD_SPLIT_PASS and q > 0:
+            kw["split_small"] = True                   # (rounds behind the first: their gather trails the NEXT round's first pass)
         gen = self.model.iter_clip_results(fr, self.plan[g][0], self.plan[g][1], primed=True, side_streams=SHARD_SIDE_STREAMS, **kw)
         next(gen)
         return gen

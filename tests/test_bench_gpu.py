@@ -68,7 +68,9 @@ def test_bench_side_configs_and_root_load_ride_in_the_same_line():
     rl = d["root_load"]
     assert "error" not in rl, rl
     assert rl["world"] == 8 and rl["frames_virtual"] == 8 * 36 and rl["ms_per_step"] > 0 and 0.0 < rl["predicted_efficiency"] <= 1.05
-    assert rl["replay_total_ms"] >= rl["sharded_world1"]["replay_total_ms"] and rl["compute"] > 0 and rl["tracked_instances"] >= 1
+    assert rl["verified"] is True and rl["replay_total_ms"] > 0 and rl["compute"] > 0 and rl["tracked_instances"] >= 1
+    assert abs(rl["predicted_efficiency"] - rl["single_gpu_ms_per_step"] / rl["ms_per_step"]) < 1e-9
+    assert rl["tracker_native_ms_per_step"]["updates_per_step"] >= 8 * 30       # the replay really carried eight ranks' clips
 
 
 def test_bench_gpus_2_runs_two_ranks_without_torchrun():

@@ -202,7 +202,7 @@ class _FakeModel:
     def __init__(self, log):
         self.log = log
 
-    def iter_clip_results(self, frames, clips, f0, trace=None, primed=False, on_frames_queued=None, side_streams=True):
+    def iter_clip_results(self, frames, clips, f0, trace=None, primed=False, on_frames_queued=None, side_streams=True, split_small=False):
         self.log.append(("frames_queued", clips[0][0]))
         if primed:
             yield None
@@ -333,7 +333,7 @@ def test_producer_failure_stops_the_replay_workers():
     import mdqe_cvpr2023_amd.meta_arch as MA
 
     class Boom(_FakeModel):
-        def iter_clip_results(self, frames, clips, f0, trace=None, primed=False, on_frames_queued=None, side_streams=True):
+        def iter_clip_results(self, frames, clips, f0, trace=None, primed=False, on_frames_queued=None, side_streams=True, split_small=False):
             if frames.shape[0] == 7:
                 raise ValueError("bad video")
             yield from super().iter_clip_results(frames, clips, f0, trace, primed, on_frames_queued)
