@@ -374,6 +374,7 @@ def box_xyxy_to_cxcywh(b):
     return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], -1)
 
 
+INST_STREAMS = {}            # launch stream handle -> the decoder's instance-chain side stream (process-wide: see meta_arch._STREAMS)
 DEC_TWO_STREAMS = os.environ.get("MDQE_DEC_TWO_STREAMS", "1") != "0"   # instance-level chain of a decoder layer beside the next layer's box level
 DEC_FUSED = os.environ.get("MDQE_DEC_FUSED", "1") != "0"   # 0: position embedding materialised, separate q/k and v projections (A/B)
 
@@ -648,6 +649,13 @@ class Engine:
         P, cfg = self.P, self.cfg
         Bc = len(starts)
         fidx_h = np.asarray([[a + t for t in range(T)] for a in starts], dtype=np.int32).reshape(Bc, T)
+        # the cache may be a long linear buffer (meta_arch.iter_clip_results): the batch addresses rows [lo, hi) of it -- the kernels get
+        # views of exactly that range (their value / row bounds are then the frames this batch reads, which is also what the bench's
+        # byte model of the decoder gathers counts) and indices relative to it
+        lo, hi = int(fidx_h.min()), int(fidx_h.max()) + 1
+        if lo > 0 or hi < cache["content"].shape[0]:
+            cache = {k: v[lo:hi] for k, v in cache.items() if k in ("coords", "content", "emb", "vals")}
+            fidx_h = fidx_h - lo
         fidx = self._to_dev_i32(fidx_h)                                                        # [Bc,T] cache frame of (clip, t)
         content, vals = cache["content"], cache["vals"]
         Q, C = content.shape[1], content.shape[2]
@@ -707,7 +715,7 @@ class Engine:
         main = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
         two = DEC_TWO_STREAMS and two_streams and main is not None and len(P.dec) > 1
         if two:
-            pool = self.__dict__.setdefault("_inst_streams", {})       # one side stream per launch stream (two decoders may run at once)
+            pool = INST_STREAMS                         # one side stream per launch stream (two decoders may run at once), shared by every engine
             side = pool.get(main.cuda_stream)
             if side is None:
                 side = pool[main.cuda_stream] = torch.cuda.Stream(self.dev, priority=-1)

@@ -39,7 +39,35 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
         m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
+# The pipeline's HIP streams, ONE set per device and process, shared by every MDQE instance (a process runs one model at a time, as the
+# reference's harness does).  HIP deals streams onto its hardware queues in the order they are first used and a queue is served in order,
+# so WHICH streams share a queue decides how well the pipeline overlaps (tools/stream_map_ab.py): a second model in the same process -- the
+# bench's extra configurations, an evaluator that rebuilds the model -- used to create a second set of streams and land on another, usually
+# worse, deal (Swin-L as the third model of a bench process: 135 against 150 frames/s in a process of its own).
+_STREAMS = {}
+
+
+def _shared_stream(name):
+    def key(self):
+        d = self.device
+        return ("cpu",) if d.type != "cuda" else (d.index if d.index is not None else torch.cuda.current_device(),)
+
+    def get(self):
+        return _STREAMS.get(key(self) + (name,))
+
+    def put(self, stream):
+        if stream is not None:
+            _STREAMS[key(self) + (name,)] = stream
+    return property(get, put)
+
+
 class MDQE(nn.Module):
+    _trk_stream = _shared_stream("tracker")
+    _frame_stream = _shared_stream("frame")
+    _copy_stream = _shared_stream("copy")
+    _ahead_stream = _shared_stream("ahead")
+    _work_stream = _shared_stream("work")
+
     def __init__(self, cfg, state_dict=None, backbone_fn=None, seed=0):
         super().__init__()
         self.cfg = cfg if isinstance(cfg, MDQEConfig) else from_d2_cfg(cfg)
@@ -63,11 +91,8 @@ class MDQE(nn.Module):
         self._extra = {k: v for k, v in sd.items() if k not in man}      # e.g. custom-backbone weights
         # frames per pass of the per-frame stages: 0 = by resolution (~300k encoder tokens per pass: at most 40 frames: 40 at 360p, 20 at 640p)
         self.frame_batch = int(os.environ.get("MDQE_FRAME_BATCH", "0"))
-        self._trk_stream = None
         # priority of the tracker's stream (0 normal, -1 high): its kernels are small and sit on the per-clip critical path of the replay
         self.trk_priority = int(os.environ.get("MDQE_TRK_PRIORITY", "0"))
-        self._frame_stream = None
-        self._copy_stream = None
         self.resize_on_device = False               # True: frames arrive at native size and get the mapper's ResizeShortestEdge here
         self.rle_output = False                     # True: forward() returns per-frame COCO RLEs ("pred_rles") instead of dense masks
         self.merge_on_cpu = None                    # None: cfg.merge_on_cpu (MODEL.MDQE.MERGE_ON_CPU); True / False override it
@@ -79,10 +104,8 @@ class MDQE(nn.Module):
         # the decoder of a group starts as soon as ITS inputs of the group's last frame pass exist (queries + value projections); the
         # mask-feature head of that pass, which only inference_clip reads, runs beside the decoder's first layers (round 4)
         self.early_decode = os.environ.get("MDQE_EARLY_DECODE", "1") != "0"
-        self._ahead_stream = None
         self.overlap_streams = os.environ.get("MDQE_OVERLAP_STREAMS", "1") != "0"   # frame stages on their own stream
         self.clip_priority = os.environ.get("MDQE_CLIP_PRIORITY", "1") != "0"       # per-clip stages on a high-priority stream
-        self._work_stream = None
         self.stage_times = None
         self.taper_passes = os.environ.get("MDQE_TAPER_PASSES", "1") != "0"   # half-size first / last frame pass (pipeline fill / drain)
         self.taper_tail = int(os.environ.get("MDQE_TAPER_TAIL", "0"))          # frames of the last pass (0: half a pass)
@@ -158,7 +181,7 @@ class MDQE(nn.Module):
         if order:
             if self._ahead_stream is None:
                 self._ahead_stream = torch.cuda.Stream(self.device, priority=-1)
-            pool = self.engine.__dict__.setdefault("_inst_streams", {})
+            from .engine import INST_STREAMS as pool
             inst = pool.setdefault(self._work_stream.cuda_stream, torch.cuda.Stream(self.device, priority=-1))
             table = {"w": self._work_stream, "i": inst, "a": self._ahead_stream, "c": self._copy_stream, "f": self._frame_stream, "t": self._trk_stream}
             for ch in order:

@@ -35,9 +35,10 @@ with torch.no_grad():
     for rep in range(3):
         m = ClipMerger(model, (360, 640), (360, 640), (geo.Hp // ms, geo.Wp // ms), n_frames=W * L)
         t_flush = [0.0]
-        orig = m._early_masks
-        def timed_early(mm, orig=orig):
-            t0 = time.perf_counter(); orig(mm); t_flush[0] += time.perf_counter() - t0
+        import types, weakref
+        wm = weakref.ref(m)                         # (no cycle merger -> wrapper -> merger: the pinned pool re-issues a video's buffers when the
+        def timed_early(mm, wm=wm):                 #  LAST reference to its result is gone, and a cycle would keep them until a gc pass)
+            t0 = time.perf_counter(); ClipMerger._early_masks(wm(), mm); t_flush[0] += time.perf_counter() - t0
         m._early_masks = timed_early
         lib.mdqe_debug_trk_times(None, 1)
         torch.cuda.synchronize()
