@@ -460,6 +460,55 @@ def fail_hook(where, rank):
         time.sleep(3600)
 
 
+def root_load_child(W, budget, frames, config):
+    """The N = W root load (sharding.expand_root_load: rank 0's own chunks of a W-rank job + the replay / final masks / mask read-back of
+    all W ranks' clips) measured in a CHILD process -- `MDQE_BENCH_ROOT_LOAD=W python bench.py`, a fresh HIP runtime whose streams are
+    created in the sharded job's own order.  The parent starts it before it touches the GPU itself (see main)."""
+    import subprocess
+    t_in = time.perf_counter()
+    env = dict(os.environ, MDQE_BENCH_ROOT_LOAD=str(W), MDQE_BENCH_SIDE_CONFIGS="0", MDQE_BENCH_ROOT_LOAD_LEG="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MDQE_BENCH_FORCE_SHARDED"):
+        env.pop(k, None)
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(s_.getsockname()[1])
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--frames", str(frames), "--no-cpu-baseline", "--no-fast-mode"]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = proc.communicate(timeout=budget)
+    except subprocess.TimeoutExpired:
+        proc.kill()                                    # (this child's own pid)
+        proc.communicate()
+        return {"error": "the child did not finish within %g s" % budget}
+    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or len(lines) != 1:
+        return {"error": "child exit code %s: %s" % (proc.returncode, se[-400:])}
+    c = json.loads(lines[0])
+    sb = c["scaling_breakdown"]
+    pr = {k: v[0] for k, v in sb["per_rank_ms"].items()}
+    from mdqe_cvpr2023_amd import sharding
+    from mdqe_cvpr2023_amd.config import PRESETS
+    fh, fw = FRAME_SIZES[config]
+    T = PRESETS[config].n_frames_test
+    return {"world": W, "frames_per_rank": frames, "frames_virtual": frames * W, "steps": c["steps"], "warmup": c["warmup"],
+            "chunk_frames_per_round": sharding.round_sizes(frames, T, ratio=round_ratio(W)), "verified": c.get("verified"),
+            "ms_per_step": c["ms_per_step"], "frames_per_s_per_rank": c["value"], "frames_per_s_per_rank_median": c.get("value_median"),
+            "compute": pr["compute"], "replay_exposed_ms": pr["replay_exposed"], "replay_total_ms": pr.get("replay_busy"),
+            "gather_ms": round(pr["gather_wait"] + pr["gather_payload"], 2), "halo_frac": sb["halo_frac"],
+            "tracker_native_ms_per_step": sb.get("tracker_native_ms_per_step"), "tracked_instances": c["config"]["tracked_instances"],
+            "d2h_MB_per_step": round((c["config"]["tracked_instances"] or 0) * frames * W * fh * fw / 1e6, 1),
+            "what": "rank 0 of a %d-rank job on this one GPU, in a child process (`MDQE_BENCH_ROOT_LOAD=%d python bench.py`): it computes its own %d frames "
+                    "per step (the same chunks as in the real job) while its replay thread is fed every gathered round as rank 0 of that job would "
+                    "receive it (a %d-frame video whose foreign chunks repeat rank 0's clip results under their own frame indices): tracker replay, bank "
+                    "updates, window flushes, final_mask_kernel and the device->host copies of the masks carry the N = %d volume.  predicted_efficiency "
+                    "= this run's single-GPU step time / rank 0's step time there (rank 0 is the only rank that does more than compute + send, so its "
+                    "step is the job's); the wire and the other ranks' pace are not in it.  N = 1 / 2 / 4 / 8: profiles/r05_root_load_N.json"
+                    % (W, W, frames, frames * W, W),
+            "wall_s": round(time.perf_counter() - t_in, 1)}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -492,6 +541,7 @@ def main():
                     help="R50_ovis_360 is BASELINE.json's metric config; R50_ovis_720 = 640x1138 frames (configs[2]); "
                          "swinl_ovis = SwinV2-L, 480x853 frames, 2-frame clips (configs[3])")
     args = ap.parse_args()
+    t_start = time.perf_counter()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
@@ -541,6 +591,17 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if one_dev:
         local = 0
+    # The N = 8 root-load rehearsal of the default line runs FIRST, as a child process that has the GPU to itself (this process has not
+    # touched the GPU runtime yet); its summary joins the line at the end
+    rl = os.environ.get("MDQE_BENCH_ROOT_LOAD_LEG", "")             # "W": that world, "0": never, unset: 8 with the other extras
+    rl_w = int(rl) if rl else (8 if not args.no_fast_mode else 0)
+    root_load_res = None
+    if not sharded and not probe and rank == 0 and rl_w > 1 and args.config == "R50_ovis_360" and args.precision == "f32":
+        try:
+            root_load_res = root_load_child(rl_w, float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "150")), args.frames, args.config)
+        except Exception as e:                                      # an extra must not take the headline down
+            root_load_res = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if not probe:
         if not one_dev and world > 1 and torch.cuda.device_count() < world:
             print("bench.py: --gpus %d but only %d visible" % (world, torch.cuda.device_count()), file=sys.stderr)
@@ -585,7 +646,6 @@ def main():
     from mdqe_cvpr2023_amd import sharding
     from mdqe_cvpr2023_amd import ops
 
-    t_start = time.perf_counter()
     meter = Meter()
     meter.install()
 
@@ -939,52 +999,6 @@ def main():
         e["wall_s"] = round(time.perf_counter() - t_in, 1)
         return e
 
-    def root_load_child(W, budget):
-        """The N = W root load (sharding.expand_root_load: rank 0's own chunks of a W-rank job + the replay / final masks / mask read-back of
-        all W ranks' clips) measured in a CHILD process -- `MDQE_BENCH_ROOT_LOAD=W python bench.py`, a fresh HIP runtime whose streams are
-        created in the sharded job's own order (inside this process, after the single-GPU legs, the same leg lands on a different stream ->
-        hardware-queue map and its replay runs 30 % slower) -- and summarised against THIS run's single-GPU step time."""
-        import subprocess
-        t_in = time.perf_counter()
-        env = dict(os.environ, MDQE_BENCH_ROOT_LOAD=str(W), MDQE_BENCH_SIDE_CONFIGS="0", MDQE_BENCH_ROOT_LOAD_LEG="0")
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MDQE_BENCH_FORCE_SHARDED"):
-            env.pop(k, None)
-        import socket
-        with socket.socket() as s_:
-            s_.bind(("127.0.0.1", 0))
-            env["MASTER_PORT"] = str(s_.getsockname()[1])
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--frames", str(args.frames), "--no-cpu-baseline", "--no-fast-mode"]
-        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        try:
-            so, se = proc.communicate(timeout=budget)
-        except subprocess.TimeoutExpired:
-            proc.kill()                                    # (this child's own pid)
-            proc.communicate()
-            return {"error": "the child did not finish within %g s" % budget}
-        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
-        if proc.returncode != 0 or len(lines) != 1:
-            return {"error": "child exit code %s: %s" % (proc.returncode, se[-400:])}
-        c = json.loads(lines[0])
-        sb = c["scaling_breakdown"]
-        pr = {k: v[0] for k, v in sb["per_rank_ms"].items()}
-        single_ms = 1e3 * dt / args.steps
-        return {"world": W, "frames_per_rank": args.frames, "frames_virtual": args.frames * W, "steps": c["steps"], "warmup": c["warmup"],
-                "chunk_frames_per_round": sharding.round_sizes(args.frames, T, ratio=round_ratio(W)), "verified": c.get("verified"),
-                "ms_per_step": c["ms_per_step"], "frames_per_s_per_rank": c["value"], "frames_per_s_per_rank_median": c.get("value_median"),
-                "compute": pr["compute"], "replay_exposed_ms": pr["replay_exposed"], "replay_total_ms": pr.get("replay_busy"),
-                "gather_ms": round(pr["gather_wait"] + pr["gather_payload"], 2), "halo_frac": sb["halo_frac"],
-                "tracker_native_ms_per_step": sb.get("tracker_native_ms_per_step"), "tracked_instances": c["config"]["tracked_instances"],
-                "d2h_MB_per_step": round((c["config"]["tracked_instances"] or 0) * args.frames * W * fh * fw / 1e6, 1),
-                "single_gpu_ms_per_step": single_ms, "predicted_efficiency": single_ms / c["ms_per_step"],
-                "what": "rank 0 of a %d-rank job on this one GPU, in a child process (`MDQE_BENCH_ROOT_LOAD=%d python bench.py`): it computes its own %d frames "
-                        "per step (the same chunks as in the real job) while its replay thread is fed every gathered round as rank 0 of that job would "
-                        "receive it (a %d-frame video whose foreign chunks repeat rank 0's clip results under their own frame indices): tracker replay, bank "
-                        "updates, window flushes, final_mask_kernel and the device->host copies of the masks carry the N = %d volume.  predicted_efficiency "
-                        "= this run's single-GPU step time / rank 0's step time there (rank 0 is the only rank that does more than compute + send, so its "
-                        "step is the job's); the wire and the other ranks' pace are not in it.  N = 1 / 2 / 4 / 8: profiles/r05_root_load_N.json"
-                        % (W, W, args.frames, args.frames * W, W),
-                "wall_s": round(time.perf_counter() - t_in, 1)}
-
     line = None
     if rank == 0:
         line = {
@@ -1065,15 +1079,11 @@ def main():
                     line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         ops.set_gemm_precision("f32")
 
-    rl = os.environ.get("MDQE_BENCH_ROOT_LOAD_LEG", "")             # "W": that world, "0": never, unset: 8 with the other extras
-    rl_w = int(rl) if rl else (8 if not args.no_fast_mode else 0)
-    if not sharded and rank == 0 and rl_w > 1 and args.config == "R50_ovis_360" and args.precision == "f32":
-        budget = float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "150"))
-        try:
-            torch.cuda.empty_cache()
-            line["root_load"] = root_load_child(rl_w, budget)
-        except Exception as e:
-            line["root_load"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if root_load_res is not None and rank == 0:
+        if "ms_per_step" in root_load_res:
+            single_ms = 1e3 * dt / args.steps
+            root_load_res.update(single_gpu_ms_per_step=single_ms, predicted_efficiency=single_ms / root_load_res["ms_per_step"])
+        line["root_load"] = root_load_res
 
     if rank == 0:
         line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
