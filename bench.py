@@ -374,10 +374,11 @@ def round_ratio(world):
     v = os.environ.get("MDQE_BENCH_ROUND_RATIO")
     if v:
         return float(v)
-    # Three rounds from three ranks up (ratio >= 0.5): the frame passes of round q+1 are queued BEFORE round q's clip work (the frame stream
+    # Three rounds at every world size (ratio >= 0.5): the frame passes of round q+1 are queued BEFORE round q's clip work (the frame stream
     # must not run dry), so round q's gather trails its frames by about one pass and a TWO-round plan hides next to nothing of round 0's
     # replay (N = 4 rehearsal: 91 / 29 frames, 30 of 37 ms of replay exposed -- worse than N = 8 on three rounds)
-    return 0.3 if world <= 2 else min(0.7, max(0.5, 0.08 * world))
+    # (one and two ranks as well: the one-rank rehearsal runs 157.6 ms on 69 / 34 / 17 against 161.9 on 92 / 28)
+    return min(0.7, max(0.5, 0.08 * world))
 
 
 class EmitOnce:

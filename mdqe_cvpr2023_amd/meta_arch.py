@@ -45,6 +45,7 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
 # bench's extra configurations, an evaluator that rebuilds the model -- used to create a second set of streams and land on another, usually
 # worse, deal (Swin-L as the third model of a bench process: 135 against 150 frames/s in a process of its own).
 _STREAMS = {}
+HALO_EARLY_DECODE = os.environ.get("MDQE_HALO_EARLY_DECODE", "1") != "0"     # (A/B knob: 0 = round 4's behaviour)
 
 
 def _shared_stream(name):
@@ -456,9 +457,9 @@ class MDQE(nn.Module):
                             if end >= c1:
                                 break
                 started = True
-                # what the DECODER reads of this pass is complete (the mask features may still be on their way); not with the halo exchange,
-                # whose straddling clips write cache rows on the clip stream
-                dr = torch.cuda.Event() if cuda and self.early_decode and halo is None else None
+                # what the DECODER reads of this pass is complete (the mask features may still be on their way).  (Also with the halo
+                # exchange since round 5: the neighbour's rows are written on the clip stream itself, in front of the group that reads them.)
+                dr = torch.cuda.Event() if cuda and self.early_decode and (halo is None or HALO_EARLY_DECODE) else None
                 self._frame_cache(frames_dev[nxt:c1], geo, ring=bufs[seg["b"]], at=row, dec_ready=dr)
                 ready = None
                 if cuda:

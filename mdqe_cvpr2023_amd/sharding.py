@@ -26,6 +26,7 @@ SHARD_SIDE_STREAMS = os.environ.get("MDQE_SHARD_SIDE_STREAMS", "0") == "1"
 # split_small) -- the previous round's clip work, and with it that round's gather and the start of its replay on rank 0, trails the pass
 # queued behind it.  Measured in the N = 8 / N = 4 root-load rehearsal: 179.2 against 177.3 ms, 169.6 against 166.5 ms per step -- no gain, so
 # off by default (profiles/r05_ab_split_pass.txt)
+HALO_LOCAL = os.environ.get("MDQE_HALO_LOCAL", "0") == "1"
 SHARD_SPLIT_PASS = os.environ.get("MDQE_SHARD_SPLIT_PASS", "0") == "1"
 
 FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
@@ -358,6 +359,15 @@ class _Halo:
         self.tail_sent = True
         T1, N, C, Hm, Wm, M = self.dims
         ops = []
+        if HALO_LOCAL and self.send_to is not None and self.send_to == self.recv_from:
+            # (tools A/B at world 1: the message handed over in place of the grouped send/recv to oneself -- what the exchange costs
+            # WITHOUT the communicator)
+            k = enc_tail.shape[0]
+            self.recv_buf = torch.cat([enc_tail.reshape(k, -1), mf_tail.reshape(k, -1)], 1).contiguous()
+            self.local_ev = torch.cuda.Event() if self.recv_buf.is_cuda else None
+            if self.local_ev is not None:
+                self.local_ev.record()
+            return
         if self.send_to is not None:
             k = enc_tail.shape[0]
             flat = torch.cat([enc_tail.reshape(k, -1), mf_tail.reshape(k, -1)], 1).contiguous()
@@ -374,6 +384,8 @@ class _Halo:
         for w in self.works:
             w.wait()
         self.works = []
+        if getattr(self, "local_ev", None) is not None:
+            torch.cuda.current_stream().wait_event(self.local_ev)
         if self.recv_buf is None:
             return None
         if self.host:
