@@ -463,51 +463,75 @@ def fail_hook(where, rank):
 
 def root_load_child(W, budget, frames, config):
     """The N = W root load (sharding.expand_root_load: rank 0's own chunks of a W-rank job + the replay / final masks / mask read-back of
-    all W ranks' clips) measured in a CHILD process -- `MDQE_BENCH_ROOT_LOAD=W python bench.py`, a fresh HIP runtime whose streams are
-    created in the sharded job's own order.  The parent starts it before it touches the GPU itself (see main)."""
+    all W ranks' clips) measured in CHILD processes -- `MDQE_BENCH_ROOT_LOAD=W python bench.py`, a fresh HIP runtime whose streams are
+    created in the sharded job's own order, alone on the GPU: the parent starts them before it touches the GPU itself (see main).  With
+    rank 0 resting in the last round (sharding.rest_root_sizes) the other ranks carry more frames than rank 0, so a second child plays
+    rank 1 of the same plan (`MDQE_BENCH_AS_RANK=1`: its chunks, compute + gather, no replay) and the job's step is the slower of the two."""
+    import socket
     import subprocess
     t_in = time.perf_counter()
-    env = dict(os.environ, MDQE_BENCH_ROOT_LOAD=str(W), MDQE_BENCH_SIDE_CONFIGS="0", MDQE_BENCH_ROOT_LOAD_LEG="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MDQE_BENCH_FORCE_SHARDED"):
-        env.pop(k, None)
-    import socket
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        env["MASTER_PORT"] = str(s_.getsockname()[1])
-    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--frames", str(frames), "--no-cpu-baseline", "--no-fast-mode"]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    try:
-        so, se = proc.communicate(timeout=budget)
-    except subprocess.TimeoutExpired:
-        proc.kill()                                    # (this child's own pid)
-        proc.communicate()
-        return {"error": "the child did not finish within %g s" % budget}
-    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
-    if proc.returncode != 0 or len(lines) != 1:
-        return {"error": "child exit code %s: %s" % (proc.returncode, se[-400:])}
-    c = json.loads(lines[0])
-    sb = c["scaling_breakdown"]
-    pr = {k: v[0] for k, v in sb["per_rank_ms"].items()}
+
+    def child(extra):
+        env = dict(os.environ, MDQE_BENCH_ROOT_LOAD=str(W), MDQE_BENCH_SIDE_CONFIGS="0", MDQE_BENCH_ROOT_LOAD_LEG="0", **extra)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MDQE_BENCH_FORCE_SHARDED"):
+            env.pop(k, None)
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s_.getsockname()[1])
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--frames", str(frames), "--no-cpu-baseline", "--no-fast-mode"]
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            so, se = proc.communicate(timeout=budget)
+        except subprocess.TimeoutExpired:
+            proc.kill()                                    # (this child's own pid)
+            proc.communicate()
+            raise RuntimeError("the child did not finish within %g s" % budget)
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or len(lines) != 1:
+            raise RuntimeError("child exit code %s: %s" % (proc.returncode, se[-400:]))
+        return json.loads(lines[0])
+
     from mdqe_cvpr2023_amd import sharding
     from mdqe_cvpr2023_amd.config import PRESETS
     fh, fw = FRAME_SIZES[config]
     T = PRESETS[config].n_frames_test
-    return {"world": W, "frames_per_rank": frames, "frames_virtual": frames * W, "steps": c["steps"], "warmup": c["warmup"],
-            "chunk_frames_per_round": sharding.round_sizes(frames, T, ratio=round_ratio(W)), "verified": c.get("verified"),
-            "ms_per_step": c["ms_per_step"], "frames_per_s_per_rank": c["value"], "frames_per_s_per_rank_median": c.get("value_median"),
-            "compute": pr["compute"], "replay_exposed_ms": pr["replay_exposed"], "replay_total_ms": pr.get("replay_busy"),
-            "gather_ms": round(pr["gather_wait"] + pr["gather_payload"], 2), "halo_frac": sb["halo_frac"],
-            "tracker_native_ms_per_step": sb.get("tracker_native_ms_per_step"), "tracked_instances": c["config"]["tracked_instances"],
-            "d2h_MB_per_step": round((c["config"]["tracked_instances"] or 0) * frames * W * fh * fw / 1e6, 1),
-            "what": "rank 0 of a %d-rank job on this one GPU, in a child process (`MDQE_BENCH_ROOT_LOAD=%d python bench.py`): it computes its own %d frames "
-                    "per step (the same chunks as in the real job) while its replay thread is fed every gathered round as rank 0 of that job would "
-                    "receive it (a %d-frame video whose foreign chunks repeat rank 0's clip results under their own frame indices): tracker replay, bank "
-                    "updates, window flushes, final_mask_kernel and the device->host copies of the masks carry the N = %d volume.  predicted_efficiency "
-                    "= this run's single-GPU step time / rank 0's step time there (rank 0 is the only rank that does more than compute + send, so its "
-                    "step is the job's); the wire and the other ranks' pace are not in it.  N = 1 / 2 / 4 / 8: profiles/r05_root_load_N.json"
-                    % (W, W, frames, frames * W, W),
-            "wall_s": round(time.perf_counter() - t_in, 1)}
-
+    rest = os.environ.get("MDQE_BENCH_ROOT_REST", "1") != "0"
+    sizes = sharding.round_sizes(frames, T, ratio=round_ratio(W))
+    if rest:
+        sizes = sharding.rest_root_sizes(sizes, W)
+    o = None
+    if any(isinstance(s_, list) for s_ in sizes):
+        # the other ranks first: rank 1's chunks, compute + pack + gather, no replay; its time up to the LAST gather is when that gather
+        # can complete on rank 0, which rests in that round and must not be let through earlier
+        o = child({"MDQE_BENCH_AS_RANK": "1"})
+        po = {k: v[0] for k, v in o["scaling_breakdown"]["per_rank_ms"].items()}
+        c = child({"MDQE_BENCH_REST_UNTIL_MS": "%.2f" % (po["compute"] + po["pack"])})
+    else:
+        c = child({})
+    sb = c["scaling_breakdown"]
+    pr = {k: v[0] for k, v in sb["per_rank_ms"].items()}
+    res = {"world": W, "frames_per_rank": frames, "frames_virtual": frames * W, "steps": c["steps"], "warmup": c["warmup"],
+           "chunk_frames_per_round": sizes, "verified": c.get("verified"),
+           "root_ms_per_step": c["ms_per_step"], "root_frames_per_step": sum(s_[0] if isinstance(s_, list) else s_ for s_ in sizes),
+           "compute": pr["compute"], "replay_exposed_ms": pr["replay_exposed"], "replay_total_ms": pr.get("replay_busy"),
+           "gather_ms": round(pr["gather_wait"] + pr["gather_payload"], 2), "halo_frac": sb["halo_frac"],
+           "tracker_native_ms_per_step": sb.get("tracker_native_ms_per_step"), "tracked_instances": c["config"]["tracked_instances"],
+           "d2h_MB_per_step": round((c["config"]["tracked_instances"] or 0) * frames * W * fh * fw / 1e6, 1)}
+    res["ms_per_step"] = c["ms_per_step"]
+    if o is not None:
+        res.update(other_rank_ms_per_step=o["ms_per_step"], other_rank_frames_per_step=sum(s_[1] if isinstance(s_, list) else s_ for s_ in sizes),
+                   other_rank_compute=po["compute"], last_gather_not_before_ms=round(po["compute"] + po["pack"], 2),
+                   ms_per_step=max(c["ms_per_step"], o["ms_per_step"]))
+    res["what"] = ("rank 0 of a %d-rank job on this one GPU, in a child process (`MDQE_BENCH_ROOT_LOAD=%d python bench.py`): it computes its own chunks of the "
+                   "job's plan while its replay thread is fed every gathered round as rank 0 of that job would receive it (a %d-frame video whose foreign "
+                   "chunks repeat rank 0's clip results under their own frame indices): tracker replay, bank updates, window flushes, final_mask_kernel and "
+                   "the device->host copies of the masks carry the N = %d volume.  Rank 0 rests in the last round (its frames go to the other ranks), so a "
+                   "child plays rank 1 first (`MDQE_BENCH_AS_RANK=1`: compute + gather, no replay) and rank 0's child is held at the last gather until rank 1 would "
+                   "have delivered (`MDQE_BENCH_REST_UNTIL_MS`); ms_per_step = the slower of the two = the job's step; "
+                   "predicted_efficiency = this run's single-GPU step time / that.  The wire and waiting for each other are not in it.  "
+                   "N = 1 / 2 / 4 / 8: profiles/r05_root_load_N.json" % (W, W, frames * W, W))
+    res["wall_s"] = round(time.perf_counter() - t_in, 1)
+    return res
 
 
 def main():
@@ -584,6 +608,8 @@ def main():
         print("bench.py: MDQE_BENCH_ROOT_LOAD is a one-rank rehearsal (WORLD_SIZE=%d)" % world, file=sys.stderr)
         sys.exit(2)
     sharded = world > 1 or os.environ.get("MDQE_BENCH_FORCE_SHARDED") == "1" or root_load > 0
+    root_rest = os.environ.get("MDQE_BENCH_ROOT_REST", "1") != "0"       # N >= 3: rank 0 takes no chunk in the last round (sharding.rest_root_sizes)
+    as_rank = int(os.environ.get("MDQE_BENCH_AS_RANK", "0")) if root_load > 0 else 0     # rehearsal: play THAT rank of the N-rank job (no replay)
     # HIP deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue is served in order.  The pipeline runs
     # seven streams (frame, clip, instance chain, decode-ahead, copy, tracker, + RCCL's when sharded): with 4 queues the tracker's per-clip
     # kernels of rank 0's replay sit behind the frame stream's GEMMs (N = 8 root-load rehearsal: 188.7 -> 177.4 ms per step with 8 queues,
@@ -675,12 +701,15 @@ def main():
     if sharded or vworld:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
         chunk = sharding.round_sizes(args.frames, T, ratio=round_ratio(pworld)) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
+        if isinstance(chunk, list) and root_rest and not args.halo_exchange:
+            chunk = sharding.rest_root_sizes(chunk, pworld)          # rank 0 rests in the last round (its frames go to the other ranks)
 
     def shard(halo, n_frames=None, chunk_=None, seed=0, vw=None):
         pw = vw or world
         n_frames = args.frames * pw if n_frames is None else n_frames
         pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk if chunk_ is None else chunk_, halo_exchange=halo, world=pw)
-        return pl, {g: synth_video(pl[g][1], pl[g][2], seed=seed, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(pl, pw, rank)}, vw
+        me = as_rank if vw else rank
+        return pl, {g: synth_video(pl[g][1], pl[g][2], seed=seed, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(pl, pw, me) if pl[g][0]}, vw
 
     if not sharded:
         video = synth_video(0, L, seed=0, h=fh, w=fw).pin_memory()
@@ -723,12 +752,13 @@ def main():
             for _ in range(k):
                 t0 = time.perf_counter()
                 o = sharding.run_round_robin(mdl, chunk_frames, plan, rank, world, dist, out_size=(fh, fw), root_only=True,
-                                             halo_exchange=halo, like=like, stats=stats, vworld=vw)
+                                             halo_exchange=halo, like=like, stats=stats, vworld=vw, as_rank=as_rank if vw else 0)
                 if step_ms is not None:
                     step_ms.append(1e3 * (time.perf_counter() - t0))
         else:
             for o in sharding.run_round_robin_stream(mdl, ((chunk_frames, plan, like) for _ in range(k)), rank, world, dist,
-                                                     out_size=(fh, fw), root_only=True, halo_exchange=halo, stats=stats, vworld=vw):
+                                                     out_size=(fh, fw), root_only=True, halo_exchange=halo, stats=stats, vworld=vw,
+                                                     as_rank=as_rank if vw else 0):
                 pass
         return o
 
@@ -1018,9 +1048,10 @@ def main():
                                    "calibrated so that several instances per clip survive (BASELINE.md §3, DESIGN.md §5)"
                                    % (args.config, args.frames, fh, fw, cfg.n_frames_test, cfg.n_frames_window_test),
                        "frames_per_gpu": args.frames, "clips_per_step": len(range(0, L, cfg.clip_stride)) - (T - 2),
-                       "instances_out": len(out["pred_scores"]),
+                       "instances_out": len(out["pred_scores"]) if out is not None else None,
                        "tracked_instances": getattr(model, "last_num_tracks", None),       # tracks the tracker held at the end of the video
-                       "output": "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
+                       "output": "none (a non-root rank of the rehearsal)" if out is None else
+                                 "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
                        "merge_on_cpu": bool(cfg.merge_on_cpu), "early_masks": bool(model.early_masks),
                        "cls_bias_shift": round(bias_shift, 3), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
@@ -1028,12 +1059,14 @@ def main():
                        "ranks_seen": ranks_seen, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
                        "parallelism": ("%d ranks counted by all-reduce; 1 process/GPU;" % ranks_seen + " %s-frame chunks dealt round-robin (pinned host, uploaded per chunk), %s, per-round RCCL gather of the "
                                        "clip results to rank 0, whose native tracker replay runs on a worker thread under the next round"
-                                       % ("/".join(str(c) for c in chunk) + " (one size per round)" if isinstance(chunk, list) else str(chunk),
+                                       % (" / ".join(("[" + ",".join(str(v) for v in c) + "]") if isinstance(c, (list, tuple)) else str(c) for c in chunk)
+                                          + " (one size per round; [..] = per rank, rank 0 rests)" if isinstance(chunk, list) else str(chunk),
                                           "halo exchange (T-1 frames of encoder tokens + mask features by send/recv)" if args.halo_exchange
                                           else "a chunk's T-1 frame halo is computed by its owner again")) if sharded else "single GPU"},
         }
         if vworld:
             line["config"]["root_load_world"] = vworld
+            line["config"]["as_rank"] = as_rank
             line["config"]["workload"] += ("; ROOT-LOAD REHEARSAL (MDQE_BENCH_ROOT_LOAD=%d): this rank computes rank 0's %d frames of a %d-rank job and "
                                            "replays the clips of all %d ranks (sharding.expand_root_load); `value` counts this rank's own frames only"
                                            % (vworld, args.frames, vworld, vworld))

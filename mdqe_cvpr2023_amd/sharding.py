@@ -26,6 +26,7 @@ SHARD_SIDE_STREAMS = os.environ.get("MDQE_SHARD_SIDE_STREAMS", "0") == "1"
 # split_small) -- the previous round's clip work, and with it that round's gather and the start of its replay on rank 0, trails the pass
 # queued behind it.  Measured in the N = 8 / N = 4 root-load rehearsal: 179.2 against 177.3 ms, 169.6 against 166.5 ms per step -- no gain, so
 # off by default (profiles/r05_ab_split_pass.txt)
+REST_UNTIL_MS = float(os.environ.get("MDQE_BENCH_REST_UNTIL_MS", "0"))     # bench.py's root-load rehearsal (run_round_robin_stream)
 HALO_LOCAL = os.environ.get("MDQE_HALO_LOCAL", "0") == "1"
 SHARD_SPLIT_PASS = os.environ.get("MDQE_SHARD_SPLIT_PASS", "0") == "1"
 
@@ -222,7 +223,7 @@ class ReplayThread:
         self.t.join()
 
 
-def expand_root_load(merged, q, plan, vworld, T):
+def expand_root_load(merged, q, plan, vworld, T, template=None):
     """The N = `vworld` ROOT LOAD on one GPU (bench.py MDQE_BENCH_ROOT_LOAD): `merged` holds the clip results of chunk q*vworld -- rank
     0's own chunk of round q in the plan of a `vworld`-rank job -- and the return value is the round as rank 0 of that job would have
     gathered it: the clips of chunks q*vworld .. q*vworld+vworld-1 in global clip order, where a foreign chunk repeats rank 0's own
@@ -235,10 +236,17 @@ def expand_root_load(merged, q, plan, vworld, T):
     own_clips = plan[g0][0]
     if [c[0] for c in own_clips] != sorted(own):
         raise RuntimeError("expand_root_load: the gathered round is not rank 0's chunk %d of the plan" % g0)
+    if not own_clips:
+        # rank 0 rests in this round (rest_root_sizes): the foreign chunks repeat the results of its LAST own round (`template`)
+        if not template:
+            raise RuntimeError("expand_root_load: rank 0 has no chunk in round %d and no earlier round to repeat" % q)
+        srcs = [r for _, _, _, r in template]
+    else:
+        srcs = [own[c[0]][3] for c in own_clips]
     out = []
     for g in range(g0, min(g0 + vworld, len(plan))):
         for k, (s, e, l) in enumerate(plan[g][0]):
-            src = own[own_clips[min(k, len(own_clips) - 1)][0]][3]
+            src = srcs[min(k, len(srcs) - 1)]
             if g == g0:
                 out.append((s, e, l, src))
                 continue
@@ -279,12 +287,20 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
     a whole clip of its own)."""
     from .meta_arch import MDQE
     clips = MDQE.clip_schedule(L, T, stride)
-    sizes = [int(chunk)] if isinstance(chunk, int) else [int(c) for c in chunk]
-    if min(sizes) < 1:
+    sizes = [chunk] if isinstance(chunk, int) else list(chunk)
+    per_rank = any(isinstance(c, (list, tuple)) for c in sizes)       # a round as a list of per-RANK sizes (rest_root_sizes): zeros allowed
+    w = max(world, 1)
+    if per_rank and (halo_exchange or any(isinstance(c, (list, tuple)) and len(c) != w for c in sizes)):
+        raise ValueError("chunk_plan: per-rank chunk sizes need one entry per rank and the recompute form")
+
+    def size_of(g):
+        c = sizes[min(g // w, len(sizes) - 1)]
+        return int(c[g % w]) if isinstance(c, (list, tuple)) else int(c)
+    if any((min(c) < 0 or max(c) < 1) if isinstance(c, (list, tuple)) else int(c) < 1 for c in sizes):
         raise ValueError("chunk_plan: chunk sizes must be positive")
     edges, g = [0], 0
     while edges[-1] < L:
-        edges.append(min(L, edges[-1] + sizes[min(g // max(world, 1), len(sizes) - 1)]))
+        edges.append(min(L, edges[-1] + size_of(g)))
         g += 1
     if halo_exchange:
         if len(edges) > 2 and edges[-1] - edges[-2] < T:
@@ -295,7 +311,24 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
         cl = [c for c in clips if a <= c[0] < b]
         if cl:
             plan.append((cl, cl[0][0], max(c[1] for c in cl)))
+        elif per_rank:
+            plan.append(([], a, a))                # an EMPTY chunk keeps its slot: chunk g still belongs to rank g % world
     return plan
+
+
+def rest_root_sizes(sizes, world):
+    """Per-round chunk sizes with rank 0 RESTING in the last round: that round's frames go to ranks 1 .. world-1 (its entry becomes a
+    per-rank list [0, a, a, .., b]).  Rank 0 is the only rank with work after the last gather -- the replay of the last round, the last
+    window flushes, the video merge -- and in the rounds before it replays beside its own compute; with no chunk of its own in the last
+    round it has caught up with the replay when the last gather arrives and runs the last round's updates on an idle GPU.  The other
+    ranks take 1 / (world - 1) more frames of that round each."""
+    sizes = list(sizes)
+    if world < 3 or len(sizes) < 2 or isinstance(sizes[-1], (list, tuple)):
+        return sizes
+    total = int(sizes[-1]) * world
+    base, extra = divmod(total, world - 1)
+    sizes[-1] = [0] + [base + (1 if r < extra else 0) for r in range(world - 1)]
+    return sizes
 
 
 def owned_chunks(plan, world, rank):
@@ -305,7 +338,7 @@ def owned_chunks(plan, world, rank):
 
 
 def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, like=None,
-                    stats=None, vworld=None):
+                    stats=None, vworld=None, as_rank=0):
     """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
     Default: every rank all-gathers each round and replays the tracker (all ranks return the video result;
     emit_masks=False skips the mask production on ranks that only keep the tracker in step).
@@ -313,7 +346,8 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
     its main thread goes on with the next round; the other ranks only compute and send, and return None.
     `like`: any [.., h, w] tensor on the frames' device -- needed by a rank that owns NO chunk of this video (more ranks than chunks)."""
     return next(run_round_robin_stream(model, [(chunk_frames, plan, like) if like is not None else (chunk_frames, plan)], rank, world, dist, out_size,
-                                       emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange, stats=stats, vworld=vworld))
+                                       emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange, stats=stats, vworld=vworld,
+                                       as_rank=as_rank))
 
 
 _HALO_GROUPS = {}
@@ -441,13 +475,15 @@ class _Job:
             if root_only:
                 self.replay = ReplayThread(self.merger, self.device)
         self.rounds = (len(plan) + world - 1) // world
+        self.t0 = time.perf_counter()              # start of this video on this rank
+        self.own_last = None                       # root-load rehearsal: rank 0's clip results of its last non-empty round
         self.tm = {"compute": 0.0, "pack": 0.0, "gather_wait": 0.0, "gather_payload": 0.0, "feed": 0.0, "replay_exposed": 0.0, "replay_busy": 0.0}
         self.replay_busy = 0.0
 
     def start(self, q):
         """Queue the per-frame work of this rank's chunk of round q (async); the returned generator yields its clip results."""
         g = q * self.world + self.rank
-        if q >= self.rounds or g >= len(self.plan):
+        if q >= self.rounds or g >= len(self.plan) or not self.plan[g][0]:      # (an empty chunk: this rank rests in round q)
             return None
         fr, h2d = self.chunk_frames[g], None
         if not fr.is_cuda and self.device.type == "cuda":          # a1's host->device copy of this chunk, chunked on the copy stream
@@ -514,7 +550,7 @@ def halo_recompute_frac(plan, L):
 
 
 def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, stats=None,
-                           vworld=None):
+                           vworld=None, as_rank=0):
     """Videos as a stream through the round-robin schedule.  jobs: iterable of (chunk_frames, plan[, like]) as for
     run_round_robin (`like`: any [.., h, w] tensor on the device, for a rank that owns no chunk of a short video); yields each video's result in order (None on the ranks that do not replay).  Within a video the next round's per-frame
     work is queued before this round's clip work; ACROSS videos the first round of video k+1 is queued before the last round's
@@ -531,12 +567,15 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     if vworld is not None and (world != 1 or rank != 0 or halo_exchange):
         raise ValueError("the root-load rehearsal runs on ONE rank, without the halo exchange")
     pworld = vworld if vworld is not None else world   # the world the chunks are dealt to
+    # as_rank (rehearsal only): play rank `as_rank` of the vworld-rank job instead of rank 0 -- its chunks, no replay (a non-root rank of
+    # the root-only schedule computes and sends): what the OTHER ranks' step costs when rank 0 rests in the last round
+    prank = as_rank if vworld is not None else rank
     it = iter(jobs)
     ws = getattr(model, "work_stream", contextlib.nullcontext)      # the model's high-priority stream (no context is held across a yield)
 
     def open_next():
         j = next(it, None)
-        return None if j is None else _Job(model, j[0], j[1], rank, pworld, out_size, emit_masks, root_only,
+        return None if j is None else _Job(model, j[0], j[1], prank, pworld, out_size, emit_masks, root_only,
                                            like=j[2] if len(j) > 2 else None, dist=dist, halo_exchange=halo_exchange)
 
     def finish(j):
@@ -566,10 +605,17 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
                         nxt_gen = nxt_job.start(0) if nxt_job is not None else None
                     local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
                     t_c = time.perf_counter()
+                    if vworld is not None and prank == 0 and REST_UNTIL_MS > 0 and not job.plan[q * vworld][0]:
+                        # rehearsal of a resting root: the round's gather completes when the OTHER ranks deliver -- not before
+                        # REST_UNTIL_MS after the start of the video (their measured compute + pack); the replay thread works on meanwhile
+                        while (time.perf_counter() - job.t0) * 1e3 < REST_UNTIL_MS:
+                            time.sleep(2e-4)
                     tg = {}
                     merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank, timing=tg)
-                    if vworld is not None:
-                        merged = expand_root_load(merged, q, job.plan, vworld, job.T)
+                    if vworld is not None and prank == 0:
+                        merged = expand_root_load(merged, q, job.plan, vworld, job.T, template=job.own_last)
+                        if job.plan[q * vworld][0]:
+                            job.own_last = merged[:len(job.plan[q * vworld][0])]
                     t_g = time.perf_counter()
                     job.feed(merged)
                     tm = job.tm

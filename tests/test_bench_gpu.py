@@ -67,8 +67,12 @@ def test_bench_side_configs_and_root_load_ride_in_the_same_line():
         assert e["instances_out"] >= 1
     rl = d["root_load"]
     assert "error" not in rl, rl
-    assert rl["world"] == 8 and rl["frames_virtual"] == 8 * 36 and rl["ms_per_step"] > 0 and 0.0 < rl["predicted_efficiency"] <= 1.05
+    assert rl["world"] == 8 and rl["frames_virtual"] == 8 * 36 and rl["ms_per_step"] > 0 and 0.0 < rl["predicted_efficiency"] <= 1.1
     assert rl["verified"] is True and rl["replay_total_ms"] > 0 and rl["compute"] > 0 and rl["tracked_instances"] >= 1
+    # rank 0 rests in the last round: the job's step is the slower of rank 0's and another rank's (a second child plays rank 1)
+    assert isinstance(rl["chunk_frames_per_round"][-1], list) and rl["chunk_frames_per_round"][-1][0] == 0
+    assert rl["ms_per_step"] == max(rl["root_ms_per_step"], rl["other_rank_ms_per_step"]) and rl["other_rank_frames_per_step"] > rl["root_frames_per_step"]
+    assert rl["root_ms_per_step"] >= rl["last_gather_not_before_ms"]               # rank 0 was held at the last gather until rank 1 would have delivered
     assert abs(rl["predicted_efficiency"] - rl["single_gpu_ms_per_step"] / rl["ms_per_step"]) < 1e-9
     assert rl["tracker_native_ms_per_step"]["updates_per_step"] >= 8 * 30       # the replay really carried eight ranks' clips
 

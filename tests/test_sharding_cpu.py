@@ -466,3 +466,88 @@ def test_root_load_expansion_is_the_round_rank_0_of_an_n_rank_job_would_gather()
     import pytest
     with pytest.raises(RuntimeError):
         sharding.expand_root_load([(1, 4, False, fake_result(1, 4))], 0, plan, W, T)
+
+
+def test_resting_root_plan_keeps_every_clip_once_and_rank_0_free_in_the_last_round():
+    """sharding.rest_root_sizes: the last round's frames go to ranks 1 .. N-1; rank 0's chunk of that round is an EMPTY placeholder (chunk g
+    still belongs to rank g % world), every clip is owned exactly once and in order, two ranks / one round are left alone."""
+    T = 4
+    for per, W in ((120, 8), (120, 4), (60, 3)):
+        base = sharding.round_sizes(per, T, ratio=0.6)
+        sizes = sharding.rest_root_sizes(base, W)
+        assert isinstance(sizes[-1], list) and sizes[-1][0] == 0 and sum(sizes[-1]) == base[-1] * W and max(sizes[-1]) - min(sizes[-1][1:]) <= 1
+        Lv = per * W
+        plan = sharding.chunk_plan(Lv, T, 1, sizes, world=W)
+        assert [c for ch in plan for c in ch[0]] == clip_schedule(Lv, T, 1)
+        rounds = -(-len(plan) // W)
+        assert rounds == len(sizes)
+        g_rest = (rounds - 1) * W
+        assert plan[g_rest][0] == [] and all(plan[g][0] for g in range(len(plan)) if g != g_rest)
+        assert sharding.owned_chunks(plan, W, 0)[-1] == g_rest
+        for g, (cl, f0, f1) in enumerate(plan):
+            assert all(f0 <= c[0] and c[1] <= f1 for c in cl)
+    assert sharding.rest_root_sizes([69, 34, 17], 2) == [69, 34, 17] and sharding.rest_root_sizes([120], 8) == [120]
+    import pytest
+    with pytest.raises(ValueError):
+        sharding.chunk_plan(100, T, 1, [10, [0, 5]], halo_exchange=True, world=2)
+
+
+def test_root_load_expansion_with_a_resting_root_repeats_its_last_own_round():
+    T, W, per = CFG.n_frames_test, 4, 24
+    sizes = sharding.rest_root_sizes(sharding.round_sizes(per, T, ratio=0.5, smallest=3), W)
+    assert isinstance(sizes[-1], list)
+    Lv = per * W
+    plan = sharding.chunk_plan(Lv, T, 1, sizes, world=W)
+    rounds = -(-len(plan) // W)
+    seen, template = [], None
+    for q in range(rounds):
+        own = [(s, e, l, fake_result(s, e)) for s, e, l in plan[q * W][0]]
+        out = sharding.expand_root_load(own, q, plan, W, T, template=template)
+        if own:
+            template = out[:len(own)]
+        assert [(s, e, l) for s, e, l, _ in out] == [c for g in range(q * W, min(q * W + W, len(plan))) for c in plan[g][0]]
+        seen += out
+    assert plan[(rounds - 1) * W][0] == [] and [(s, e, l) for s, e, l, _ in seen] == clip_schedule(Lv, T, 1)
+    assert sum(m.shape[1] for _, m in replay(seen)) == Lv
+
+
+def rest_stream_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    import mdqe_cvpr2023_amd.meta_arch as MA
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    MA.ClipMerger = _FakeMerger
+    model = _FakeModel([])
+    Lv = 72
+    sizes = sharding.rest_root_sizes([10, 5, 3], world)
+    plan = sharding.chunk_plan(Lv, CFG.n_frames_test, 1, sizes, world=world)
+    frames = {g: torch.zeros(plan[g][2] - plan[g][1], 3, HW[0] * 4, HW[1] * 4) for g in sharding.owned_chunks(plan, world, rank) if plan[g][0]}
+    out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (HW[0] * 4, HW[1] * 4), root_only=True,
+                                   like=torch.zeros(0, 3, HW[0] * 4, HW[1] * 4))
+    torch.save((out, plan), os.path.join(outdir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_round_robin_with_a_resting_root_four_ranks(tmp_path):
+    """Four gloo ranks, rank 0 without a chunk in the last round: it still takes part in that round's gather (zero clips), sees every clip
+    once in global order and replays to the single-process tracker result."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=rest_stream_worker, args=(r, 4, port, str(tmp_path))) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(4)]
+    out0, plan = got[0]
+    assert all(g[0] is None for g in got[1:])
+    assert plan[8][0] == [] and len(plan) == 12
+    clip_order, tracks = out0
+    clips = clip_schedule(72, CFG.n_frames_test, 1)
+    assert clip_order == clips
+    ref = replay([(s, e, l, fake_result(s, e)) for s, e, l in clips])
+    assert len(tracks) == len(ref)
+    for (c, m), (cr, mr) in zip(tracks, ref):
+        assert torch.allclose(c, cr) and torch.equal(m, mr)

@@ -7,7 +7,20 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for w in "${@:-1 2 4 8}"; do
   for ww in $w; do
-    MDQE_BENCH_ROOT_LOAD=$ww python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-fast-mode > gpurun_out/root_load_$ww.json 2> gpurun_out/root_load_$ww.err
+    until=0
+    if [ "$ww" -ge 3 ]; then      # rank 0 rests in the last round: the OTHER ranks first (rank 1's chunks, compute + gather, no replay) ...
+      MDQE_BENCH_ROOT_LOAD=$ww MDQE_BENCH_AS_RANK=1 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-fast-mode > gpurun_out/root_load_${ww}_rank1.json 2> gpurun_out/root_load_${ww}_rank1.err
+      until=$(python - "$ww" <<'P'
+import json, sys
+d = json.load(open("gpurun_out/root_load_%s_rank1.json" % sys.argv[1]))
+p = d["scaling_breakdown"]["per_rank_ms"]
+sys.stderr.write("root load %s, as rank 1: %.1f ms/step; compute %.1f\n" % (sys.argv[1], d["ms_per_step"], p["compute"][0]))
+print("%.2f" % (p["compute"][0] + p["pack"][0]))
+P
+)
+    fi
+    # ... then rank 0, held at the last gather until rank 1 would have delivered
+    MDQE_BENCH_REST_UNTIL_MS=$until MDQE_BENCH_ROOT_LOAD=$ww python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-fast-mode > gpurun_out/root_load_$ww.json 2> gpurun_out/root_load_$ww.err
     python - "$ww" <<'P'
 import json, sys
 w = sys.argv[1]
