@@ -701,13 +701,16 @@ def main():
     if sharded or vworld:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
         chunk = sharding.round_sizes(args.frames, T, ratio=round_ratio(pworld)) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
+        chunk_plain = chunk                                          # (the halo-exchange form partitions frames: uniform chunks per round)
         if isinstance(chunk, list) and root_rest and not args.halo_exchange:
             chunk = sharding.rest_root_sizes(chunk, pworld)          # rank 0 rests in the last round (its frames go to the other ranks)
 
     def shard(halo, n_frames=None, chunk_=None, seed=0, vw=None):
         pw = vw or world
         n_frames = args.frames * pw if n_frames is None else n_frames
-        pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk if chunk_ is None else chunk_, halo_exchange=halo, world=pw)
+        if chunk_ is None:
+            chunk_ = chunk_plain if halo else chunk
+        pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk_, halo_exchange=halo, world=pw)
         me = as_rank if vw else rank
         return pl, {g: synth_video(pl[g][1], pl[g][2], seed=seed, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(pl, pw, me) if pl[g][0]}, vw
 
@@ -1135,15 +1138,18 @@ def main():
             give_up("halo_exchange", budget)()
         sync()
         with Deadline(budget, halo_gave_up, emitted):
-            shards[True] = shard(True)
-            ok, vinfo = verify_sharded(True)
-            res = {"verified": bool(ok)}
-            if ok:
-                st_h = []
-                d, _ = timed(args.precision, False, key=True, stats=st_h)
-                res.update(rate(d), per_rank_ms=rank_stats(st_h), halo_frac=round(sharding.halo_recompute_frac(shards[True][0], L), 4),
-                           what="the same steps with the halo exchange: chunks partition the frames, a chunk's first T-1 clips read the left "
-                                "neighbour's last T-1 frames from shipped encoder tokens + mask features (one grouped send/recv per rank and round)")
+            try:
+                shards[True] = shard(True)
+                ok, vinfo = verify_sharded(True)
+                res = {"verified": bool(ok)}
+                if ok:
+                    st_h = []
+                    d, _ = timed(args.precision, False, key=True, stats=st_h)
+                    res.update(rate(d), per_rank_ms=rank_stats(st_h), halo_frac=round(sharding.halo_recompute_frac(shards[True][0], L), 4),
+                               what="the same steps with the halo exchange: chunks partition the frames, a chunk's first T-1 clips read the left "
+                                    "neighbour's last T-1 frames from shipped encoder tokens + mask features (one grouped send/recv per rank and round)")
+            except Exception as e:                                   # an extra must never take the headline down (every rank fails alike here,
+                res = {"error": "%s: %s" % (type(e).__name__, e)}    #  or the others run into the soft deadline)
         if rank == 0:
             line["halo_exchange"] = res
     if rank == 0:
