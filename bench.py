@@ -368,9 +368,9 @@ def spawn_ranks(n):
 
 
 def round_ratio(world):
-    """Chunk-size ratio of consecutive rounds (sharding.round_sizes): rank 0 replays round q -- world x the clips of a chunk, ~0.1 ms each in
-    the pipeline -- under the compute of round q+1 -- ~1.25 ms per frame -- so a round may shrink to 0.08 x world of the one before and
-    still hide its replay; the fewer ranks, the steeper the decrease (and the fewer rounds).  MDQE_BENCH_ROUND_RATIO overrides."""
+    """Chunk-size ratio of consecutive rounds (sharding.round_sizes): rank 0 replays round q -- world x the clips of a chunk, ~0.06 ms each in
+    the pipeline -- under the compute of round q+1 -- ~1.25 ms per frame -- so a round may shrink to 0.06 x world of the one before and
+    still hide its replay, but never below 0.5 (three rounds).  MDQE_BENCH_ROUND_RATIO overrides."""
     v = os.environ.get("MDQE_BENCH_ROUND_RATIO")
     if v:
         return float(v)
@@ -378,7 +378,9 @@ def round_ratio(world):
     # must not run dry), so round q's gather trails its frames by about one pass and a TWO-round plan hides next to nothing of round 0's
     # replay (N = 4 rehearsal: 91 / 29 frames, 30 of 37 ms of replay exposed -- worse than N = 8 on three rounds)
     # (one and two ranks as well: the one-rank rehearsal runs 157.6 ms on 69 / 34 / 17 against 161.9 on 92 / 28)
-    return min(0.7, max(0.5, 0.08 * world))
+    # (with rank 0 resting in the last round the N = 8 rehearsal runs 161.3 ms on ratio 0.5, 164.7 on 0.64, 167.4 on 0.4:
+    # profiles/r05_ab_round_ratio_resting_root.txt)
+    return min(0.7, max(0.5, 0.06 * world))
 
 
 class EmitOnce:

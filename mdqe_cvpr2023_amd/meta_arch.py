@@ -196,6 +196,25 @@ class MDQE(nn.Module):
                 with torch.cuda.stream(st):
                     torch.zeros(1, device=self.device)
 
+    def touch_streams(self):
+        """Give the pipeline's normal-priority streams their hardware queues NOW, in a fixed order (copy, frame, tracker): a stream gets its
+        queue when it is first used, and whatever creates streams of its own in between -- a second RCCL communicator (the halo exchange's),
+        a host application -- shifts the deal.  The sharded schedule calls this before it creates anything else (one-rank halo-exchange
+        rehearsal under 8 queues: 180.9 ms per step without, 153.5 with; profiles/r05_ab_halo_exchange_queues.txt).  Once per process."""
+        if self.device.type != "cuda":
+            return
+        key = ("touched", self.device.index if self.device.index is not None else torch.cuda.current_device())
+        if _STREAMS.get(key):
+            return
+        with self._on_device():
+            with self.work_stream():                   # (creates the streams if this is the first use of the model)
+                pass
+            for st in (self._copy_stream, self._frame_stream, self._trk_stream):
+                if st is not None:
+                    with torch.cuda.stream(st):
+                        torch.zeros(1, device=self.device)
+        _STREAMS[key] = True
+
     @contextlib.contextmanager
     def work_stream(self):
         """The model's own HIGH-PRIORITY stream for the per-clip stages (decoder, inference_clip: hundreds of small kernels

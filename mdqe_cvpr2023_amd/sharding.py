@@ -571,6 +571,9 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     # the root-only schedule computes and sends): what the OTHER ranks' step costs when rank 0 rests in the last round
     prank = as_rank if vworld is not None else rank
     it = iter(jobs)
+    touch = getattr(model, "touch_streams", None)
+    if touch is not None:
+        touch()                                        # the model's streams take their hardware queues before a job creates a communicator
     ws = getattr(model, "work_stream", contextlib.nullcontext)      # the model's high-priority stream (no context is held across a yield)
 
     def open_next():
