@@ -191,7 +191,7 @@ class MDQE(nn.Module):
                     self._pad_streams.append(st)
                 with torch.cuda.stream(st):
                     torch.zeros(1, device=self.device)
-        elif os.environ.get("MDQE_STREAM_TOUCH", "0") == "1":
+        elif os.environ.get("MDQE_STREAM_TOUCH", "0") == "1" or getattr(self, "_touch_on_create", False):
             for st in self._pad_streams + [self._copy_stream, self._frame_stream, self._trk_stream]:
                 with torch.cuda.stream(st):
                     torch.zeros(1, device=self.device)
@@ -206,14 +206,17 @@ class MDQE(nn.Module):
         key = ("touched", self.device.index if self.device.index is not None else torch.cuda.current_device())
         if _STREAMS.get(key):
             return
-        with self._on_device():
-            with self.work_stream():                   # (creates the streams if this is the first use of the model)
-                pass
-            for st in (self._copy_stream, self._frame_stream, self._trk_stream):
-                if st is not None:
-                    with torch.cuda.stream(st):
-                        torch.zeros(1, device=self.device)
         _STREAMS[key] = True
+        if self._work_stream is not None:
+            return                                     # the streams are in use already: their queues are taken
+        # the same order as MDQE_STREAM_TOUCH=1: copy, frame, tracker are touched inside `_make_streams`, right when the streams are
+        # created and BEFORE the work stream's own first use (touching them behind it measured no better than not touching at all)
+        self._touch_on_create = True
+        try:
+            with self._on_device(), self.work_stream():
+                pass
+        finally:
+            self._touch_on_create = False
 
     @contextlib.contextmanager
     def work_stream(self):
