@@ -361,7 +361,9 @@ def spawn_ranks(n):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    # few host threads per rank: the ranks' torch CPU pools spin-wait, and n x (cores / n) of them beside the ranks' launch, replay and HIP
+    # threads oversubscribe the host (two ranks x 8 threads on a 16-CPU box: the same run took 45 .. 150 s of wall time)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(4, (os.cpu_count() or n) // n))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode

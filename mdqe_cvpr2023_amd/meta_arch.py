@@ -201,7 +201,7 @@ class MDQE(nn.Module):
         queue when it is first used, and whatever creates streams of its own in between -- a second RCCL communicator (the halo exchange's),
         a host application -- shifts the deal.  The sharded schedule calls this before it creates anything else (one-rank halo-exchange
         rehearsal under 8 queues: 180.9 ms per step without, 153.5 with; profiles/r05_ab_halo_exchange_queues.txt).  Once per process."""
-        if self.device.type != "cuda":
+        if self.device.type != "cuda" or os.environ.get("MDQE_NO_STREAM_TOUCH") == "1":
             return
         key = ("touched", self.device.index if self.device.index is not None else torch.cuda.current_device())
         if _STREAMS.get(key):
