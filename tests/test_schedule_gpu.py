@@ -112,6 +112,22 @@ def test_pinned_mask_buffers_are_pooled_but_never_shared():
     _same(r1, r3)
 
 
+def test_streams_are_shared_by_models_and_touched_once():
+    """One set of pipeline streams per device and process: a second model instance runs on the SAME stream objects (a second set would take
+    another deal of hardware queues), `touch_streams()` is idempotent, and none of it changes a bit."""
+    cfg, m1 = _small_model()
+    _, m2 = _small_model()
+    frames = _video(10).cuda()
+    inp = [{"image": frames, "height": 96, "width": 160}]
+    a = m1(inp)
+    m2.touch_streams(); m2.touch_streams()
+    b = m2(inp)
+    _same(a, b)
+    for name in ("_frame_stream", "_copy_stream", "_trk_stream", "_work_stream"):
+        s1, s2 = getattr(m1, name), getattr(m2, name)
+        assert s1 is not None and s1 is s2, name
+
+
 def test_early_masks_equal_the_direct_path():
     """ClipMerger with n_frames (masks produced per window into pinned memory) vs without (one pass at the end)."""
     cfg, model = _small_model()
