@@ -465,7 +465,7 @@ def fail_hook(where, rank):
         time.sleep(3600)
 
 
-def root_load_child(W, budget, frames, config):
+def root_load_child(W, budget, frames, config, halo=False):
     """The N = W root load (sharding.expand_root_load: rank 0's own chunks of a W-rank job + the replay / final masks / mask read-back of
     all W ranks' clips) measured in CHILD processes -- `MDQE_BENCH_ROOT_LOAD=W python bench.py`, a fresh HIP runtime whose streams are
     created in the sharded job's own order, alone on the GPU: the parent starts them before it touches the GPU itself (see main).  With
@@ -483,6 +483,8 @@ def root_load_child(W, budget, frames, config):
             s_.bind(("127.0.0.1", 0))
             env["MASTER_PORT"] = str(s_.getsockname()[1])
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--frames", str(frames), "--no-cpu-baseline", "--no-fast-mode"]
+        if halo:
+            cmd.append("--halo-exchange")
         proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         try:
             so, se = proc.communicate(timeout=budget)
@@ -502,7 +504,7 @@ def root_load_child(W, budget, frames, config):
     rest = os.environ.get("MDQE_BENCH_ROOT_REST", "1") != "0"
     sizes = sharding.round_sizes(frames, T, ratio=round_ratio(W))
     if rest:
-        sizes = sharding.rest_root_sizes(sizes, W)
+        sizes = sharding.rest_root_sizes(sizes, W, halo_exchange=halo)
     o = None
     if any(isinstance(s_, list) for s_ in sizes):
         # the other ranks first: rank 1's chunks, compute + pack + gather, no replay; its time up to the LAST gather is when that gather
@@ -626,12 +628,18 @@ def main():
     # touched the GPU runtime yet); its summary joins the line at the end
     rl = os.environ.get("MDQE_BENCH_ROOT_LOAD_LEG", "")             # "W": that world, "0": never, unset: 8 with the other extras
     rl_w = int(rl) if rl else (8 if not args.no_fast_mode else 0)
-    root_load_res = None
+    root_load_res = root_load_halo = None
     if not sharded and not probe and rank == 0 and rl_w > 1 and args.config == "R50_ovis_360" and args.precision == "f32":
         try:
             root_load_res = root_load_child(rl_w, float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "150")), args.frames, args.config)
         except Exception as e:                                      # an extra must not take the headline down
             root_load_res = {"error": "%s: %s" % (type(e).__name__, e)}
+        if os.environ.get("MDQE_BENCH_ROOT_LOAD_HALO", "1") != "0":
+            # ... and of the halo-exchange form of the same job (chunks partition the frames, rank 0 takes 0.93 of a round's chunk size)
+            try:
+                root_load_halo = root_load_child(rl_w, float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "150")), args.frames, args.config, halo=True)
+            except Exception as e:
+                root_load_halo = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if not probe:
         if not one_dev and world > 1 and torch.cuda.device_count() < world:
@@ -705,16 +713,23 @@ def main():
     if sharded or vworld:
         # chunks of tracker windows dealt round-robin: rank r holds the frames (+T-1 halo) of chunks r, r+N, ... (pinned host)
         chunk = sharding.round_sizes(args.frames, T, ratio=round_ratio(pworld)) if args.chunk_rounds == "decreasing" else cfg.n_frames_window_test * args.chunk_windows
-        chunk_plain = chunk                                          # (the halo-exchange form partitions frames: uniform chunks per round)
-        if isinstance(chunk, list) and root_rest and not args.halo_exchange:
-            chunk = sharding.rest_root_sizes(chunk, pworld)          # rank 0 rests in the last round (its frames go to the other ranks)
+        chunk_plain = chunk
+        chunk_by_form = {False: chunk, True: chunk}
+        if isinstance(chunk, list) and root_rest:
+            # rank 0 rests in the last round (its frames go to the other ranks) and, with the halo exchange, takes a smaller chunk before
+            chunk_by_form = {h_: sharding.rest_root_sizes(chunk_plain, pworld, halo_exchange=h_) for h_ in (False, True)}
+            chunk = chunk_by_form[bool(args.halo_exchange)]
 
     def shard(halo, n_frames=None, chunk_=None, seed=0, vw=None):
         pw = vw or world
         n_frames = args.frames * pw if n_frames is None else n_frames
-        if chunk_ is None:
-            chunk_ = chunk_plain if halo else chunk
-        pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk_, halo_exchange=halo, world=pw)
+        try:
+            pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk_by_form[bool(halo)] if chunk_ is None else chunk_, halo_exchange=halo, world=pw)
+        except ValueError:
+            if chunk_ is not None or not halo:
+                raise
+            # (a resting root whose plan leaves a chunk of the halo-exchange form without a whole clip: uniform chunks per round)
+            pl = sharding.chunk_plan(n_frames, T, cfg.clip_stride, chunk_plain, halo_exchange=True, world=pw)
         me = as_rank if vw else rank
         return pl, {g: synth_video(pl[g][1], pl[g][2], seed=seed, h=fh, w=fw).pin_memory() for g in sharding.owned_chunks(pl, pw, me) if pl[g][0]}, vw
 
@@ -1121,10 +1136,17 @@ def main():
         ops.set_gemm_precision("f32")
 
     if root_load_res is not None and rank == 0:
+        single_ms = 1e3 * dt / args.steps
         if "ms_per_step" in root_load_res:
-            single_ms = 1e3 * dt / args.steps
             root_load_res.update(single_gpu_ms_per_step=single_ms, predicted_efficiency=single_ms / root_load_res["ms_per_step"])
         line["root_load"] = root_load_res
+        if root_load_halo is not None:
+            if "ms_per_step" in root_load_halo:
+                root_load_halo.update(single_gpu_ms_per_step=single_ms, predicted_efficiency=single_ms / root_load_halo["ms_per_step"])
+                root_load_halo["what"] = ("the same rehearsal with the halo exchange (`--halo-exchange`): no frame is computed twice, a chunk's own last T-1 "
+                                          "frames stand in for the neighbour's message (no peer exists on one GPU: the wire is not rehearsed), rank 0 takes "
+                                          "0.93 of a round's chunk size in the rounds it computes in (sharding.root_share)")
+            line["root_load_halo"] = root_load_halo
 
     if rank == 0:
         line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)

@@ -46,6 +46,7 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
 # worse, deal (Swin-L as the third model of a bench process: 135 against 150 frames/s in a process of its own).
 _STREAMS = {}
 HALO_EARLY_DECODE = os.environ.get("MDQE_HALO_EARLY_DECODE", "1") != "0"     # (A/B knob: 0 = round 4's behaviour)
+HALO_OWN_STREAM = os.environ.get("MDQE_HALO_OWN_STREAM", "1") != "0"         # (A/B knob: 0 = the halo hand-over on the frame stream)
 
 
 def _shared_stream(name):
@@ -501,7 +502,7 @@ class MDQE(nn.Module):
         tail_state = {"views": None, "ev": None, "consuming": False}
 
         def send_tail():
-            """The grouped send/recv of the halo exchange, on the frame stream behind the chunk's last pass.  Never while the
+            """The grouped send/recv of the halo exchange, behind the chunk's last pass.  Never while the
             generator is being primed: every rank must issue it at the same point of its program -- between the gathers of two
             rounds -- or a rank whose chunk is a single pass would queue it BEFORE the previous round's gather and RCCL, which runs
             a rank's operations in issue order, would deadlock against a rank that queued it after."""
@@ -510,10 +511,23 @@ class MDQE(nn.Module):
             if not tail_state["consuming"]:       # (guard for future edits: calling this from plan_next / the priming loop hangs ranks)
                 raise RuntimeError("halo exchange: send_tail() while the generator is being primed -- the grouped send/recv must be "
                                    "issued between the gathers of two rounds on every rank")
-            with fctx():
-                if cuda:
-                    fstream.wait_event(tail_state["ev"])
+            if not cuda or not HALO_OWN_STREAM:
+                with fctx():
+                    if cuda:
+                        fstream.wait_event(tail_state["ev"])
+                    halo.on_tail(*tail_state["views"])
+                return
+            # On the model's COPY stream, behind the event of the chunk's last pass only.  (Rounds 3-4 issued it on the frame stream --
+            # which by now holds the NEXT round's primed passes: the message, and with it the last decoder group of every rank of this
+            # round, waited for 1-3 passes of the next round.)
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(frames_dev.device)
+            hs = self._copy_stream
+            hs.wait_event(tail_state["ev"])
+            with torch.cuda.stream(hs):
                 halo.on_tail(*tail_state["views"])
+            for v in tail_state["views"]:
+                v.record_stream(hs)
 
         from collections import deque
         states = deque()                          # prepared (their frames queued on the frame stream) and not yet decoded, in clip order

@@ -28,6 +28,15 @@ SHARD_SIDE_STREAMS = os.environ.get("MDQE_SHARD_SIDE_STREAMS", "0") == "1"
 # off by default (profiles/r05_ab_split_pass.txt)
 REST_UNTIL_MS = float(os.environ.get("MDQE_BENCH_REST_UNTIL_MS", "0"))     # bench.py's root-load rehearsal (run_round_robin_stream)
 HALO_LOCAL = os.environ.get("MDQE_HALO_LOCAL", "0") == "1"
+
+
+def root_share(halo_exchange=False, world=8):
+    """Rank 0's share of a round's chunk size in the rounds it computes in (rest_root_sizes; MDQE_SHARD_ROOT_SHARE overrides).  Measured in
+    the root-load rehearsal (profiles/r05_ab_root_share.txt): with the halo's recompute the OTHER ranks' delivery of the last round is what
+    rank 0 waits for at N = 4 and 8 and a smaller root chunk only slows them (1.0); with the halo exchange they are 5 % faster, rank 0's
+    own load decides and 0.93 balances the two (N = 8: 164.0 -> 153.2 ms per step)."""
+    v = os.environ.get("MDQE_SHARD_ROOT_SHARE", "")
+    return float(v) if v else (0.93 if halo_exchange and world >= 3 else 1.0)     # (two ranks: 0.97 left rank 1 the slower one, 153.0 / 146.1 ms)
 SHARD_SPLIT_PASS = os.environ.get("MDQE_SHARD_SPLIT_PASS", "0") == "1"
 
 FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
@@ -290,8 +299,8 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
     sizes = [chunk] if isinstance(chunk, int) else list(chunk)
     per_rank = any(isinstance(c, (list, tuple)) for c in sizes)       # a round as a list of per-RANK sizes (rest_root_sizes): zeros allowed
     w = max(world, 1)
-    if per_rank and (halo_exchange or any(isinstance(c, (list, tuple)) and len(c) != w for c in sizes)):
-        raise ValueError("chunk_plan: per-rank chunk sizes need one entry per rank and the recompute form")
+    if per_rank and any(isinstance(c, (list, tuple)) and len(c) != w for c in sizes):
+        raise ValueError("chunk_plan: per-rank chunk sizes need one entry per rank")
 
     def size_of(g):
         c = sizes[min(g // w, len(sizes) - 1)]
@@ -305,7 +314,10 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
     if halo_exchange:
         if len(edges) > 2 and edges[-1] - edges[-2] < T:
             del edges[-2]
-        return [([c for c in clips if a <= c[1] - 1 < b], a, b) for a, b in zip(edges[:-1], edges[1:])]
+        plan = [([c for c in clips if a <= c[1] - 1 < b], a, b) for a, b in zip(edges[:-1], edges[1:])]
+        if per_rank and any(b > a and not cl for cl, a, b in plan):
+            raise ValueError("chunk_plan: a chunk of the halo-exchange form holds frames but no whole clip")
+        return plan                                # (an EMPTY chunk, a == b, keeps its slot: chunk g belongs to rank g % world)
     plan = []
     for a, b in zip(edges[:-1], edges[1:]):
         cl = [c for c in clips if a <= c[0] < b]
@@ -316,19 +328,33 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
     return plan
 
 
-def rest_root_sizes(sizes, world):
-    """Per-round chunk sizes with rank 0 RESTING in the last round: that round's frames go to ranks 1 .. world-1 (its entry becomes a
-    per-rank list [0, a, a, .., b]).  Rank 0 is the only rank with work after the last gather -- the replay of the last round, the last
-    window flushes, the video merge -- and in the rounds before it replays beside its own compute; with no chunk of its own in the last
-    round it has caught up with the replay when the last gather arrives and runs the last round's updates on an idle GPU.  The other
-    ranks take 1 / (world - 1) more frames of that round each."""
+def rest_root_sizes(sizes, world, share=None, halo_exchange=False):
+    """Per-round chunk sizes that take load off rank 0, the only rank that replays the tracker (and runs the window flushes, the final
+    masks and their read-back) beside its own compute.
+    (a) Rank 0 RESTS in the last round: that round's frames go to ranks 1 .. world-1 (its entry becomes a per-rank list [0, a, a, .., b]).
+    Rank 0 is the only rank with work after the last gather -- the replay of the last round, the last window flushes, the video merge;
+    with no chunk of its own in the last round it has caught up with the replay when the last gather arrives and runs the last round's
+    updates on an idle GPU.  (world >= 3 and more than one round.)
+    (b) `share` < 1 (default: root_share(halo_exchange)): in the rounds before, rank 0's chunk is `share` of the round's size and the other ranks split
+    the rest -- the replay of N ranks' clips costs rank 0 a fixed slice of its GPU, which it gets back as fewer frames."""
     sizes = list(sizes)
-    if world < 3 or len(sizes) < 2 or isinstance(sizes[-1], (list, tuple)):
+    if world < 2 or any(isinstance(s_, (list, tuple)) for s_ in sizes):
         return sizes
-    total = int(sizes[-1]) * world
-    base, extra = divmod(total, world - 1)
-    sizes[-1] = [0] + [base + (1 if r < extra else 0) for r in range(world - 1)]
-    return sizes
+    share = root_share(halo_exchange, world) if share is None else float(share)
+    rest = world >= 3 and len(sizes) >= 2
+    out = []
+    for q, c in enumerate(sizes):
+        c = int(c)
+        if rest and q == len(sizes) - 1:
+            root = 0
+        elif share < 1.0:
+            root = max(1, int(round(c * share)))
+        else:
+            out.append(c)
+            continue
+        base, extra = divmod(c * world - root, world - 1)
+        out.append([root] + [base + (1 if r < extra else 0) for r in range(world - 1)])
+    return out
 
 
 def owned_chunks(plan, world, rank):
@@ -380,12 +406,19 @@ class _Halo:
     of two rounds.  Rank 0's left neighbour is the LAST rank of the previous round: what rank 0 receives in round q it uses in
     round q+1 (`carry`).  gloo (the 1-GPU tests) moves host copies."""
 
-    def __init__(self, dist, send_to, recv_from, dims, device, carry_src=None, group=None):
+    def __init__(self, dist, send_to, recv_from, dims, device, carry_src=None, group=None, carry_from=None, local=False):
         self.dist, self.send_to, self.recv_from, self.dims, self.device = dist, send_to, recv_from, dims, device
         self.group = group                         # the exchange's own communicator (halo_group); None = the default group
         self.tail_sent = False
-        self.works, self.recv_buf, self.send_buf = [], None, None
-        self.carry_src = carry_src                 # rank 0: the _Halo of the previous round (its message is this round's head)
+        self.works, self.recv_buf, self.send_buf, self.carry_buf = [], None, None, None
+        # recv_from: the owner of the chunk in front of this one when it runs in the SAME round (this chunk's head).  carry_from: the
+        # owner of the chunk in front of this rank's NEXT chunk, when that one runs in this round -- the message is posted here, where
+        # every rank of the round issues its grouped send/recv, and read a round later through `carry_src` (the _Halo that posted it)
+        self.carry_from = carry_from
+        self.carry_src = carry_src
+        # local: the rehearsal forms on one GPU (HALO_LOCAL at world 1; the root-load rehearsal of an N-rank plan): this chunk's own
+        # tail stands in for every message it would receive -- what the exchange costs WITHOUT the communicator
+        self.local = bool(local)
         self.host = dist is not None and getattr(dist, "get_backend", lambda: "")() == "gloo"
 
     def on_tail(self, enc_tail, mf_tail):
@@ -393,12 +426,14 @@ class _Halo:
         self.tail_sent = True
         T1, N, C, Hm, Wm, M = self.dims
         ops = []
-        if HALO_LOCAL and self.send_to is not None and self.send_to == self.recv_from:
-            # (tools A/B at world 1: the message handed over in place of the grouped send/recv to oneself -- what the exchange costs
-            # WITHOUT the communicator)
+        if self.local:
             k = enc_tail.shape[0]
-            self.recv_buf = torch.cat([enc_tail.reshape(k, -1), mf_tail.reshape(k, -1)], 1).contiguous()
-            self.local_ev = torch.cuda.Event() if self.recv_buf.is_cuda else None
+            flat = torch.cat([enc_tail.reshape(k, -1), mf_tail.reshape(k, -1)], 1).contiguous()
+            if self.recv_from is not None:
+                self.recv_buf = flat
+            if self.carry_from is not None:
+                self.carry_buf = flat
+            self.local_ev = torch.cuda.Event() if flat.is_cuda else None
             if self.local_ev is not None:
                 self.local_ev.record()
             return
@@ -410,30 +445,35 @@ class _Halo:
         if self.recv_from is not None:
             self.recv_buf = torch.empty(T1, N * C + Hm * Wm * M, dtype=torch.float32, device="cpu" if self.host else self.device)
             ops.append(self.dist.P2POp(self.dist.irecv, self.recv_buf, self.recv_from, self.group))
+        if self.carry_from is not None:
+            self.carry_buf = torch.empty(T1, N * C + Hm * Wm * M, dtype=torch.float32, device="cpu" if self.host else self.device)
+            ops.append(self.dist.P2POp(self.dist.irecv, self.carry_buf, self.carry_from, self.group))
         if ops:
             self.works = self.dist.batch_isend_irecv(ops)
 
-    def received(self):
-        """The message this rank received in this round (complete on the current stream), or None."""
+    def received(self, carry=False):
+        """The message this rank received in this round (complete on the current stream), or None: the head of this round's chunk, or
+        (carry=True) the head of this rank's next chunk."""
         for w in self.works:
             w.wait()
         self.works = []
         if getattr(self, "local_ev", None) is not None:
             torch.cuda.current_stream().wait_event(self.local_ev)
-        if self.recv_buf is None:
+        buf = self.carry_buf if carry else self.recv_buf
+        if buf is None:
             return None
         if self.host:
-            return self.recv_buf.to(self.device)       # (pageable host memory: a plain, blocking copy -- this is the gloo rehearsal path)
+            return buf.to(self.device)                 # (pageable host memory: a plain, blocking copy -- this is the gloo rehearsal path)
         # the buffer was allocated under the FRAME stream (on_tail) and is read on the caller's stream: tell the caching allocator,
         # or the block could be handed to a later frame-stream allocation while the reader's kernels are still queued
-        self.recv_buf.record_stream(torch.cuda.current_stream(self.recv_buf.device))
+        buf.record_stream(torch.cuda.current_stream(buf.device))
         if self.send_buf is not None and self.send_buf.is_cuda:
             self.send_buf.record_stream(torch.cuda.current_stream(self.send_buf.device))
-        return self.recv_buf
+        return buf
 
     def head(self):
         """(encoder tokens [T-1, N, C], mask features [T-1, Hm, Wm, M]) of the T-1 frames before this chunk."""
-        flat = self.carry_src.received() if self.carry_src is not None else self.received()
+        flat = self.carry_src.received(carry=True) if self.carry_src is not None else self.received()
         if flat is None:
             raise RuntimeError("halo exchange: no message from the left neighbour")
         T1, N, C, Hm, Wm, M = self.dims
@@ -444,7 +484,7 @@ class _Job:
     """One video of the round-robin schedule on this rank: its chunks, its merger and (root-only form) its replay thread."""
 
     def __init__(self, model, chunk_frames, plan, rank, world, out_size, emit_masks, root_only, like=None, dist=None,
-                 halo_exchange=False):
+                 halo_exchange=False, local_halo=False):
         from .meta_arch import ClipMerger
         cfg = model.cfg
         self.model, self.chunk_frames, self.plan, self.rank, self.world = model, chunk_frames, plan, rank, world
@@ -460,10 +500,11 @@ class _Job:
         self.proto = {"scores": ((), torch.float32), "pred_classes": ((), torch.int64), "cls_probs": ((cfg.num_classes,), torch.float32),
                       "query_embeds": ((cfg.hidden_dim,), torch.float32), "pred_masks": ((self.T,) + tuple(mask_hw), torch.float32)}
         self.dist, self.halo_exchange = dist, bool(halo_exchange)
+        self.local_halo = bool(local_halo)         # the root-load rehearsal: no peer exists, a chunk's own tail stands in (_Halo.local)
         self.halo_carry = None                     # rank 0: the last rank's tail of the previous round
         self.halos = {}
         self.halo_dims = (geo.N, cfg.hidden_dim, mask_hw[0], mask_hw[1], cfg.mask_dim) if halo_exchange else None
-        self.halo_pg = halo_group(dist, world) if halo_exchange else None
+        self.halo_pg = halo_group(dist, world) if halo_exchange and not local_halo else None
         self.merger = self.replay = None
         if not root_only or rank == 0:
             self.merger = ClipMerger(model, (h, w), out_size, mask_hw, n_frames=max(c[2] for c in plan), emit_masks=emit_masks)
@@ -500,19 +541,38 @@ class _Job:
         return gen
 
     def _halo(self, q, g):
-        """Send to the owner of chunk g+1, receive from the owner of chunk g-1 -- or, on rank 0, the tail of the round's LAST
-        chunk, which the NEXT round's first chunk (rank 0 again) needs."""
-        world, rank = self.world, self.rank
-        send_to = (rank + 1) % world if g + 1 < len(self.plan) else None
-        carry_src = None
-        if rank > 0:
-            recv_from = rank - 1
-        else:
-            recv_from = world - 1 if q * world + world < len(self.plan) else None      # consumed in round q+1
-            carry_src = self.halos.get(q - 1) if g > 0 else None
-        if world == 1 and self.dist is None:
-            send_to = recv_from = None                 # (with a backend, one rank sends to itself: the 1-GPU RCCL rehearsal)
-        h = _Halo(self.dist, send_to, recv_from, (self.T - 1,) + self.halo_dims, self.device, carry_src=carry_src, group=self.halo_pg)
+        """The exchange of this rank's chunk g (round q) in the ring of the plan's NON-EMPTY chunks: its tail goes to the owner of the
+        next one; its head comes from the owner of the one before -- in the same grouped send/recv when that chunk runs in this round,
+        else from the message this rank posted a round earlier (`carry`: rank 0, whose left neighbour is the last rank of the round
+        before; with a resting root, rank 1 in the last round)."""
+        world, rank, plan = self.world, self.rank, self.plan
+
+        def step(i, d):
+            i += d
+            while 0 <= i < len(plan) and not plan[i][0]:
+                i += d
+            return i if 0 <= i < len(plan) else None
+        nx, pv = step(g, 1), step(g, -1)
+        send_to = nx % world if nx is not None else None
+        recv_from = carry_src = carry_from = None
+        if pv is not None:
+            if pv // world == q:
+                recv_from = pv % world
+            else:
+                carry_src = self.halos.get(pv // world)
+                if carry_src is None or carry_src.carry_from is None:
+                    raise ValueError("halo exchange: chunk %d's left neighbour ran in round %d, where rank %d posted no receive for it"
+                                     % (g, pv // world, rank))
+        g2 = next((i for i in range(g + world, len(plan), world) if plan[i][0]), None)      # this rank's next non-empty chunk ...
+        if g2 is not None:
+            p2 = step(g2, -1)
+            if p2 is not None and p2 // world == q and g2 // world > q:
+                carry_from = p2 % world            # ... whose left neighbour runs in THIS round: its tail is received now
+        local = self.local_halo or (HALO_LOCAL and world == 1)
+        if world == 1 and self.dist is None and not local:
+            send_to = recv_from = carry_from = None    # (with a backend, one rank sends to itself: the 1-GPU RCCL rehearsal)
+        h = _Halo(self.dist, send_to, recv_from, (self.T - 1,) + self.halo_dims, self.device, carry_src=carry_src, group=self.halo_pg,
+                  carry_from=carry_from, local=local)
         self.halos[q] = h
         self.halos.pop(q - 2, None)
         return h
@@ -563,9 +623,10 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     replay thread), `replay_exposed` (joining the replay + the video merge after the last gather: what no later round hides),
     `replay_busy` (the replay worker's busy time: tracker + window flushes of every round), `rounds`.
     vworld (one rank only): the root-load rehearsal -- `plan` is the plan of a `vworld`-rank job, this rank computes rank 0's chunks of it
-    and every gathered round is expanded to the `vworld` chunks rank 0 of that job would replay (expand_root_load)."""
-    if vworld is not None and (world != 1 or rank != 0 or halo_exchange):
-        raise ValueError("the root-load rehearsal runs on ONE rank, without the halo exchange")
+    and every gathered round is expanded to the `vworld` chunks rank 0 of that job would replay (expand_root_load); with the halo
+    exchange a chunk's own tail stands in for the neighbour's message (no peer exists: the wire is not rehearsed)."""
+    if vworld is not None and (world != 1 or rank != 0):
+        raise ValueError("the root-load rehearsal runs on ONE rank")
     pworld = vworld if vworld is not None else world   # the world the chunks are dealt to
     # as_rank (rehearsal only): play rank `as_rank` of the vworld-rank job instead of rank 0 -- its chunks, no replay (a non-root rank of
     # the root-only schedule computes and sends): what the OTHER ranks' step costs when rank 0 rests in the last round
@@ -579,7 +640,8 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     def open_next():
         j = next(it, None)
         return None if j is None else _Job(model, j[0], j[1], prank, pworld, out_size, emit_masks, root_only,
-                                           like=j[2] if len(j) > 2 else None, dist=dist, halo_exchange=halo_exchange)
+                                           like=j[2] if len(j) > 2 else None, dist=dist, halo_exchange=halo_exchange,
+                                           local_halo=halo_exchange and vworld is not None)
 
     def finish(j):
         t0 = time.perf_counter()

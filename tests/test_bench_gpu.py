@@ -75,6 +75,13 @@ def test_bench_side_configs_and_root_load_ride_in_the_same_line():
     assert rl["root_ms_per_step"] >= rl["last_gather_not_before_ms"]               # rank 0 was held at the last gather until rank 1 would have delivered
     assert abs(rl["predicted_efficiency"] - rl["single_gpu_ms_per_step"] / rl["ms_per_step"]) < 1e-9
     assert rl["tracker_native_ms_per_step"]["updates_per_step"] >= 8 * 30       # the replay really carried eight ranks' clips
+    # ... and the halo-exchange form of the same rehearsal: no frame twice, rank 0 rests in the last round and takes a smaller chunk before
+    rh = d["root_load_halo"]
+    assert "error" not in rh, rh
+    assert rh["world"] == 8 and rh["verified"] is True and rh["halo_frac"] == 0.0 and rh["ms_per_step"] > 0 and 0.0 < rh["predicted_efficiency"] <= 1.1
+    first, last = rh["chunk_frames_per_round"][0], rh["chunk_frames_per_round"][-1]
+    assert isinstance(first, list) and first[0] < first[1] and sum(first) == 8 * rl["chunk_frames_per_round"][0] and last[0] == 0
+    assert rh["tracker_native_ms_per_step"]["updates_per_step"] >= 8 * 30
 
 
 def test_bench_gpus_2_runs_two_ranks_without_torchrun():

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 VIDEO_MODES = ["round_robin", "root_only", "contiguous", "halo_exchange", "decreasing", "decreasing_halo_exchange"]
 STREAM_MODES = ["stream", "stream_root_only", "stream_two_window_chunks", "stream_halo_exchange"]
 ONE_RANK_MODES = ["round_robin", "root_only", "stream_root_only", "halo_exchange", "stream_halo_exchange"]
-FOUR_RANK_MODES = ["round_robin", "halo_exchange", "stream_root_only", "stream_halo_exchange"]
+FOUR_RANK_MODES = ["round_robin", "halo_exchange", "stream_root_only", "stream_halo_exchange", "rest_root", "rest_root_halo_exchange"]
+REST_L = 44                                # the resting-root modes' video: three rounds of 4-frame chunks on four ranks, the last without rank 0
 
 
 def _cfg():
@@ -48,6 +49,19 @@ def _run_mode(mode, model, cfg, rank, world, dist, sharding):
             jobs.append(({g: v[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank)}, plan, v[:0].cuda()))
         out = list(sharding.run_round_robin_stream(model, jobs, rank, world, dist, (64, 96), root_only=root_only, halo_exchange=halo))
         assert len(out) == len(STREAM) and (not root_only or all((o is None) == (rank != 0) for o in out))
+        return out
+    if mode.startswith("rest_root"):
+        # rank 0 rests in the last of three rounds (sharding.rest_root_sizes), root-only gathers; with the halo exchange the ring skips the
+        # empty chunk: the last rank of round 1 sends its tail to rank 1
+        halo = mode.endswith("halo_exchange")
+        video = _video(REST_L, 7)
+        sizes = sharding.rest_root_sizes([4, 4, 3], world)
+        assert sizes[-1] == [0, 4, 4, 4]
+        plan = sharding.chunk_plan(REST_L, cfg.n_frames_test, cfg.clip_stride, sizes, halo_exchange=halo, world=world)
+        assert len(plan) == 12 and not plan[8][0]
+        frames = {g: video[plan[g][1]:plan[g][2]].cuda() for g in sharding.owned_chunks(plan, world, rank) if plan[g][0]}
+        out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (64, 96), root_only=True, halo_exchange=halo, like=video[:0].cuda())
+        assert (out is None) == (rank != 0)
         return out
     if mode == "contiguous":
         f0, f1 = sharding.frame_range(L, world, rank, cfg.n_frames_test)
@@ -124,6 +138,7 @@ def refs():
     model = MDQE(_cfg(), seed=5).eval()
     with torch.no_grad():
         return {"video": model([{"image": _video(), "height": 64, "width": 96}]),
+                "rest": model([{"image": _video(REST_L, 7), "height": 64, "width": 96}]),
                 "stream": [model([{"image": _video(Lv, seed), "height": 64, "width": 96}]) for Lv, seed in STREAM]}
 
 
@@ -193,10 +208,12 @@ def test_four_rank_sharded_equals_single_gpu(four_ranks, refs, mode):
     d, codes = four_ranks
     errs = sorted(f for f in os.listdir(d) if f.endswith(".err"))
     assert codes == [0, 0, 0, 0] and not errs, "exit codes %s\n%s" % (codes, "\n".join("%s:\n%s" % (f, open(os.path.join(d, f)).read()) for f in errs))
-    root = mode in ("root_only", "stream_root_only")
+    root = mode in ("root_only", "stream_root_only") or mode.startswith("rest_root")
     for r in range(1 if root else 4):
         outs = _load(d, mode, r)
-        if mode.startswith("stream"):
+        if mode.startswith("rest_root"):
+            _same(outs, refs["rest"])
+        elif mode.startswith("stream"):
             for out, ref in zip(outs, refs["stream"]):
                 _same(out, ref)
         else:

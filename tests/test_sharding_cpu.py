@@ -384,7 +384,7 @@ def test_chunk_plan_properties_on_random_inputs():
 
 
 # ---- the halo exchange's ring on its own process group (gloo, 3 ranks, 2 rounds) ------------------------------------------------------
-def halo_worker(rank, world, port, outdir):
+def halo_worker(rank, world, port, outdir, rounds=2, rest=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -392,14 +392,20 @@ def halo_worker(rank, world, port, outdir):
     T1, N, C, Hm, Wm, M = 3, 5, 4, 2, 3, 2
     job = sharding._Job.__new__(sharding._Job)                 # only what _halo() reads
     job.world, job.rank, job.dist, job.T, job.device = world, rank, dist, T1 + 1, torch.device("cpu")
-    job.plan = [None] * (2 * world)                            # two rounds of `world` chunks
-    job.halo_dims, job.halos = (N, C, Hm, Wm, M), {}
+    job.plan = [([g], g, g + 1) for g in range(rounds * world)]      # `rounds` rounds of `world` chunks (only emptiness is read)
+    if rest:
+        job.plan[(rounds - 1) * world] = ([], 0, 0)            # rank 0 rests in the last round (rest_root_sizes)
+    job.halo_dims, job.halos, job.local_halo = (N, C, Hm, Wm, M), {}, False
     job.halo_pg = sharding.halo_group(dist, world)
     assert job.halo_pg is not None and job.halo_pg is not dist.group.WORLD        # its own communicator
     assert sharding.halo_group(dist, world) is job.halo_pg                          # created once
     got = {}
-    for q in range(2):
+    for q in range(rounds):
         g = q * world + rank
+        if not job.plan[g][0]:
+            t = torch.ones(1)
+            dist.all_reduce(t)                                 # (the resting rank still takes part in the round's default-group collective)
+            continue
         h = job._halo(q, g)
         # a collective on the DEFAULT group between the exchanges, issued on different sides of it by even and odd ranks: harmless now
         t = torch.ones(1)
@@ -436,6 +442,29 @@ def test_halo_ring_on_its_own_process_group(tmp_path):
     assert sorted(seen) == [1, 2, 3, 4, 5]
     for g, (e, m, es, ms_) in seen.items():
         assert e == float(g - 1) and m == float(g - 1) + 0.5 and es == (3, 5, 4) and ms_ == (3, 2, 3, 2), (g, e, m)
+
+
+def test_halo_ring_skips_the_resting_root(tmp_path):
+    """The ring over the NON-EMPTY chunks of a plan (sharding._Job._halo) with rank 0 resting in the last of three rounds, four ranks: the
+    last rank of round 1 sends its tail to rank 1, which posted the receive in round 1 beside its own chunk's and reads it a round later;
+    rank 0 posts nothing for a round it does not compute."""
+    world, rounds = 4, 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=halo_worker, args=(r, world, port, str(tmp_path), rounds, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    seen = {}
+    for r in range(world):
+        seen.update(torch.load(os.path.join(str(tmp_path), f"halo{r}.pt"), weights_only=False))
+    g_rest = (rounds - 1) * world
+    assert sorted(seen) == [g for g in range(1, rounds * world) if g != g_rest]
+    for g, (e, m, es, ms_) in seen.items():
+        src = g - 2 if g == g_rest + 1 else g - 1                 # chunk g_rest + 1 reads the tail of the chunk BEFORE the empty one
+        assert e == float(src) and m == float(src) + 0.5, (g, e, m)
 
 
 def test_root_load_expansion_is_the_round_rank_0_of_an_n_rank_job_would_gather():
@@ -489,7 +518,17 @@ def test_resting_root_plan_keeps_every_clip_once_and_rank_0_free_in_the_last_rou
     assert sharding.rest_root_sizes([69, 34, 17], 2) == [69, 34, 17] and sharding.rest_root_sizes([120], 8) == [120]
     import pytest
     with pytest.raises(ValueError):
-        sharding.chunk_plan(100, T, 1, [10, [0, 5]], halo_exchange=True, world=2)
+        sharding.chunk_plan(100, T, 1, [10, [0, 5, 5]], world=2)                      # one entry per rank
+    with pytest.raises(ValueError):
+        sharding.chunk_plan(100, T, 1, [[2, 10]], halo_exchange=True, world=2)       # frames but no whole clip
+    # the halo-exchange form with a resting root: the frames are partitioned, the empty chunk keeps its slot, every clip once and in order
+    for per, W in ((120, 8), (60, 3)):
+        sizes = sharding.rest_root_sizes(sharding.round_sizes(per, T, ratio=0.6), W)
+        plan = sharding.chunk_plan(per * W, T, 1, sizes, halo_exchange=True, world=W)
+        g_rest = (len(sizes) - 1) * W
+        assert plan[g_rest][0] == [] and plan[g_rest][1] == plan[g_rest][2]
+        assert [c for ch in plan for c in ch[0]] == clip_schedule(per * W, T, 1)
+        assert all(a[2] == b[1] for a, b in zip(plan[:-1], plan[1:])) and plan[0][1] == 0 and plan[-1][2] == per * W
 
 
 def test_root_load_expansion_with_a_resting_root_repeats_its_last_own_round():
