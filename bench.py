@@ -828,7 +828,14 @@ def main():
         the verdict (broadcast); a mismatch ends the run with exit code 3 on all ranks."""
         Lv = max(2 * cfg.n_frames_window_test, 12 * world)
         cv = max(T + 2, Lv // (2 * world))
-        shards["verify"] = shard(halo, Lv, cv, seed=1)
+        # the same KIND of plan as the timed job's: from three ranks up rank 0 rests in the second round (and, with the halo exchange, takes
+        # a smaller first chunk; the ring of send/recv then skips its empty chunk)
+        cplan = sharding.rest_root_sizes([cv, cv], world, halo_exchange=halo) if root_rest and isinstance(chunk, list) else cv
+        try:
+            shards["verify"] = shard(halo, Lv, cplan, seed=1)
+        except ValueError:
+            cplan = cv
+            shards["verify"] = shard(halo, Lv, cplan, seed=1)
         with torch.no_grad():
             o = sharding.run_round_robin(model, shards["verify"][1], shards["verify"][0], rank, world, dist, out_size=(fh, fw), root_only=True,
                                          halo_exchange=halo, like=like)
@@ -847,7 +854,7 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.broadcast(flag, 0)
         sync()
-        return bool(int(flag.item())), {"frames": Lv, "chunk_frames": cv, "rounds": -(-len(sharding.chunk_plan(Lv, T, cfg.clip_stride, cv, halo, world)) // world)}
+        return bool(int(flag.item())), {"frames": Lv, "chunk_frames": cplan, "rounds": -(-len(sharding.chunk_plan(Lv, T, cfg.clip_stride, cplan, halo, world)) // world)}
 
     STAT_KEYS = ("compute", "pack", "gather_wait", "gather_payload", "feed", "replay_exposed", "replay_busy")
 
