@@ -37,6 +37,12 @@ extern "C" {
 #define MDQE_ACT_SIGMOID 3
 #define MDQE_ACT_TANH 4
 
+/* ABI version of this header: bumped whenever an existing entry point changes what it reads or WRITES under an unchanged signature.
+ *   6: mdqe_f16x3_split_f32 writes THREE planes (6*n bytes; versions < 6 wrote two, 4*n bytes) -- a caller that sized its buffer for an
+ *      older header must not call a newer library.  mdqe_abi_version() returns the library's value; a binding compares it with the
+ *      MDQE_ABI_VERSION it was written against before the first call (mdqe_cvpr2023_amd/_lib.py does, and refuses a mismatch). */
+#define MDQE_ABI_VERSION 6
+int mdqe_abi_version(void);
 int mdqe_version(void);
 const char* mdqe_strerror(int code);
 

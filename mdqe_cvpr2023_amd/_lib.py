@@ -102,6 +102,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 6                     # include/mdqe_hip.h MDQE_ABI_VERSION this binding was written against
+
+
 class LibraryMissing(RuntimeError):
     pass
 
@@ -127,6 +130,11 @@ def load_library(path=None):
     import torch  # noqa: F401
     h = ctypes.CDLL(path)
     h.mdqe_version.restype = c_int
+    h.mdqe_abi_version.restype = c_int                 # AttributeError on a library older than the versioned ABI: loud by design
+    h.mdqe_abi_version.argtypes = []
+    if h.mdqe_abi_version() != ABI_VERSION:
+        raise MdqeError(f"{path} implements ABI {h.mdqe_abi_version()}, this binding was written against ABI {ABI_VERSION} "
+                        f"(include/mdqe_hip.h MDQE_ABI_VERSION): rebuild with `make -C mdqe_cvpr2023_amd/csrc`")
     h.mdqe_strerror.restype = c_char_p
     h.mdqe_strerror.argtypes = [c_int]
     h.mdqe_get_gemm_precision.restype = c_int

@@ -1,5 +1,6 @@
 #include "common.h"
 extern "C" int mdqe_version(void) { return 100; }
+extern "C" int mdqe_abi_version(void) { return MDQE_ABI_VERSION; }
 extern "C" const char* mdqe_strerror(int code) {
   switch (code) {
     case MDQE_OK: return "ok";

@@ -59,11 +59,13 @@ def main(argv=None):
         import subprocess
         env = prepare_environment(dict(os.environ))
         # The child is the script's own process tree (detectron2 `launch` / mp.spawn ranks below it).  It stays in the terminal's foreground
-        # process group, so a Ctrl-C reaches it ONCE, from the terminal; this parent ignores SIGINT and only forwards SIGTERM (which a
-        # supervisor sends to this pid alone).  Handlers are in place BEFORE the child exists: no window in which a signal kills the
-        # parent and orphans the ranks.
+        # process group, so a Ctrl-C reaches it ONCE, from the terminal; this parent survives SIGINT (to pass the child's exit code on) and
+        # only forwards SIGTERM (which a supervisor sends to this pid alone).  The parent's SIGINT disposition is a no-op HANDLER, not
+        # SIG_IGN: an ignored signal stays ignored across fork/exec (and CPython then never installs KeyboardInterrupt), a handler is reset
+        # to the default in the child -- the script and its ranks stay interruptible.  Handlers are in place BEFORE the child exists: no
+        # window in which a signal kills the parent and orphans the ranks.
         holder = {}
-        signal.signal(signal.SIGINT, signal.SIG_IGN)
+        signal.signal(signal.SIGINT, lambda s, f: None)
         signal.signal(signal.SIGTERM, lambda s, f: holder["p"].send_signal(s) if "p" in holder else sys.exit(128 + s))
         proc = holder["p"] = subprocess.Popen([sys.executable, argv[0]] + argv[1:], env=env)
         rc = proc.wait()

@@ -26,8 +26,10 @@ SHARD_SIDE_STREAMS = os.environ.get("MDQE_SHARD_SIDE_STREAMS", "0") == "1"
 # split_small) -- the previous round's clip work, and with it that round's gather and the start of its replay on rank 0, trails the pass
 # queued behind it.  Measured in the N = 8 / N = 4 root-load rehearsal: 179.2 against 177.3 ms, 169.6 against 166.5 ms per step -- no gain, so
 # off by default (profiles/r05_ab_split_pass.txt)
-REST_UNTIL_MS = float(os.environ.get("MDQE_BENCH_REST_UNTIL_MS", "0"))     # bench.py's root-load rehearsal (run_round_robin_stream)
+SHARD_SPLIT_PASS = os.environ.get("MDQE_SHARD_SPLIT_PASS", "0") == "1"
 HALO_LOCAL = os.environ.get("MDQE_HALO_LOCAL", "0") == "1"
+
+FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
 
 
 def root_share(halo_exchange=False, world=8):
@@ -37,9 +39,6 @@ def root_share(halo_exchange=False, world=8):
     own load decides and 0.93 balances the two (N = 8: 164.0 -> 153.2 ms per step)."""
     v = os.environ.get("MDQE_SHARD_ROOT_SHARE", "")
     return float(v) if v else (0.93 if halo_exchange and world >= 3 else 1.0)     # (two ranks: 0.97 left rank 1 the slower one, 153.0 / 146.1 ms)
-SHARD_SPLIT_PASS = os.environ.get("MDQE_SHARD_SPLIT_PASS", "0") == "1"
-
-FIELDS = ("scores", "pred_classes", "cls_probs", "query_embeds", "pred_masks")
 
 
 def owned_range(L, world, rank):
@@ -304,6 +303,10 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
 
     def size_of(g):
         c = sizes[min(g // w, len(sizes) - 1)]
+        if g // w >= len(sizes) and isinstance(c, (list, tuple)) and min(c) == 0:
+            # a video longer than the sizes were planned for: a RESTING entry (a rank with 0 frames) is not repeated -- the overflow
+            # rounds deal the same round total evenly, so no rank idles in every remaining round
+            return max(1, -(-sum(int(v) for v in c) // w))
         return int(c[g % w]) if isinstance(c, (list, tuple)) else int(c)
     if any((min(c) < 0 or max(c) < 1) if isinstance(c, (list, tuple)) else int(c) < 1 for c in sizes):
         raise ValueError("chunk_plan: chunk sizes must be positive")
@@ -364,7 +367,7 @@ def owned_chunks(plan, world, rank):
 
 
 def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, like=None,
-                    stats=None, vworld=None, as_rank=0):
+                    stats=None, vworld=None, as_rank=0, rest_until_ms=0.0):
     """chunk_frames: {g: device tensor of frames plan[g].f0 .. plan[g].f1} for the chunks this rank owns.
     Default: every rank all-gathers each round and replays the tracker (all ranks return the video result;
     emit_masks=False skips the mask production on ranks that only keep the tracker in step).
@@ -373,7 +376,7 @@ def run_round_robin(model, chunk_frames, plan, rank, world, dist, out_size, emit
     `like`: any [.., h, w] tensor on the frames' device -- needed by a rank that owns NO chunk of this video (more ranks than chunks)."""
     return next(run_round_robin_stream(model, [(chunk_frames, plan, like) if like is not None else (chunk_frames, plan)], rank, world, dist, out_size,
                                        emit_masks=emit_masks, root_only=root_only, halo_exchange=halo_exchange, stats=stats, vworld=vworld,
-                                       as_rank=as_rank))
+                                       as_rank=as_rank, rest_until_ms=rest_until_ms))
 
 
 _HALO_GROUPS = {}
@@ -610,7 +613,7 @@ def halo_recompute_frac(plan, L):
 
 
 def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=True, root_only=False, halo_exchange=False, stats=None,
-                           vworld=None, as_rank=0):
+                           vworld=None, as_rank=0, rest_until_ms=0.0):
     """Videos as a stream through the round-robin schedule.  jobs: iterable of (chunk_frames, plan[, like]) as for
     run_round_robin (`like`: any [.., h, w] tensor on the device, for a rank that owns no chunk of a short video); yields each video's result in order (None on the ranks that do not replay).  Within a video the next round's per-frame
     work is queued before this round's clip work; ACROSS videos the first round of video k+1 is queued before the last round's
@@ -624,7 +627,9 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
     `replay_busy` (the replay worker's busy time: tracker + window flushes of every round), `rounds`.
     vworld (one rank only): the root-load rehearsal -- `plan` is the plan of a `vworld`-rank job, this rank computes rank 0's chunks of it
     and every gathered round is expanded to the `vworld` chunks rank 0 of that job would replay (expand_root_load); with the halo
-    exchange a chunk's own tail stands in for the neighbour's message (no peer exists: the wire is not rehearsed)."""
+    exchange a chunk's own tail stands in for the neighbour's message (no peer exists: the wire is not rehearsed).
+    rest_until_ms (rehearsal of a resting root only; bench.py supplies the other ranks' measured compute + pack): a round in which
+    this rank has no chunk is gathered no earlier than that many milliseconds after the start of the video."""
     if vworld is not None and (world != 1 or rank != 0):
         raise ValueError("the root-load rehearsal runs on ONE rank")
     pworld = vworld if vworld is not None else world   # the world the chunks are dealt to
@@ -670,10 +675,10 @@ def run_round_robin_stream(model, jobs, rank, world, dist, out_size, emit_masks=
                         nxt_gen = nxt_job.start(0) if nxt_job is not None else None
                     local = [r for r in gen] if gen is not None else []     # ... and runs under this round's decoder + clip inference
                     t_c = time.perf_counter()
-                    if vworld is not None and prank == 0 and REST_UNTIL_MS > 0 and not job.plan[q * vworld][0]:
+                    if vworld is not None and prank == 0 and rest_until_ms > 0 and not job.plan[q * vworld][0]:
                         # rehearsal of a resting root: the round's gather completes when the OTHER ranks deliver -- not before
-                        # REST_UNTIL_MS after the start of the video (their measured compute + pack); the replay thread works on meanwhile
-                        while (time.perf_counter() - job.t0) * 1e3 < REST_UNTIL_MS:
+                        # rest_until_ms after the start of the video (their measured compute + pack); the replay thread works on meanwhile
+                        while (time.perf_counter() - job.t0) * 1e3 < rest_until_ms:
                             time.sleep(2e-4)
                     tg = {}
                     merged = all_gather_clips(local, job.T, dist, world, job.device, job.proto, root=0 if root_only else None, rank=rank, timing=tg)

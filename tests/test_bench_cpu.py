@@ -90,7 +90,8 @@ def test_cpu_baseline_runs_and_reports_cores_and_model():
     r = cpu_baseline(cfg, sd, synth_video(0, 4, seed=0))
     assert r["kind"] == "port" and r["unit"] == "frames/s" and r["value"] > 0 and 1 <= r["cores"] <= r["physical_cores"] <= r["logical_cpus"]
     assert r["cpu_model"] and len(r["threads_tried"]) >= 1 and abs(max(r["threads_tried"].values()) - r["value"]) < 1e-3
-    assert 0 < r["as_reference"]["value"] < r["value"]           # the reference's window recompute costs three more frame passes
+    assert 0 < r["as_reference_value"] < r["value"]              # the reference's window recompute costs three more frame passes
+    assert len(r["threads_tried"]) == 1 and len(r["sample"]) <= 140      # a bounded sweep; the line quotes the sample as it is
 
 
 def test_a_failing_rank_ends_the_whole_run_quickly_and_loudly():
@@ -163,3 +164,108 @@ def test_soft_deadline_prints_what_it_has_and_leaves_with_exit_code_zero():
     assert r.returncode == 0, r.stderr[-2000:]
     out = r.stdout.splitlines()
     assert out[0] == "FIRST" and out[1].startswith('{"value": 1.0') and "UNREACHABLE" not in r.stdout and "NEVER" not in r.stdout
+
+
+def _fat_full_line():
+    """A full result object with every leg on and paragraphs in every free-text field (what round 5's 25.7 KB line looked like)."""
+    prose = "x" * 3000
+    roof = {"bound": "mfma", "kernel": "gemm_nt_f32_k16_kernel " + prose, "achieved": 93.7238391576, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.5958286024,
+            "traffic": None, "traffic_ref": "profiles/r05_pmc_gemm_summary.txt " + prose, "launches": 312, "launches_timed": 312, "launches_total": 1560,
+            "avg_launch_us": 558.5852541710035, "note": prose}
+    msda = {"bound": "hbm", "kernel": prose, "achieved": 1.1229757790084047, "peak": 8.0, "unit": "TB/s", "frac": 0.1403719723760506, "frac_isolated": 0.157,
+            "avg_launch_us": 314.3, "algorithmic_MB_per_launch": 352.95, "traffic": None, "traffic_ref": "profiles/x.txt", "bytes": prose,
+            "decoder_box": {"frac": 0.034, "frac_isolated": 0.205, "bytes": prose}, "decoder_temporal": {"frac": 0.056, "frac_isolated": 0.139, "bytes": prose}}
+    side = {"value": 306.9, "ms_per_step": 195.5, "frames_per_step": 60, "steps": 4, "workload": prose, "roofline": dict(roof), "roofline_msda": dict(msda)}
+    rl = {"world": 8, "ms_per_step": 164.4, "root_ms_per_step": 164.4, "other_rank_ms_per_step": 157.0, "predicted_efficiency": 0.884, "verified": True,
+          "what": prose, "chunk_frames_per_round": [69, 34, [0, 20, 20, 20, 19, 19, 19, 19]], "tracker_native_ms_per_step": {"updates_per_step": 1197}}
+    full = {"metric": "frames/sec (eval-only) R50 OVIS 360p 4-frame clip", "value": 826.123456789, "value_median": 830.8, "unit": "frames/s", "n_gpus": 1,
+            "steps": 20, "warmup": 5, "ms_per_step": 145.26, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "value_is": prose,
+            "config": {"workload": "R50_ovis_360 eval-only, H2D included: " + prose, "frames_per_gpu": 120, "clips_per_step": 118, "instances_out": 10,
+                       "tracked_instances": 7, "parallelism": "single GPU", "output": prose},
+            "roofline": roof, "roofline_isolated": dict(roof), "roofline_msda": msda,
+            "clip_stage": {"frac": 0.385, "tflops": 60.6, "ms_per_step": 24.2, "clips": 117, "what": prose},
+            "cpu_baseline": {"value": 0.5763, "unit": "frames/s", "cores": 32, "kind": "port", "sample": prose, "cpu_model": "AMD EPYC 9575F 64-Core Processor",
+                             "physical_cores": 128, "as_reference_value": 0.34, "threads_tried": {"16": 0.53, "32": 0.57}},
+            "config_R50_ovis_720": side, "config_swinl_ovis": dict(side), "root_load": rl, "root_load_halo": dict(rl),
+            "scaling_breakdown": {"per_rank_ms": {k: [1.0] * 8 for k in ("compute", "pack", "gather_wait")}, "replay_exposed_ms": 3.0, "gather_ms": 1.0,
+                                  "halo_frac": 0.07, "rounds": 3, "what": prose},
+            "halo_exchange": {"value": 800.0, "ms_per_step": 150.0, "verified": True, "halo_frac": 0.0, "what": prose},
+            "bench_wall_s": 101.2}
+    for k in ("fast_mode", "autocast_f16", "reference_precision_map", "stream_mode", "frames_resident", "late_masks", "init_reference"):
+        full[k] = {"value": 1072.9996920898907, "unit": "frames/s", "ms_per_step": 111.8, "what": prose}
+    return full
+
+
+def test_compact_line_is_bounded_whatever_the_legs_say():
+    """the 25.7 KB line came back `parsed: null`.  The printed line is <= 4096 bytes with EVERY leg on and paragraphs in every
+    free-text field, keeps the driver's contract keys, `roofline` and `cpu_baseline`, and carries the extras as numbers only."""
+    import json
+    from bench import LINE_LIMIT, compact_line
+    full = _fat_full_line()
+    text = compact_line(full, "gpurun_out/bench_extras.json")
+    assert LINE_LIMIT == 4096 and len(text) <= LINE_LIMIT and "\n" not in text
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "roofline_msda", "extras"):
+        assert k in d, k
+    assert d["value"] == 826.123 and len(d["config"]["workload"]) <= 300 and "model" not in d["config"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and len(d["roofline"]["kernel"]) <= 60
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert d["roofline_msda"]["decoder_box_frac"] == 0.034 and d["root_load"]["predicted_efficiency"] == 0.884
+    assert d["config_R50_ovis_720"] == {"value": 306.9, "value_median": None, "ms_per_step": 195.5, "frames_per_step": 60, "steps": 4,
+                                        "roofline_frac": 0.5958, "msda_frac": 0.1404} or d["config_R50_ovis_720"]["roofline_frac"] == 0.5958
+    assert d["fast_mode"] == 1073.0 and not any(isinstance(v, str) and len(v) > 300 for v in d.values())
+    # no string anywhere in the line is a paragraph
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    assert max(len(v) for v in strings(d)) <= 300
+    # an object that cannot fit drops optional keys from the end, never the contract
+    full["scaling_breakdown"]["per_rank_ms"]["compute"] = [123.456] * 3000
+    d2 = json.loads(compact_line(full, None))
+    assert "roofline" in d2 and "cpu_baseline" in d2 and "scaling_breakdown" not in d2 and len(json.dumps(d2)) <= LINE_LIMIT
+
+
+def test_orchestrator_runs_the_headline_first_and_skips_the_rehearsal_when_the_budget_is_spent(monkeypatch, capsys, tmp_path):
+    """The default invocation: the parent starts the `main` leg FIRST, then the N = 8 root-load leg in a second child only while the wall
+    budget has room; it prints one compact line and writes the full objects to the extras file.  (run_leg is replaced: no GPU here.)"""
+    import json
+    import types
+    import bench
+    calls = []
+    full = _fat_full_line()
+    del full["root_load"], full["root_load_halo"]
+
+    def fake_leg(leg, env, argv, budget):
+        calls.append((leg, dict(env), list(argv)))
+        if leg == "main":
+            return dict(full), 0
+        return {"root_load": {"world": 8, "ms_per_step": 160.0, "verified": True}, "root_load_halo": {"world": 8, "ms_per_step": 150.0, "verified": True}}, 0
+    monkeypatch.setattr(bench, "run_leg", fake_leg)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    args = types.SimpleNamespace(no_fast_mode=False, config="R50_ovis_360", precision="f32", frames=120)
+    monkeypatch.delenv("MDQE_BENCH_ROOT_LOAD_LEG", raising=False)
+    assert bench.orchestrate(args, ["--steps", "20"]) == 0
+    out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(out) == 1 and len(out[0]) <= bench.LINE_LIMIT
+    d = json.loads(out[0])
+    assert [c[0] for c in calls] == ["main", "root_load"] and calls[1][1]["MDQE_BENCH_ROOT_LOAD"] == "8"
+    assert abs(d["root_load"]["predicted_efficiency"] - 145.26 / 160.0) < 1e-3 and abs(d["root_load_halo"]["predicted_efficiency"] - 145.26 / 150.0) < 1e-3
+    ex = json.load(open(os.path.join(str(tmp_path), d["extras"])))
+    assert len(ex["config"]["workload"]) > 3000 and ex["root_load"]["single_gpu_ms_per_step"] == 145.26      # the full objects are in the file
+    # budget spent: the rehearsal is skipped, the headline still goes out
+    calls.clear()
+    monkeypatch.setenv("MDQE_BENCH_BUDGET_S", "1")
+    assert bench.orchestrate(args, []) == 0
+    d = json.loads(capsys.readouterr().out.strip())
+    assert [c[0] for c in calls] == ["main"] and "skipped" in d["root_load"] and d["value"] == 826.123
+    # a failing main leg: no line, its exit code
+    monkeypatch.setattr(bench, "run_leg", lambda *a: ({"error": "boom"}, 3))
+    assert bench.orchestrate(args, []) == 3 and capsys.readouterr().out.strip() == ""

@@ -10,23 +10,42 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line_and_full(stdout):
+    """(the ONE printed line as a dict, its text, the full objects of the extras file it names)."""
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout[:2000]          # nothing but the JSON line on stdout
+    assert len(lines[0]) <= 4096, len(lines[0])                               # VERDICT r05: a 25.7 KB line came back `parsed: null`
+    d = json.loads(lines[0])
+    path = d["extras"] if os.path.isabs(d["extras"]) else os.path.join(ROOT, d["extras"])
+    return d, lines[0], json.load(open(path))
+
+
+def _contract(d, frames, steps, warmup):
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["vs_baseline"] is None and d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["unit"] == "frames/s"
+    assert "workload" in d["config"] and "model" not in d["config"] and "H2D included" in d["config"]["workload"] and len(d["config"]["workload"]) <= 300
+    assert abs(d["value"] - frames * 1e3 / d["ms_per_step"]) < 2e-3 * d["value"]          # value = frames per step / time per step (rounded to 3 places)
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["traffic"] is None and rf["traffic_ref"].startswith("profiles/")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.0 < rf["frac"] < 1.0 and rf["peak"] == 157.3 and len(rf["kernel"]) <= 60
+
+
 def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "24", "--no-cpu-baseline", "--no-fast-mode"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                           # ONE JSON line on stdout
-    d = json.loads(lines[0])
-    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
-                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict)):
-        assert isinstance(d[k], t), (k, d[k])
-    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["unit"] == "frames/s"
-    assert "workload" in d["config"] and "model" not in d["config"] and "H2D included" in d["config"]["workload"]
-    assert abs(d["value"] - 24 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]             # value = frames per step / time per step
+    c, text, d = _line_and_full(r.stdout)
+    _contract(c, 24, 2, 1)
+    assert c["n_gpus"] == 1 and c["config"]["clips_per_step"] == 22 and c["config"]["instances_out"] >= 1
+    assert 0.0 < c["roofline_msda"]["frac"] < 1.0 and 0.0 < c["roofline_msda"]["decoder_box_frac"] < 1.0 and 0.0 < c["roofline_msda"]["decoder_temporal_frac"] < 1.0
+    assert "cpu_baseline" not in c and "root_load" not in c                  # (--no-cpu-baseline --no-fast-mode)
+    # ... and the full objects of the same run (the extras file)
+    assert abs(d["value"] - 24 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] and abs(d["value"] - c["value"]) < 1e-3
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["traffic"] is None
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] < 1.0 and rf["peak"] == 157.3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["config"]["clips_per_step"] == 24 - 2 and d["config"]["instances_out"] >= 1
     assert rf["launches_timed"] <= rf["launches_total"] and rf["launches_total"] >= 1
     # the deformable gather's HBM figure is in the same line (north star: "rocprof HBM GB/s on the deformable gather")
@@ -41,23 +60,32 @@ def test_bench_line_contract():
         pc = rm[k]["bytes_per_clip_convention"]
         assert pc["MB_per_launch"] >= rm[k]["algorithmic_MB_per_launch"] and "frac" not in pc
     # mean and median of the per-step times, and which one `value` is
-    assert d["value_median"] > 0 and abs(d["value_median"] / d["value"] - 1) < 0.25 and d["value_is"].startswith("mean")
+    assert d["value_median"] > 0 and abs(d["value_median"] / d["value"] - 1) < 0.25
     assert d["bench_wall_s"] > 0 and "degraded" not in d
 
 
-def test_bench_side_configs_and_root_load_ride_in_the_same_line():
-    """The default invocation's extra legs at reduced size: BASELINE.json configs[2] / configs[3] (`config_R50_ovis_720`, `config_swinl_ovis`) and
-    the N = 8 root-load rehearsal (`root_load`) are keys of the SAME line as the headline, each with its own roofline objects / breakdown, and
-    the headline keeps its contract."""
-    env = dict(os.environ, MDQE_BENCH_SIDE_CONFIGS="1", MDQE_BENCH_ROOT_LOAD_LEG="8", MDQE_BENCH_SIDE_FRAMES="12", MDQE_BENCH_SIDE_STEPS="1",
-               MDQE_BENCH_SIDE_S="300", MDQE_BENCH_ROOT_LOAD_S="300")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "36", "--no-cpu-baseline", "--no-fast-mode"],
+def test_bench_default_invocation_every_leg_on_fits_the_line():
+    """The DEFAULT invocation (every leg on: extra modes, CPU baseline, configs[2] / configs[3], the N = 8 root-load rehearsal in both forms) at
+    reduced size: ONE line of at most 4096 bytes that keeps the driver's contract and carries the extras as numbers; the headline is timed
+    FIRST (the rehearsal's child starts after the main leg has left); the full objects are in the extras file."""
+    env = dict(os.environ, MDQE_BENCH_SIDE_FRAMES="12", MDQE_BENCH_SIDE_STEPS="1", MDQE_BENCH_SIDE_S="300", MDQE_BENCH_ROOT_LOAD_LEG="8",
+               MDQE_BENCH_ROOT_LOAD_S="400")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "36"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
-    d = json.loads(lines[0])
+    c, text, d = _line_and_full(r.stdout)
+    _contract(c, 36, 2, 1)
+    cb = c["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and 0 < cb["as_reference_value"] < cb["value"] and cb["sample"]
+    for k in ("fast_mode", "autocast_f16", "reference_precision_map", "stream_mode", "frames_resident", "late_masks", "init_reference"):
+        assert isinstance(c[k], float) and c[k] > 0, k                        # numbers only
+    for k in ("config_R50_ovis_720", "config_swinl_ovis"):
+        assert c[k]["value"] > 0 and 0.0 < c[k]["roofline_frac"] < 1.0 and 0.0 < c[k]["msda_frac"] < 1.0
+    for k in ("root_load", "root_load_halo"):
+        assert c[k]["world"] == 8 and c[k]["ms_per_step"] > 0 and 0.0 < c[k]["predicted_efficiency"] <= 1.1 and c[k]["verified"] is True
+    assert 0.0 < c["clip_stage"]["frac"] < 1.0 and 0.0 < c["roofline_isolated"]["frac"] < 1.0
     assert "degraded" not in d and abs(d["value"] - 36 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["root_load"]["wall_s"] > 0 and d["bench_wall_s"] > d["root_load"]["wall_s"]
     for key, cfgname in (("config_R50_ovis_720", "R50_ovis_720"), ("config_swinl_ovis", "swinl_ovis")):
         e = d[key]
         assert "error" not in e, e
@@ -68,6 +96,7 @@ def test_bench_side_configs_and_root_load_ride_in_the_same_line():
     rl = d["root_load"]
     assert "error" not in rl, rl
     assert rl["world"] == 8 and rl["frames_virtual"] == 8 * 36 and rl["ms_per_step"] > 0 and 0.0 < rl["predicted_efficiency"] <= 1.1
+    assert abs(rl["single_gpu_ms_per_step"] - d["ms_per_step"]) < 1e-9      # against THIS run's headline
     assert rl["verified"] is True and rl["replay_total_ms"] > 0 and rl["compute"] > 0 and rl["tracked_instances"] >= 1
     # rank 0 rests in the last round: the job's step is the slower of rank 0's and another rank's (a second child plays rank 1)
     assert isinstance(rl["chunk_frames_per_round"][-1], list) and rl["chunk_frames_per_round"][-1][0] == 0
@@ -101,9 +130,10 @@ def test_bench_gpus_2_runs_two_ranks_without_torchrun():
         env.update(MDQE_BENCH_BACKEND="gloo", MDQE_BENCH_ONE_DEVICE="1")
     r = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]     # nothing but the JSON line on stdout (gloo / RCCL banners -> stderr)
-    d = json.loads(lines[0])
+    c, text, d = _line_and_full(r.stdout)                                    # (gloo / RCCL banners -> stderr)
+    assert c["n_gpus"] == 2 and c["config"]["ranks_seen"] == 2 and c["verified"] is True and c["scaling"] == "weak"
+    assert abs(c["value"] - 48 * 1e3 / c["ms_per_step"]) < 2e-3 * c["value"] and len(c["scaling_breakdown"]["compute_ms"]) == 2
+    assert c["halo_exchange"]["verified"] is True and c["halo_exchange"]["value"] > 0
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["frames_per_gpu"] == 24 and d["scaling"] == "weak"
     assert abs(d["value"] - 48 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]              # whole-job frames / max-over-ranks time
     assert d["config"]["instances_out"] >= 1

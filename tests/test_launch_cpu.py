@@ -144,3 +144,23 @@ def test_alias_mode_and_exit_code_pass_through(tmp_path):
     r = subprocess.run([sys.executable, "-m", "mdqe_cvpr2023_amd.launch", str(tmp_path / "missing.py")], capture_output=True, text=True, env=_env(tmp_path),
                        cwd=ROOT, timeout=300)
     assert r.returncode == 2 and "no such script" in r.stderr
+
+
+def test_ctrl_c_reaches_the_launched_script(tmp_path):
+    """the launcher must not hand an IGNORED SIGINT down to the script (an ignored disposition survives fork/exec and CPython
+    then never installs KeyboardInterrupt).  SIGINT to the whole process group, as a terminal's Ctrl-C delivers it: the script sees
+    KeyboardInterrupt and leaves with 130; the launcher survives the signal and passes that code on."""
+    import signal
+    import subprocess
+    import time
+    script = tmp_path / "sleeper.py"
+    script.write_text("import signal, sys, time\n"
+                      "print('disposition', signal.getsignal(signal.SIGINT) is signal.default_int_handler, flush=True)\n"
+                      "try:\n    time.sleep(60)\nexcept KeyboardInterrupt:\n    print('interrupted', flush=True)\n    sys.exit(130)\n")
+    p = subprocess.Popen([sys.executable, "-m", "mdqe_cvpr2023_amd.launch", str(script)], cwd=ROOT, stdout=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    assert p.stdout.readline().strip() == "disposition True"          # Python's own handler is installed in the child
+    time.sleep(0.3)
+    os.killpg(p.pid, signal.SIGINT)
+    out, _ = p.communicate(timeout=30)
+    assert "interrupted" in out and p.returncode == 130
