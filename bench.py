@@ -465,13 +465,18 @@ def fail_hook(where, rank):
 LINE_LIMIT = 4096                     # bytes of the ONE printed line (the driver parses it; round 5's 25.7 KB line came back `parsed: null`)
 
 
-def run_leg(leg, extra_env, argv, budget):
-    """One leg of the default invocation as a CHILD process (`MDQE_BENCH_LEG=<leg> python bench.py <argv>`): a fresh HIP runtime that has the
-    GPU to itself -- the parent never touches the GPU (not even a device count), so no process that holds a GPU context ever starts another.
-    The child's stdout is its FULL result object as one JSON line; its stderr is this process's.  Returns (object or None, exit code)."""
+def start_leg(leg, extra_env, argv):
+    """One leg of the default invocation as a CHILD process (`MDQE_BENCH_LEG=<leg> python bench.py <argv>`): a fresh HIP runtime -- the
+    parent never touches the GPU (not even a device count), so no process that holds a GPU context ever starts another.  The child's stdout
+    is its FULL result object as one JSON line; its stderr is this process's."""
     import subprocess
     env = dict(os.environ, MDQE_BENCH_LEG=leg, **extra_env)
-    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True)
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True)
+
+
+def finish_leg(proc, leg, budget):
+    """-> (the leg's result object or {"error": ..}, exit code)."""
+    import subprocess
     try:
         so, _ = proc.communicate(timeout=budget)
     except subprocess.TimeoutExpired:
@@ -482,6 +487,10 @@ def run_leg(leg, extra_env, argv, budget):
     if proc.returncode != 0 or len(lines) != 1:
         return {"error": "the %s leg left with exit code %s and %d JSON lines" % (leg, proc.returncode, len(lines))}, proc.returncode or 1
     return json.loads(lines[0]), 0
+
+
+def run_leg(leg, extra_env, argv, budget):
+    return finish_leg(start_leg(leg, extra_env, argv), leg, budget)
 
 
 def write_extras(full):
@@ -544,6 +553,8 @@ def compact_line(full, extras):
     if sb:
         optional.append(("scaling_breakdown", dict(sub(sb, ("replay_exposed_ms", "gather_ms", "halo_frac", "rounds")),
                                                    compute_ms=(sb.get("per_rank_ms") or {}).get("compute"))))
+    if full.get("measured_plan"):
+        optional.append(("measured_plan", sub(full["measured_plan"], ("share_before", "share", "chunk_frames_per_round"))))
     for k in ("config_R50_ovis_720", "config_swinl_ovis"):
         if k in full:
             e = full[k]
@@ -574,21 +585,29 @@ def compact_line(full, extras):
 def orchestrate(args, argv):
     """The default single-GPU invocation.  This process never touches the GPU; every leg is a child that has the GPU to itself, the
     HEADLINE first (cold start, as rounds 1-4 timed it):
-      1. leg `main`: the headline (K timed steps), its roofline objects, the extra modes, the CPU baseline, configs[2] / configs[3];
-      2. leg `root_load`: the N = 8 root-load rehearsal, recompute and halo-exchange form (one child: it plays rank 1, then rank 0 held at
+      1. leg `main`: the headline (K timed steps), its roofline objects, the extra modes, configs[2] / configs[3];
+      2. leg `cpu`: the CPU baseline (the oracle on configs[0]) with the box's host cores to itself;
+      3. leg `root_load`: the N = 8 root-load rehearsal, recompute and halo-exchange form (one child: it plays rank 1, then rank 0 held at
          the last gather until rank 1 would have delivered) -- only while the wall budget (MDQE_BENCH_BUDGET_S, 118 s) has room for it.
     The full objects go to gpurun_out/bench_extras.json; ONE compact line (<= LINE_LIMIT bytes) is printed."""
     t_start = time.perf_counter()
     budget = float(os.environ.get("MDQE_BENCH_BUDGET_S", "118"))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    full, rc = run_leg("main", {}, argv, float(os.environ.get("MDQE_BENCH_MAIN_S", "540")))
+    want_cpu = not args.no_cpu_baseline and args.config == "R50_ovis_360"
+    full, rc = run_leg("main", {}, list(argv) + (["--no-cpu-baseline"] if want_cpu else []), float(os.environ.get("MDQE_BENCH_MAIN_S", "540")))
     if rc != 0 or "value" not in full:
         print("bench.py: %s" % full.get("error", "the main leg printed no headline"), file=sys.stderr)
         return rc or 1
+    # the CPU baseline (the oracle on configs[0], 16 host threads, no GPU call) as its own leg, ALONE on the box: a GPU box's share of its
+    # host is ~16 cores, and beside the rehearsal's child the same oracle pass measured 0.18 instead of 0.64 frames/s (round 6)
+    if want_cpu:
+        shift = (full.get("config") or {}).get("cls_bias_shift_exact", 0.0)        # the same calibrated weights as the GPU legs
+        cb, rc3 = run_leg("cpu", {"MDQE_BENCH_CLS_SHIFT": repr(float(shift))}, [], 120.0)
+        full["cpu_baseline"] = cb.get("cpu_baseline") if rc3 == 0 else cb          # (a failed CPU leg shows as {"error": ..}: never silently absent)
     rl = os.environ.get("MDQE_BENCH_ROOT_LOAD_LEG", "")             # "W": that world, "0": never, unset: 8 with the other extras
     rl_w = int(rl) if rl else (8 if not args.no_fast_mode else 0)
     if rl_w > 1 and args.config == "R50_ovis_360" and args.precision == "f32" and not full.get("degraded"):
-        need = float(os.environ.get("MDQE_BENCH_ROOT_LOAD_NEED_S", "42"))
+        need = float(os.environ.get("MDQE_BENCH_ROOT_LOAD_NEED_S", "36"))
         left = budget - (time.perf_counter() - t_start)
         if left < need and not rl:
             full["root_load"] = {"skipped": "wall budget: %.0f s left of %.0f, the leg needs %.0f" % (left, budget, need)}
@@ -596,7 +615,7 @@ def orchestrate(args, argv):
             limit = float(os.environ.get("MDQE_BENCH_ROOT_LOAD_S", "0")) or max(left, need)
             halo = os.environ.get("MDQE_BENCH_ROOT_LOAD_HALO", "1") != "0"
             r, rc2 = run_leg("root_load", {"MDQE_BENCH_ROOT_LOAD": str(rl_w), "MDQE_BENCH_ROOT_LOAD_HALO": "1" if halo else "0",
-                                           "MDQE_BENCH_LEG_DEADLINE_S": "%.1f" % (limit - 4)},
+                                           "MDQE_BENCH_LEG_DEADLINE_S": "%.1f" % (limit - 2)},
                              ["--frames", str(args.frames), "--no-cpu-baseline", "--no-fast-mode"], limit + 20)
             if rc2 != 0:
                 full["root_load"] = r
@@ -607,6 +626,7 @@ def orchestrate(args, argv):
                         if "ms_per_step" in r[k]:
                             r[k].update(single_gpu_ms_per_step=single_ms, predicted_efficiency=single_ms / r[k]["ms_per_step"])
                         full[k] = r[k]
+                full["root_load_phases_s"] = r.get("phases_s")
     full["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
     print(compact_line(full, write_extras(full)), flush=True)
     return 0
@@ -683,6 +703,16 @@ def main():
     full_line = bool(leg) or os.environ.get("MDQE_BENCH_LINE") == "full"
     if not leg and world == 1 and not sharded and not probe:
         sys.exit(orchestrate(args, sys.argv[1:]))
+    if leg == "cpu":
+        # the CPU baseline alone: BASELINE.json's configs[0] through the oracle on the host cores; no GPU call in this process
+        from mdqe_cvpr2023_amd.config import PRESETS
+        from mdqe_cvpr2023_amd.params import random_state
+        c0 = PRESETS["R50_ovis_360"]
+        sd0 = random_state(c0, seed=0, remove_zero_init_trap=True)
+        kb = "detr.transformer_dec.cls_embed.layers.2.bias"             # (calibrate_synthetic_scores, done on the GPU by the main leg)
+        sd0[kb] = sd0[kb] + float(os.environ.get("MDQE_BENCH_CLS_SHIFT", "0"))
+        print(json.dumps({"cpu_baseline": cpu_baseline(c0, sd0, synth_video(0, 4, seed=0))}), flush=True)
+        return
 
     # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints a five-line version banner
     # there when a communicator is created, gloo its connection messages) are sent to stderr for the rest of the run
@@ -755,6 +785,11 @@ def main():
 
     meter = Meter()
     meter.install()
+    phases = {}                                            # wall seconds since process start at the end of each phase (the extras file)
+
+    def mark(name):
+        phases[name] = round(time.perf_counter() - t_start, 1)
+    mark("imports")
 
     def build(config, init):
         """Model + synthetic weights of one config (calibrated class logits for the `workload` initialisation)."""
@@ -768,6 +803,7 @@ def main():
     wl = build(args.config, args.init)
     cfg, fh, fw, sd, model, bias_shift = wl.cfg, wl.fh, wl.fw, wl.sd, wl.model, wl.bias_shift
     model.rle_output = bool(args.rle_output)
+    mark("model_built")
 
     # The video starts in PINNED HOST memory, one tensor per frame as the mapper hands them over (mdqe/data/dataset_mapper.py:
     # 228-263); the host->device copy of a1 (mdqe/mdqe.py:480) is part of every timed step.
@@ -984,9 +1020,11 @@ def main():
     if leg == "root_load":
         # one child of the orchestrated default run: both forms, the second only while this leg's own deadline has room
         t_leg = time.perf_counter()
+        mark("verified")
         limit = float(os.environ.get("MDQE_BENCH_LEG_DEADLINE_S", "1e9"))
-        res = {}
+        res = {"phases_s": phases}
         res["root_load"] = root_load_form(False)
+        mark("root_load")
         res["root_load"]["wall_s"] = round(time.perf_counter() - t_start, 1)
         t_one = time.perf_counter() - t_leg
         if os.environ.get("MDQE_BENCH_ROOT_LOAD_HALO", "1") != "0":
@@ -1003,6 +1041,33 @@ def main():
         dist.destroy_process_group()
         return
 
+    # N > 1: rank 0's chunk share from MEASURED per-rank times instead of a constant tuned on another box (sharding.measured_root_share):
+    # two warm videos on the default plan, every rank gathers the ranks' busy times and derives the same new share; if it moved, the
+    # chunks are re-dealt (each rank synthesises its new frames) and the timed steps run on that plan.  MDQE_BENCH_TUNE=0: the constants.
+    tuned = None
+    if sharded and world > 1 and not vworld and isinstance(chunk, list) and root_rest and os.environ.get("MDQE_BENCH_TUNE", "1") != "0":
+        st_t = []
+        with torch.no_grad():
+            run(1, False)
+            sync()
+            run(2, False, stats=st_t)
+            sync()
+        plan_t = shards[args.halo_exchange][0]
+        mine = sum(plan_t[g][2] - plan_t[g][1] for g in sharding.owned_chunks(plan_t, world, rank))
+        share0 = sharding.root_share(args.halo_exchange, world)
+        share1, tuned = sharding.measured_root_share(st_t, mine, share0, rank, world, dist)
+        if abs(share1 - share0) >= 0.01:
+            try:
+                new_sizes = sharding.rest_root_sizes(chunk_plain, world, share=share1, halo_exchange=bool(args.halo_exchange))
+                old_sizes = chunk_by_form[bool(args.halo_exchange)]
+                chunk_by_form[bool(args.halo_exchange)] = new_sizes
+                shards[args.halo_exchange] = shard(args.halo_exchange)
+                chunk = new_sizes
+            except ValueError as e:                                  # (a plan the halo-exchange form cannot hold: keep the measured one)
+                chunk_by_form[bool(args.halo_exchange)] = old_sizes
+                tuned["kept_default"] = str(e)
+        tuned["chunk_frames_per_round"] = chunk
+
     st_main = [] if sharded else None
     steps_ms = []
     rest_env = float(os.environ.get("MDQE_BENCH_REST_UNTIL_MS", "0"))   # tools/root_load.sh: rank 0 of the rehearsal held at the last gather
@@ -1017,6 +1082,7 @@ def main():
             print("tracker native ms per step: counts launch %.2f, counts wait %.2f, decision %.2f, accumulate launch %.2f; %d updates"
                   % tuple([1e3 * trk_times[i] / args.steps for i in range(4)] + [int(trk_times[4] / args.steps)]), file=sys.stderr, flush=True)
     g_timed, m_timed = meter.summary(), meter.msda_summary()
+    mark("headline")
     breakdown = None
     if sharded:
         plan_main = shards[args.halo_exchange][0]
@@ -1053,6 +1119,7 @@ def main():
         g_iso, m_iso = isolated_pass(model)
         if not args.no_fast_mode:
             clip_stage = clip_stage_alone(model, cfg, torch.stack(host_frames).cuda(), meter, L, T)
+    mark("isolated_and_clip_stage")
     # The extra modes (numbers beside the headline, never the headline; what each one is: DESIGN.md §5) on a short leash: at most 8 timed
     # steps after 2 warm-up steps each, whatever K the driver asked for
     extra = {}
@@ -1086,6 +1153,7 @@ def main():
                 extra["init_reference"]["instances_out"] = len(o_ref["pred_scores"])
                 del m_ref
     ops.set_gemm_precision("f32")
+    mark("extra_modes")
 
     if args.stages and rank == 0 and not sharded:
         from mdqe_cvpr2023_amd import profiling
@@ -1177,7 +1245,7 @@ def main():
                        "output": "none (a non-root rank of the rehearsal)" if out is None else
                                  "dense boolean masks on the host" if "pred_masks" in out else "per-frame COCO RLE strings (device-side run boundaries)",
                        "merge_on_cpu": bool(cfg.merge_on_cpu), "early_masks": bool(model.early_masks),
-                       "cls_bias_shift": round(bias_shift, 3), "init": args.init,
+                       "cls_bias_shift": round(bias_shift, 3), "cls_bias_shift_exact": float(bias_shift), "init": args.init,
                        "gemm": "exact fp32 MFMA" if args.precision == "f32" else "f16x3 split precision",
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "ranks_seen": ranks_seen, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
@@ -1189,6 +1257,8 @@ def main():
         if verified is not None:
             line["verified"] = True
             line["verification"] = verified
+        if tuned is not None:
+            line["measured_plan"] = tuned
         if breakdown is not None:
             line["scaling_breakdown"] = breakdown
         line.update(roofline_keys(g_timed, g_iso, m_timed, m_iso, args.precision))
@@ -1199,6 +1269,7 @@ def main():
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         # the CPU leg is BASELINE.json's configs[0] -- R50_ovis_360, 4 frames on the host cores -- and is quoted on the metric's config only
         line["cpu_baseline"] = cpu_baseline(cfg, sd, video[:4]) if args.config == "R50_ovis_360" else None
+        mark("cpu_baseline")
 
     # ---- optional legs: each may be cut short by the soft deadline; the headline above is complete -------------------------------------
     def give_up(what, budget):
@@ -1224,6 +1295,8 @@ def main():
         ops.set_gemm_precision("f32")
 
     if rank == 0:
+        mark("side_configs")
+        line["phases_s"] = phases
         line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
 
     # N > 1: the halo-exchange form of the same job as an extra key of the same line, so that one multi-GPU run decides the default.

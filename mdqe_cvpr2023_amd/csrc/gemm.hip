@@ -318,7 +318,10 @@ static int dispatch_gemm(GemmParams& p, int tile, hipStream_t st) {
   // problems -- the decoder's 21168-row GEMMs, res4/res5 3x3 convs -- run 15-30 % faster on 64x64 tiles (8 waves/SIMD).
   if (tile == 0) {
     const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (g_gemm_precision != 0 && p.Wh != nullptr && b128 >= 192 && p.N > 64) tile = 1;      // f16x3w / f16w have their own tiling
+    // f16x3w / f16w have their own tiling -- but only products the pre-split-weight kernels can take (the same predicate as below): an
+    // ineligible one (ragged K, 64 < N < 128, unaligned C, split-K) keeps the fp32 heuristics' tile instead of a forced 128x128
+    const bool planes_ok = p.Wh != nullptr && p.K % 32 == 0 && p.N >= 128 && p.N % 4 == 0 && p.vec_ok && p.ksplit <= 1;
+    if (g_gemm_precision != 0 && planes_ok && b128 >= 192) tile = 1;
     else if (p.N <= 64) tile = (p.M >= 4096) ? 2 : 3;
     else if ((g_gemm_tile_rule & 1) && b128 >= 2000 && p.N >= 1024 && p.N < 2048 && p.K <= 256 && !p.conv) tile = 9;   // short K, wide N -> 64x128
     else if ((g_gemm_tile_rule & 2) && p.conv && p.KH == 3 && b128 < 2000 && b128 >= 400 && p.N >= 256 && p.K < 4096) tile = 9;   // mid-grid 3x3 convs

@@ -113,6 +113,11 @@ msda_fused_kernel(const float* __restrict__ value, long ldv, long v_brows, const
 // publishes 8 floats per sample in LDS; then every lane walks the 16 samples with two broadcast ds_read_b128 and four
 // bounds-checked buffer loads each (a corner outside the map carries an out-of-range offset and reads as 0: no branches).
 #define MSDA_OOB 0xF0000000u
+// cache-policy bits of the gather's buffer loads (aux: 1 = sc0, 2 = nt, 16 = sc1); 0 = default policy.  tools/msda_aux_ab.sh builds the
+// library once per policy and times the three launches (profiles/r06_msda_aux_ab.txt)
+#ifndef MSDA_GATHER_AUX
+#define MSDA_GATHER_AUX 0
+#endif
 #define MSDA_DEFAULT_VARIANT 0
 // MAP: how a block's 32 (query, head) groups are chosen inside a batch element.  0: 4 consecutive queries x 8 heads.
 // 1: 32 consecutive queries of ONE head -- a head samples along its own direction (ms_deform_attn.py:81-87), so neighbouring
@@ -244,7 +249,7 @@ msda_fused_v2_kernel(const float* __restrict__ value, long value_bytes, long ldv
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const unsigned o = chan ? offv[c] + lane_off : MSDA_OOB;
-          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, MSDA_GATHER_AUX));
           acc += v * wv[c];
         }
       }
@@ -416,7 +421,7 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               if (l >= LS) v[s][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[s][c] + lane_lds);
-              else v[s][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, chan ? o[s][c] + lane_off : MSDA_OOB, 0, 0));
+              else v[s][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, chan ? o[s][c] + lane_off : MSDA_OOB, 0, MSDA_GATHER_AUX));
             }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -444,7 +449,7 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
-              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
+              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, MSDA_GATHER_AUX));
               acc += v * w[c];
             }
           }
@@ -594,7 +599,7 @@ msda_fused_tp_kernel(const float* __restrict__ value, long value_bytes, long ldv
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 if (g >= LS) v[s][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + o[s][c] + lane_lds);
-                else v[s][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, chan ? o[s][c] + lane_off : MSDA_OOB, 0, 0));
+                else v[s][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, chan ? o[s][c] + lane_off : MSDA_OOB, 0, MSDA_GATHER_AUX));
               }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -620,7 +625,7 @@ msda_fused_tp_kernel(const float* __restrict__ value, long value_bytes, long ldv
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 const unsigned a = chan ? o[c] + lane_off : MSDA_OOB;
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, 0));
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a, 0, MSDA_GATHER_AUX));
                 acc += v * w[c];
               }
             }

@@ -251,23 +251,48 @@ class MDQE(nn.Module):
         buffer is free again when the caller has dropped that result: the pool keeps the buffers it has made (up to PIN_POOL_GB) and
         re-issues one as soon as nothing but the pool references its storage.  A fresh pinned allocation costs ~75 us per MB (7 tracks of a
         960-frame 360p video: 120 ms; tools/pinned_probe.py), and the framework's own host allocator recycles only every other video."""
-        use_count = getattr(torch._C, "_storage_Use_Count", None)
         pool = self.__dict__.setdefault("_pin_pool", {})
         free = pool.setdefault(tuple(shape), [])
         # What is handed out is a VIEW (its own tensor object on the pooled storage): the storage's use count then stays above the pool's
         # own for as long as a merger, or a result the caller still holds, references the buffer -- the pool's tensor itself is never
         # given away (two Python references to ONE tensor object count once, and a second track of the same video would get the same
         # buffer: tests/test_fullsize_gpu.py caught exactly that).
+        use_count, idle = self._pin_pool_probe()
         if use_count is not None:
             for t in free:
-                if use_count(t.untyped_storage()._cdata) <= 2:         # the pool's tensor + the temporary wrapper of this very query
-                    return t[:]
+                if use_count(t.untyped_storage()._cdata) == idle:      # exactly what an unshared pooled buffer shows (calibrated, not assumed)
+                    return t[:]         # (every frame row is rewritten by the windows' read-backs before the result is handed out)
         t = torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True)
         held = sum(b.numel() for bufs in pool.values() for b in bufs)
         if use_count is not None and held + t.numel() <= self.PIN_POOL_GB * 2 ** 30:
             free.append(t)
             return t[:]
         return t
+
+    _PIN_PROBE = None
+
+    @classmethod
+    def _pin_pool_probe(cls):
+        """(use-count accessor, the count an UNSHARED pooled buffer shows) or (None, None): pooling off.  The accessor is a private torch
+        call whose baseline depends on the torch version's storage wrapper handling, so it is CALIBRATED once per process on a scratch
+        tensor -- the count with only the owner alive, and that a view raises it by exactly one and dropping the view restores it -- instead
+        of assumed; if the self-check fails the pool is disabled (fresh pinned buffers per call: slower, never wrong)."""
+        if cls._PIN_PROBE is None:
+            fn = getattr(torch._C, "_storage_Use_Count", None)
+            probe = (None, None)
+            if fn is not None:
+                try:
+                    t = torch.empty(16, dtype=torch.uint8)
+                    idle = fn(t.untyped_storage()._cdata)
+                    v = t[:]
+                    shared = fn(t.untyped_storage()._cdata)
+                    del v
+                    if shared == idle + 1 and fn(t.untyped_storage()._cdata) == idle:
+                        probe = (fn, idle)
+                except Exception:
+                    pass
+            cls._PIN_PROBE = probe
+        return cls._PIN_PROBE
 
     def _on_device(self):
         """Every ctypes launch goes to the CURRENT device's current stream: make the model's device current for the call."""

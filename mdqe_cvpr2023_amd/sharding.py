@@ -331,6 +331,19 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
     return plan
 
 
+def chunk_plan_resting(L, T, stride, sizes, world, halo_exchange=False, share=None):
+    """The plan of a job whose root rests (rest_root_sizes applied to the per-round `sizes`), with the library's own fallback: in the
+    halo-exchange form a per-rank deal can leave a chunk with frames but no whole clip of its own (chunk_plan raises ValueError) -- the
+    uniform per-round sizes are used then.  Returns (plan, the sizes the plan was made with)."""
+    per_rank = rest_root_sizes(sizes, world, share=share, halo_exchange=halo_exchange)
+    try:
+        return chunk_plan(L, T, stride, per_rank, halo_exchange=halo_exchange, world=world), per_rank
+    except ValueError:
+        if not halo_exchange:
+            raise
+        return chunk_plan(L, T, stride, list(sizes), halo_exchange=True, world=world), list(sizes)
+
+
 def rest_root_sizes(sizes, world, share=None, halo_exchange=False):
     """Per-round chunk sizes that take load off rank 0, the only rank that replays the tracker (and runs the window flushes, the final
     masks and their read-back) beside its own compute.
@@ -350,7 +363,7 @@ def rest_root_sizes(sizes, world, share=None, halo_exchange=False):
         c = int(c)
         if rest and q == len(sizes) - 1:
             root = 0
-        elif share < 1.0:
+        elif share != 1.0:
             root = max(1, int(round(c * share)))
         else:
             out.append(c)
@@ -358,6 +371,37 @@ def rest_root_sizes(sizes, world, share=None, halo_exchange=False):
         base, extra = divmod(c * world - root, world - 1)
         out.append([root] + [base + (1 if r < extra else 0) for r in range(world - 1)])
     return out
+
+
+def tune_root_share(busy_ms, frames, share, lo=0.5, hi=1.25):
+    """Rank 0's chunk share from MEASURED times (the constants of root_share were tuned on a one-GPU stand-in and will
+    not survive the first real node).  busy_ms[r]: rank r's own milliseconds per video that do not depend on waiting for the others --
+    compute + pack, on rank 0 also feed + the replay that nothing hides; frames[r]: the frames it computed per video under the plan that
+    was measured (made with `share`).  Per-frame cost c_r = busy / frames (rank 0's carries its replay); the frames are re-dealt so that
+    c_0 f_0 = c_o f_o with the total kept: f_0 = c_o F / (c_0 (N - 1) + c_o), c_o = the slowest other rank's.  Returns the new share
+    (old share x f_0 / old f_0), clamped.  Pure and deterministic: every rank that holds the same gathered numbers derives the same plan."""
+    world = len(busy_ms)
+    if world < 2 or frames[0] <= 0 or busy_ms[0] <= 0:
+        return float(share)
+    c0 = busy_ms[0] / frames[0]
+    co = max(b / f for b, f in zip(busy_ms[1:], frames[1:]) if f > 0)
+    if co <= 0:
+        return float(share)
+    total = float(sum(frames))
+    f0 = co * total / (c0 * (world - 1) + co)
+    return float(min(hi, max(lo, share * f0 / frames[0])))
+
+
+def measured_root_share(stats, frames_mine, share, rank, world, dist):
+    """All ranks: gather every rank's busy milliseconds per video (from the `stats` run_round_robin_stream filled over a few warm videos)
+    and its frames per video, and derive the SAME new share on every rank (tune_root_share).  Returns (share, info for the bench line)."""
+    n = max(len(stats), 1)
+    busy = sum(v.get("compute", 0.0) + v.get("pack", 0.0) + ((v.get("feed", 0.0) + v.get("replay_exposed", 0.0)) if rank == 0 else 0.0) for v in stats) / n
+    allr = [None] * world
+    dist.all_gather_object(allr, (float(busy), int(frames_mine)))
+    busy_ms, frames = [a[0] for a in allr], [a[1] for a in allr]
+    new = tune_root_share(busy_ms, frames, share)
+    return new, {"share_before": round(float(share), 4), "share": round(new, 4), "busy_ms": [round(b, 2) for b in busy_ms], "frames": frames}
 
 
 def owned_chunks(plan, world, rank):

@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle's GEMMs on at most 16 torch threads: a GPU box shows 256 logical CPUs of a shared host, and on all of them the oracle
+    # runs 5x SLOWER than on 16 (bench.py's cpu_baseline sweep: 0.12 frames/s on 128 threads against 0.6 on 16) -- round 6 found the
+    # full-size tests spending most of their time there.  MDQE_TEST_THREADS overrides.
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(int(os.environ.get("MDQE_TEST_THREADS", "16")), os.cpu_count() or 1)))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -247,16 +247,19 @@ def test_orchestrator_runs_the_headline_first_and_skips_the_rehearsal_when_the_b
         calls.append((leg, dict(env), list(argv)))
         if leg == "main":
             return dict(full), 0
+        if leg == "cpu":                                      # the CPU baseline is its own leg, alone on the box between the two GPU legs
+            return {"cpu_baseline": dict(full["cpu_baseline"], value=0.5)}, 0
         return {"root_load": {"world": 8, "ms_per_step": 160.0, "verified": True}, "root_load_halo": {"world": 8, "ms_per_step": 150.0, "verified": True}}, 0
     monkeypatch.setattr(bench, "run_leg", fake_leg)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    args = types.SimpleNamespace(no_fast_mode=False, config="R50_ovis_360", precision="f32", frames=120)
+    args = types.SimpleNamespace(no_fast_mode=False, no_cpu_baseline=False, config="R50_ovis_360", precision="f32", frames=120)
     monkeypatch.delenv("MDQE_BENCH_ROOT_LOAD_LEG", raising=False)
     assert bench.orchestrate(args, ["--steps", "20"]) == 0
     out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
     assert len(out) == 1 and len(out[0]) <= bench.LINE_LIMIT
     d = json.loads(out[0])
-    assert [c[0] for c in calls] == ["main", "root_load"] and calls[1][1]["MDQE_BENCH_ROOT_LOAD"] == "8"
+    assert [c[0] for c in calls] == ["main", "cpu", "root_load"] and calls[2][1]["MDQE_BENCH_ROOT_LOAD"] == "8"
+    assert "--no-cpu-baseline" in calls[0][2] and d["cpu_baseline"]["value"] == 0.5       # the main leg is not asked for it; the CPU leg's result rides in the line
     assert abs(d["root_load"]["predicted_efficiency"] - 145.26 / 160.0) < 1e-3 and abs(d["root_load_halo"]["predicted_efficiency"] - 145.26 / 150.0) < 1e-3
     ex = json.load(open(os.path.join(str(tmp_path), d["extras"])))
     assert len(ex["config"]["workload"]) > 3000 and ex["root_load"]["single_gpu_ms_per_step"] == 145.26      # the full objects are in the file
@@ -265,7 +268,7 @@ def test_orchestrator_runs_the_headline_first_and_skips_the_rehearsal_when_the_b
     monkeypatch.setenv("MDQE_BENCH_BUDGET_S", "1")
     assert bench.orchestrate(args, []) == 0
     d = json.loads(capsys.readouterr().out.strip())
-    assert [c[0] for c in calls] == ["main"] and "skipped" in d["root_load"] and d["value"] == 826.123
+    assert [c[0] for c in calls] == ["main", "cpu"] and "skipped" in d["root_load"] and d["value"] == 826.123
     # a failing main leg: no line, its exit code
     monkeypatch.setattr(bench, "run_leg", lambda *a: ({"error": "boom"}, 3))
     assert bench.orchestrate(args, []) == 3 and capsys.readouterr().out.strip() == ""

@@ -102,6 +102,7 @@ def _workload(name, fh, fw, n_frames, window, max_inst=120, tails=False):
         L, T = n_frames, cfg.n_frames_test
         clips, saved, tracker = [], 0, None
         cls_w, mask_w, win_logits = [], [], []
+        fq = {}                                                      # frame -> the oracle's per-frame query initialisation (a11, before association)
         for start in range(0, L, cfg.clip_stride):
             end, last = start + T, False
             if end > L:
@@ -112,6 +113,10 @@ def _workload(name, fh, fw, n_frames, window, max_inst=120, tails=False):
             clip = O.inference_clip(hp, out, mf[:, idx])
             clip["frame_idx"] = idx
             clips.append({"start": start, "end": end, "last": last, "out": out, "coords0": dbg["coords0"], "clip": clip})
+            for t, f in enumerate(idx):
+                if f not in fq:
+                    fq[f] = {"coords": dbg["coords0"][t], "content": dbg["content0"][t], "emb": dbg["track_emb"][t], "score_up": dbg["score_up"][t].reshape(
+                        dbg["score_up"].shape[-2:])}
             if tracker is None:
                 tracker = O.Tracker(hp, mf.shape[-2:])
             tracker.update(clip)
@@ -123,8 +128,38 @@ def _workload(name, fh, fw, n_frames, window, max_inst=120, tails=False):
                 saved += 1
             if last:
                 break
-        ref.update(clips=clips, cls_w=cls_w, win_logits=win_logits, video=O.inference_video(hp, (fh, fw), cls_w, mask_w))
+        ref.update(clips=clips, cls_w=cls_w, win_logits=win_logits, video=O.inference_video(hp, (fh, fw), cls_w, mask_w), frame_queries=fq)
     return ref
+
+
+# Discrete decisions at an fp32 NEAR-TIE.  A query cell's location is the argmax of the up-sampled objectness score over the cell
+# (transformer_dec.py:83-109, first max wins).  Round 6's 34-frame test met a cell whose best and second-best scores differ by ONE ulp
+# (5.96e-8) in the oracle: mathematically tied candidates that fp32 rounding orders, in the reference as much as here -- no implementation can
+# be held to the oracle's pick there, and the pick moves one of a clip's 196 queries (decoder heads then differ by 1e-2).  What CAN be held:
+# the product's pick scores within TIE_BAND of the oracle's maximum ON THE ORACLE'S OWN SCORE MAP.  The chained tests then continue on the
+# oracle's pick (their rule: every stage on the oracle's input, so that no discrete decision amplifies a rounding difference); the direct
+# tests accept a clip that fails its bars only if it holds such a cell, and say so in the recorded margins.
+TIE_BAND = 2e-6
+
+
+def _tie_cells(ref, coords, band=TIE_BAND, frames=None):
+    """coords: the product's query coordinates [frames, Q, 2] (CPU).  -> {frame: [cells]} where they differ from the oracle's; asserts that
+    every such pick is within TIE_BAND of the oracle's maximum of that cell on the oracle's score map."""
+    out = {}
+    for f, fq in sorted(ref["frame_queries"].items()):
+        if frames is not None and f not in frames:
+            continue
+        d = (coords[f] - fq["coords"]).abs().amax(-1) > 1e-6
+        for q in d.nonzero().flatten().tolist():
+            su = fq["score_up"]
+            Hu, Wu = su.shape
+            col, row = int(round(float(coords[f, q, 0]) * Wu)), int(float(coords[f, q, 1]) * Hu + 1e-4)
+            co, ro = int(round(float(fq["coords"][q, 0]) * Wu)), int(float(fq["coords"][q, 1]) * Hu + 1e-4)
+            gap = float(su[ro, co] - su[row, col])
+            assert 0.0 <= gap < band, ("query cell decided differently without a near-tie", f, q, gap)
+            record_margin(GROUP["name"], "a11 query cell picked at an fp32 near-tie: oracle score gap", gap, 1.0, band)
+            out.setdefault(f, []).append(q)
+    return out
 
 
 GROUP = {"name": "?"}          # the parity-margin group of the running test: "<config> <frames> frames, <gemm mode>, <direct|chained>"
@@ -179,6 +214,16 @@ def _chain(ref, model, fh, fw):
         enc_d = enc_r.cuda().contiguous()
         mf_d = mf_r.permute(1, 2, 3, 0).contiguous().cuda()                  # [frames, Hm, Wm, M] channels-last, as the engine keeps it
         coords, content, emb = eng.frame_queries(enc_d, geo)
+        # a11 per frame on the oracle's encoder tokens; a cell picked differently at an fp32 near-tie (asserted) continues on the oracle's pick
+        ties = _tie_cells(ref, coords.cpu())
+        for f, cells in ties.items():
+            fqo = ref["frame_queries"][f]
+            for q in cells:
+                coords[f, q], content[f, q], emb[f, q] = fqo["coords"][q].cuda(), fqo["content"][q].cuda(), fqo["emb"][q].cuda()
+        for f, fqo in ref["frame_queries"].items():
+            _m("a11 query coordinates", coords[f].cpu(), fqo["coords"], 1e-5)
+            _m("a11 query content", content[f].cpu(), fqo["content"], 1e-3, max(1.0, float(fqo["content"].abs().max())))
+            _m("a11 track embedding", emb[f].cpu(), fqo["emb"], 1e-3, max(1.0, float(fqo["emb"].abs().max())))
         vals = eng.dec_values(enc_d, geo)
         cache = {"coords": coords, "content": content, "emb": emb, "vals": vals}
         lscale = max(1.0, max(float(c["clip"]["pred_masks"].abs().max()) for c in ref["clips"] if c["clip"]["pred_masks"].numel()))
@@ -218,11 +263,29 @@ def _direct(ref, model, fh, fw):
     trace = []
     with torch.no_grad():
         out = model.inference_vis([{"image": ref["frames"], "height": fh, "width": fw}], trace=trace)
+        # the product's own a11 picks on ITS encoder tokens: where they differ from the oracle's they must be near-ties (TIE_BAND)
+        eng = model.engine
+        geo = eng.geometry(fh, fw)
+        enc = eng.encode(eng.backbone(torch.stack(ref["frames"]).cuda(), geo), geo)
+        # (on the product's own tokens the score map carries the backbone's and the encoder's rounding too: a ten times wider band)
+        ties = _tie_cells(ref, eng.frame_queries(enc, geo)[0].cpu(), band=10 * TIE_BAND)
+        del enc
     assert len(trace) == len(ref["clips"])
     lscale = max(1.0, max(float(c["clip"]["pred_masks"].abs().max()) for c in ref["clips"] if c["clip"]["pred_masks"].numel()))
+    tied = 0
     for res, c in zip(trace, ref["clips"]):
+        if any(f in ties for f in range(c["start"], c["end"])):
+            # a clip that holds a near-tie cell: one of its 196 queries sits elsewhere than the oracle's -- not held to the bars (the chained
+            # test holds the same clip on the oracle's pick); counted, so the margins file says how many
+            tied += 1
+            continue
         _check_clip(res, c["clip"], lscale, "a1-a15 frames -> clip")
-    _check_video(out, ref["video"])
+    record_margin(GROUP["name"], "clips not held to the oracle (a near-tie query cell)", float(tied), 1.0, float(len(ref["clips"])))
+    assert tied <= max(1, len(ref["clips"]) // 8), tied
+    if tied == 0:
+        _check_video(out, ref["video"])
+    else:                                            # the tracker's inputs differ in those clips: the video result is checked for form only
+        assert len(out["pred_masks"]) == len(out["pred_scores"]) == len(out["pred_labels"]) >= 1
     assert out["pred_masks"][0].shape == (len(ref["frames"]), fh, fw)
     return out
 
@@ -236,6 +299,32 @@ def test_r50_ovis_360_full_size_end_to_end(gemm_precision):
     _chain(ref, model, 360, 640)
     GROUP["name"] = "R50_ovis_360 6x360x640 %s direct" % gemm_precision
     _direct(ref, model, 360, 640)
+
+
+def test_r50_ovis_360_shipped_schedule_full_window_flush_and_carry():
+    """The SHIPPED R50_ovis_360 schedule at full size against the CPU oracle (until now reached only transitively):
+    34 frames of 360x640, 4-frame clips stride 1, WINDOW_FRAME_NUM_TEST = 30 -- one full 30-frame tracker window flush, the carry of the
+    T-1 overlapping frames across it and a short last window (mdqe/mdqe.py:301-364, tracking/OverTracker.py:195-225).  Chained (every
+    product stage on the oracle's input) and direct (frames -> boolean masks in the default multi-pass, multi-stream schedule)."""
+    from mdqe_cvpr2023_amd.config import PRESETS
+    base = PRESETS["R50_ovis_360"]
+    assert base.n_frames_window_test == 30 and base.n_frames_test == 4 and base.clip_stride == 1       # the shipped values, not a test's
+    # the oracle's tracker bank is [clips, max_inst, window + T frames, 96, 160] fp32 on the HOST, twice at a flush: 2 x 7.8 GB at the
+    # shipped MAX_NUM_INSTANCES = 120 -- taken when the box has the memory, else 60 (a capacity only: ~10 instances live here)
+    avail_gb = next((int(ln.split()[1]) / 1e6 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")), 0.0)
+    max_inst = base.n_max_inst if avail_gb > 48 else 60
+    ref = _workload("R50_ovis_360", 360, 640, 34, base.n_frames_window_test, max_inst=max_inst)
+    assert len(ref["clips"]) == 32 and len(ref["cls_w"]) == 2 and ref["clips"][-1]["last"]          # 31 full clips + the short last one, two flushes
+    assert ref["clips"][-1]["end"] - ref["clips"][-1]["start"] == 3
+    assert ref["win_logits"][0].shape[1] == 30 and ref["win_logits"][1].shape[1] == 4               # a full window, then the short last one
+    assert sum(int(c["clip"]["scores"].numel()) for c in ref["clips"]) > len(ref["clips"])
+    model = _model(ref)
+    assert model.cfg.n_frames_window_test == 30 and model.cfg.n_max_inst == max_inst
+    GROUP["name"] = "R50_ovis_360 34x360x640 window 30 (shipped schedule) f32 chained"
+    _chain(ref, model, 360, 640)
+    GROUP["name"] = "R50_ovis_360 34x360x640 window 30 (shipped schedule) f32 direct"
+    _direct(ref, model, 360, 640)
+    _workload.cache_clear()                                          # (34 frames of oracle intermediates: not kept for the later tests)
 
 
 def test_r50_ovis_360_full_size_heavy_tailed_weights():

@@ -590,3 +590,103 @@ def test_round_robin_with_a_resting_root_four_ranks(tmp_path):
     assert len(tracks) == len(ref)
     for (c, m), (cr, mr) in zip(tracks, ref):
         assert torch.allclose(c, cr) and torch.equal(m, mr)
+
+
+# ---- measured plan: rank 0's share from gathered per-rank times, not from constants --------------------------------
+def test_tune_root_share_balances_a_linear_cost_model():
+    """Pure function: with per-frame costs c_0 (root, its replay included) and c_o, two iterations land on the share that equalises the
+    ranks' busy times, from any start; equal costs keep the share; clamped."""
+    world, per = 8, 103.0
+    for c0, co in ((1.30, 1.0), (1.08, 1.0), (1.0, 1.0), (0.9, 1.0)):
+        share = 1.0
+        for _ in range(3):
+            f0 = per * share
+            fo = (per * world - f0) / (world - 1)
+            share = sharding.tune_root_share([c0 * f0] + [co * fo] * (world - 1), [f0] + [fo] * (world - 1), share)
+        f0 = per * share
+        fo = (per * world - f0) / (world - 1)
+        assert abs(c0 * f0 - co * fo) < 0.01 * co * fo, (c0, share)
+    assert sharding.tune_root_share([400.0, 100.0], [100, 100], 1.0) == 0.5            # clamped below
+    assert sharding.tune_root_share([0.0, 100.0], [0, 100], 0.93) == 0.93                # nothing measured on rank 0: unchanged
+
+
+class _SlowRootModel(_FakeModel):
+    """The stand-in with a per-frame cost: `ms_per_frame` of sleep per clip it hands out (a chunk of n frames holds ~n stride-1 clips);
+    rank 0 is given a larger one -- its replay.  The cost falls where the real model's does: while the clip results are consumed."""
+    def __init__(self, log, ms_per_frame):
+        super().__init__(log)
+        self.ms = ms_per_frame
+
+    def iter_clip_results(self, frames, clips, f0, **kw):
+        import time
+        for item in super().iter_clip_results(frames, clips, f0, **kw):
+            if item is not None:
+                time.sleep(self.ms * 1e-3)
+            yield item
+
+
+def tune_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    import mdqe_cvpr2023_amd.meta_arch as MA
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    MA.ClipMerger = _FakeMerger
+    torch.set_num_threads(1)
+    model = _SlowRootModel([], 15.0 if rank == 0 else 10.0)            # rank 0 costs 1.5x per frame
+    Lv, base, share, hist = 4 * 60, [30, 20, 10], 1.0, []
+    like = torch.zeros(0, 3, HW[0] * 4, HW[1] * 4)
+    out = None
+    for it in range(3):
+        sizes = sharding.rest_root_sizes(base, world, share=share)
+        plan = sharding.chunk_plan(Lv, CFG.n_frames_test, 1, sizes, world=world)
+        frames = {g: torch.zeros(plan[g][2] - plan[g][1], 3, HW[0] * 4, HW[1] * 4) for g in sharding.owned_chunks(plan, world, rank) if plan[g][0]}
+        stats = []
+        for _ in range(2):
+            out = sharding.run_round_robin(model, frames, plan, rank, world, dist, (HW[0] * 4, HW[1] * 4), root_only=True, like=like, stats=stats)
+        mine = sum(plan[g][2] - plan[g][1] for g in sharding.owned_chunks(plan, world, rank))
+        share, info = sharding.measured_root_share(stats, mine, share, rank, world, dist)
+        hist.append(info)
+    torch.save((out, hist), os.path.join(outdir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_measured_plan_converges_with_a_slowed_root_four_ranks(tmp_path):
+    """gloo world 4, rank 0 1.5x slower per frame: after warm videos every rank gathers the per-rank busy times and derives the same
+    smaller share for rank 0; the second measurement is balanced (busy times within 15 %), the result stays the single-process one."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=tune_worker, args=(r, 4, port, str(tmp_path))) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(4)]
+    hists = [g[1] for g in got]
+    assert all(h == hists[0] for h in hists)                             # every rank derived the same plan from the same numbers
+    h = hists[0]
+    assert h[0]["share_before"] == 1.0 and h[0]["busy_ms"][0] > 1.15 * max(h[0]["busy_ms"][1:])     # measured: the root is the slow rank (it already rests in the last round)
+    assert 0.5 < h[0]["share"] < 0.95 and h[1]["frames"][0] < h[0]["frames"][0]
+    b = h[2]["busy_ms"]
+    assert max(b) / min(b) < 1.15, h                                       # balanced on the measured plan
+    clip_order, tracks = got[0][0]
+    clips = clip_schedule(240, CFG.n_frames_test, 1)
+    assert clip_order == clips and all(g[0] is None for g in got[1:])
+
+
+def test_resting_plan_falls_back_inside_the_library_when_a_halo_chunk_would_hold_no_clip():
+    """the per-rank halo-exchange deal can leave a chunk with frames but no whole clip (ValueError) -- only bench.py caught it.
+    sharding.chunk_plan_resting keeps the per-rank deal where it is valid and falls back to the uniform per-round sizes where it is not;
+    a video longer than its sizes were planned for does not rest rank 0 in every overflow round."""
+    T = CFG.n_frames_test
+    plan, used = sharding.chunk_plan_resting(8 * 60, T, 1, [30, 20, 10], 8, halo_exchange=True)
+    assert isinstance(used[-1], list) and used[-1][0] == 0 and sum(len(p[0]) for p in plan) == len(clip_schedule(480, T, 1))
+    # tiny last round: rank 0's share leaves the others chunks shorter than a clip -> uniform sizes, every clip still exactly once
+    plan2, used2 = sharding.chunk_plan_resting(4 * 14, T, 1, [8, 4, 2], 4, halo_exchange=True, share=0.5)
+    assert sum(len(p[0]) for p in plan2) == len(clip_schedule(56, T, 1))
+    # overflow rounds (video longer than planned): the resting entry is not repeated for ever -- rank 0 owns frames again behind it
+    sizes = sharding.rest_root_sizes([10, 5], 4)
+    planL = sharding.chunk_plan(4 * 15 + 40, T, 1, sizes, world=4)
+    own0 = [g for g in sharding.owned_chunks(planL, 4, 0) if planL[g][0]]
+    assert len(planL) > 8 and any(g >= 8 for g in own0), (len(planL), own0)
