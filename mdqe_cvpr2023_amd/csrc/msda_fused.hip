@@ -285,7 +285,7 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, int ref_dim, int mode, const float* __restrict__ grid, MsdaLevels lv,
                      int B, int M, int Q, int LS_rt, int stage_px, int chunk, int nchunk, float scale,
-                     float* __restrict__ out, long ldout, int xcd_order) {
+                     float* __restrict__ out, long ldout, int xcd_order, int patch) {
   const int LS = LSC >= 0 ? LSC : LS_rt;
   constexpr int LP = L * P;                    // 16
   constexpr int D = DD, HS = LP / 2;
@@ -332,11 +332,28 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
   const unsigned lane_off = chan ? (unsigned)((m * D + j * 4) * 4) : MSDA_OOB;
   const unsigned lane_lds = chan ? (unsigned)(j * 16) : 0u;
   const unsigned zero_row = (unsigned)(stage_px * D * 4);
-  const int q_end = min(Q, (ck + 1) * chunk);
-  for (int q0 = ck * chunk; q0 < q_end; q0 += NT / 8) {
-    const int q = q0 + (threadIdx.x >> 3);
-    const bool live = q < q_end;
-    const int qq = live ? q : q_end - 1;         // idle groups shadow the run's last query and do not store
+  // patch (round 6 experiment, OFF by default; encoder only, NT == 1024: the queries are the level tokens in raster order): the 128 queries
+  // of an iteration as an 8 x 16 PATCH of their level instead of a run of 128 consecutive tokens (1.6 rows of level 0) -- a wave still takes
+  // 8 consecutive tokens of a row, the block's 16 waves cover 8 rows x 16 columns whose samples land in one neighbourhood of the fine levels.
+  // Same arithmetic per query: identical bits.  MEASURED SLOWER on the bench's own model and video (profiles/r06_msda_patch_ab.txt: 505 vs
+  // 462 us per 40-frame 360p launch, 675 vs 656 at 640p, 221 vs 203 on Swin-L; 826 vs 833 frames/s): a head samples along its own direction
+  // (ms_deform_attn.py:81-87) and a row run re-uses the texture path's lines along x better than a patch does, and partial patches of the
+  // coarse levels idle lanes.  Kept behind MDQE_MSDA_PATCH=1 / mdqe_debug_msda_patch for the record.
+  const int ppb = chunk / (NT / 8);
+  const int q_end = patch ? Q : min(Q, (ck + 1) * chunk);
+  for (int q0 = patch ? 0 : ck * chunk, it = 0; patch ? it < ppb : q0 < q_end; q0 += NT / 8, ++it) {
+    int q = q0 + (threadIdx.x >> 3);
+    bool live = q < q_end;
+    if (patch) {
+      int pid = ck * ppb + it, l = 0, npx = (sW[0] + 15) >> 4, np = npx * ((sH[0] + 7) >> 3);
+      while (l + 1 < L && pid >= np) { pid -= np; ++l; npx = (sW[l] + 15) >> 4; np = npx * ((sH[l] + 7) >> 3); }
+      if (pid >= np) break;                      // (uniform: behind the last patch of the last level)
+      const int g = threadIdx.x >> 3;            // group in the block: row g / 16, column g % 16 of the patch
+      const int y = (pid / npx) * 8 + (g >> 4), x = (pid % npx) * 16 + (g & 15);
+      live = y < sH[l] && x < sW[l];
+      q = sS[l] + min(y, sH[l] - 1) * sW[l] + min(x, sW[l] - 1);
+    }
+    const int qq = live ? q : (patch ? q : q_end - 1);         // idle groups shadow a live query and do not store
     const long t = (long)b * Q + qq;
     const f32x4 o4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(offs + t * ldo + m * (2 * LP) + 4 * j));
     const f32x2 l2 = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(logits + t * ldl + m * LP + 2 * j));
@@ -648,6 +665,12 @@ extern "C" int mdqe_debug_msda_stage_kb(int v) { g_msda_stage_kb = v > 0 ? v : 1
 extern "C" int mdqe_debug_msda_dec_stage_kb(int v) { g_msda_dec_stage_kb = v > 0 ? v : 72; return MDQE_OK; }   // the decoder's box-level launch only
 static int g_msda_tp_staged = 1;   // tools/ A/B: 0 = the decoder's temporal launch stays on v2
 extern "C" int mdqe_debug_msda_tp_staged(int v) { g_msda_tp_staged = v; return MDQE_OK; }
+static int g_msda_patch = -1;      // tools/ A/B: 1 = the encoder's launch walks 8 x 16 query patches instead of token runs; -1 = MDQE_MSDA_PATCH (default 0)
+extern "C" int mdqe_debug_msda_patch(int v) { g_msda_patch = v ? 1 : 0; return MDQE_OK; }
+static int msda_patch_on() {
+  if (g_msda_patch < 0) { const char* e = getenv("MDQE_MSDA_PATCH"); g_msda_patch = (e != nullptr && e[0] == '1') ? 1 : 0; }
+  return g_msda_patch;
+}
 static int g_msda_dec_staged = 1;  // tools/ A/B: 0 = the decoder's box-level launch stays on v2 (the encoder keeps its default)
 extern "C" int mdqe_debug_msda_dec_staged(int v) { g_msda_dec_staged = v; return MDQE_OK; }
 
@@ -714,14 +737,19 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         const long staged = (px + 1) * D * 4;
         if (chunk == 0) chunk = staged < 45 * 1024 ? 128 : staged < 80 * 1024 ? 256 : 512;
         if (g_msda_variant >= 0 && ((g_msda_variant >> 4) & 7)) chunk = 32 << (((g_msda_variant >> 4) & 7) - 1);       // tools/ sweep: 32 .. 2048
-        const int nchunk = (Q + chunk - 1) / chunk;
+        // round 6 experiment (off by default, measured slower): the encoder's 1024-thread launch walks 8 x 16 query patches instead of token runs
+        const bool patch = enc_form && nt == 1024 && chunk % 128 == 0 && !(g_msda_variant >= 0 && (g_msda_variant & 2048)) && msda_patch_on();
+        long npatch = 0;
+        for (int l = 0; l < L; ++l) npatch += (long)((lv.W[l] + 15) / 16) * ((lv.H[l] + 7) / 8);
+        const int nchunk = patch ? (int)((npatch + chunk / 128 - 1) / (chunk / 128)) : (Q + chunk - 1) / chunk;
         const long nb3 = (long)B * M * nchunk;
         bool lds_ok = true;
         auto launch3 = [&](auto kern) {
           // per kernel FUNCTION (the six instantiations share this lambda's one operator()): keyed by pointer in mdqe_allow_lds
           if (mdqe_allow_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256) != hipSuccess) { lds_ok = false; return; }   // nothing launched
           hipLaunchKernelGGL(kern, dim3((unsigned)nb3), dim3(nt), smem, st, value, vbytes, ldv, v_brows, vidx, offs, ldo, logits, ldl,
-                             ref, ref_bstride, ref_dim, mode, grid, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order);
+                             ref, ref_bstride, ref_dim, mode, grid, lv, B, M, Q, LS, (int)px, chunk, nchunk, scale, out, ldout, g_msda_xcd_order,
+                             patch ? 1 : 0);
         };
         // two blocks of 1024 threads per CU need the 8-waves-per-SIMD build (variant bit 256 of the tools/ sweep turns it off)
         const bool wpe8 = !(g_msda_variant >= 0 && (g_msda_variant & 256)) && 2 * smem + 1024 <= 160 * 1024;

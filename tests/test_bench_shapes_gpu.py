@@ -177,10 +177,7 @@ def test_encoder_msda_at_pass_size_equals_per_frame_launches(shapes, B):
 
 
 @pytest.mark.parametrize("tool,args", [("fuzz_msda.py", ["21"]), ("fuzz_msda_fused.py", ["20"]), ("fuzz_inference_clip.py", ["20"]),
-                                       ("fuzz_tracker.py", ["20", "--gpu"]), ("fuzz_pipeline.py", ["4"]),
-                                       pytest.param("fuzz_pipeline.py", ["8", "4"], marks=pytest.mark.skipif(
-                                           not os.environ.get("MDQE_LONG_TESTS"), reason="pipeline seeds 4-7: MDQE_LONG_TESTS=1 (round 6: their "
-                                           "time went to the full-size shipped-schedule test, tests/test_fullsize_gpu.py)"))])
+                                       ("fuzz_tracker.py", ["20", "--gpu"]), ("fuzz_pipeline.py", ["8"])])
 def test_fuzz_seeds(tool, args):
     """The first seeds of tools/fuzz_*.py (the long runs on every round's final code: profiles/rNN_fuzz_*.txt -- 60 pipeline cases, 0 mismatches; 8 of
     them here: the suite has a 900-s budget on the driver's box and the per-seed cost is 8-12 s): native MSDA op vs the oracle, fused MSDA forms vs each

@@ -542,10 +542,18 @@ def test_encoder_msda_with_coarse_levels_in_lds_equals_the_gather_form(shapes, B
             out = torch.full((B * Nq, C), float("nan"), device="cuda")
             ops.msda_fused(proj[:, :C], proj[:, C:C + nq], proj[:, C + nq:], ref, levels, B, Nq, M, D, L, P, mode=0, v_brows=Nq, out=out)
             outs.append(out)
+        # round 6's experiment (off by default, measured slower): a block iteration as an 8 x 16 patch of queries -- every output row, patches
+        # over the levels' edges included (NaN-filled output: a row a patch skipped would show)
+        lib.mdqe_debug_msda_variant(9)
+        lib.mdqe_debug_msda_patch(1)
+        out = torch.full((B * Nq, C), float("nan"), device="cuda")
+        ops.msda_fused(proj[:, :C], proj[:, C:C + nq], proj[:, C + nq:], ref, levels, B, Nq, M, D, L, P, mode=0, v_brows=Nq, out=out)
+        outs.append(out)
     finally:
         lib.mdqe_debug_msda_variant(-1)
+        lib.mdqe_debug_msda_patch(0)
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("Q,BT", [(196, 9), (64, 20), (300, 3)])
