@@ -184,6 +184,7 @@ int mdqe_debug_gemm_lds_pad(int bytes);   /* tools/ only: extra dynamic LDS per 
 int mdqe_debug_window_attn_variant(int v);
 int mdqe_debug_msda_xcd_order(int v); /* fused MSDA: 1 = XCD-aware block order (default), 0 = plain */
 int mdqe_debug_msda_dec_staged(int v); /* fused MSDA, decoder box-level launch: 1 (default) = LDS-staged kernel, 0 = v2 */
+int mdqe_debug_msda_dec_wpe8(int v);   /* fused MSDA, the decoder's 832-thread launches: 1 = the 8-waves-per-SIMD build (tools/ A/B), 0 = natural allocation */
 int mdqe_debug_msda_patch(int v);      /* fused MSDA, encoder launch: 1 = a block iteration takes an 8 x 16 patch of queries, 0 (default; MDQE_MSDA_PATCH) = a run of 128 tokens */
 int mdqe_debug_msda_stage_kb(int v);   /* fused MSDA (encoder / box level): LDS budget in KB of the staged coarse levels (default 150); tools/ A/B */
 int mdqe_debug_msda_tp_staged(int v);  /* fused MSDA, decoder temporal launch: 1 (default) = frame-by-frame LDS staging (msda_fused_tp_kernel), 0 = v2 */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mdqe_debug_msda_xcd_order": [i],
     "mdqe_debug_msda_dec_staged": [i],
     "mdqe_debug_msda_patch": [i],
+    "mdqe_debug_msda_dec_wpe8": [i],
     "mdqe_debug_msda_op_staged": [i],
     "mdqe_debug_msda_tp_staged": [i],
     "mdqe_debug_msda_stage_kb": [i],

@@ -485,8 +485,8 @@ msda_fused_v3_kernel(const float* __restrict__ value, long value_bytes, long ldv
 // stays in registers, 2 barriers per frame.  Lane mapping of the set-up as v2 / v3 (lane j of a (query, head) group prepares look-ups
 // 2j and 2j+1 of the phase: level (2j+k) / P, point (2j+k) % P).  Sum order: frame-major (v2: level-major) -- the same value up to fp32
 // reassociation, held to v2 at 1e-5 (tests/test_kernels_gpu.py) and to the reference through the decoder goldens.
-template <int F, int P, int G, int DD, int NT, int LSC = -1>
-__global__ void __launch_bounds__(NT)
+template <int F, int P, int G, int DD, int NT, int LSC = -1, int WPE = 0>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, WPE > 0 ? WPE : 8)))
 msda_fused_tp_kernel(const float* __restrict__ value, long value_bytes, long ldv, long v_brows, const int* __restrict__ vidx,
                      const float* __restrict__ offs, long ldo, const float* __restrict__ logits, long ldl,
                      const float* __restrict__ ref, long ref_bstride, const float* __restrict__ grid, MsdaLevels lv,
@@ -671,6 +671,8 @@ static int msda_patch_on() {
   if (g_msda_patch < 0) { const char* e = getenv("MDQE_MSDA_PATCH"); g_msda_patch = (e != nullptr && e[0] == '1') ? 1 : 0; }
   return g_msda_patch;
 }
+static int g_msda_dec_wpe8 = 0;    // tools/ A/B (round 6): 1 = the decoder's 832-thread launches in the 8-waves-per-SIMD build (<= 64 VGPRs: two blocks per CU by registers)
+extern "C" int mdqe_debug_msda_dec_wpe8(int v) { g_msda_dec_wpe8 = v; return MDQE_OK; }     // (2: the temporal launch at 7 waves per SIMD, 72 VGPRs)
 static int g_msda_dec_staged = 1;  // tools/ A/B: 0 = the decoder's box-level launch stays on v2 (the encoder keeps its default)
 extern "C" int mdqe_debug_msda_dec_staged(int v) { g_msda_dec_staged = v; return MDQE_OK; }
 
@@ -769,6 +771,7 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
           if constexpr (C < 0) {
             if (two_blocks) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024, 8>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024, 8>); }
             else if (nt == 1024) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 1024>); else launch3(msda_fused_v3_kernel<4, 4, 24, 1024>); }
+            else if (nt == 832 && g_msda_dec_wpe8 && D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832, 8>);
             else if (nt == 832) { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 832>); else launch3(msda_fused_v3_kernel<4, 4, 24, 832>); }
             else { if (D == 32) launch3(msda_fused_v3_kernel<4, 4, 32, 512>); else launch3(msda_fused_v3_kernel<4, 4, 24, 512>); }
           } else {
@@ -813,6 +816,8 @@ extern "C" int mdqe_msda_fused_f32(const float* value, long ldv, long v_brows, c
         auto pick = [&](auto lsc_) {
           constexpr int C = decltype(lsc_)::value;
           if (nt == 1024) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 1024, C>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 1024, C>); }
+          else if (nt == 832 && g_msda_dec_wpe8 == 1 && D == 32 && C < 0) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 832, -1, 8>);
+          else if (nt == 832 && g_msda_dec_wpe8 == 2 && D == 32 && C < 0) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 832, -1, 7>);
           else if (nt == 832) { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 832, C>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 832, C>); }
           else { if (D == 32) launch_tp(msda_fused_tp_kernel<4, 4, 4, 32, 512, C>); else launch_tp(msda_fused_tp_kernel<4, 4, 4, 24, 512, C>); }
         };
