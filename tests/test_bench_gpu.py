@@ -134,6 +134,10 @@ def test_bench_gpus_2_runs_two_ranks_without_torchrun():
     assert c["n_gpus"] == 2 and c["config"]["ranks_seen"] == 2 and c["verified"] is True and c["scaling"] == "weak"
     assert abs(c["value"] - 48 * 1e3 / c["ms_per_step"]) < 2e-3 * c["value"] and len(c["scaling_breakdown"]["compute_ms"]) == 2
     assert c["halo_exchange"]["verified"] is True and c["halo_exchange"]["value"] > 0
+    # rank 0's chunk share came from this run's own measured per-rank times (sharding.measured_root_share), the same on every rank
+    mp = d["measured_plan"]
+    assert mp["share_before"] == 1.0 and 0.5 <= mp["share"] <= 1.25 and len(mp["busy_ms"]) == 2 and min(mp["busy_ms"]) > 0 and len(mp["frames"]) == 2
+    assert c["measured_plan"]["share"] == mp["share"] and mp["chunk_frames_per_round"]
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["frames_per_gpu"] == 24 and d["scaling"] == "weak"
     assert abs(d["value"] - 48 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]              # whole-job frames / max-over-ranks time
     assert d["config"]["instances_out"] >= 1
