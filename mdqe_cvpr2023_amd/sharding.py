@@ -303,9 +303,11 @@ def chunk_plan(L, T, stride, chunk, halo_exchange=False, world=1):
 
     def size_of(g):
         c = sizes[min(g // w, len(sizes) - 1)]
-        if g // w >= len(sizes) and isinstance(c, (list, tuple)) and min(c) == 0:
+        if g // w >= len(sizes) and isinstance(c, (list, tuple)) and min(c) == 0 and not halo_exchange:
             # a video longer than the sizes were planned for: a RESTING entry (a rank with 0 frames) is not repeated -- the overflow
-            # rounds deal the same round total evenly, so no rank idles in every remaining round
+            # rounds deal the same round total evenly, so no rank idles in every remaining round.  (Not in the halo-exchange form: its
+            # ring needs a rank to have run in round q to receive the tail its chunk of round q + 1 starts from, _Job._halo -- there
+            # the resting entry repeats, as before.)
             return max(1, -(-sum(int(v) for v in c) // w))
         return int(c[g % w]) if isinstance(c, (list, tuple)) else int(c)
     if any((min(c) < 0 or max(c) < 1) if isinstance(c, (list, tuple)) else int(c) < 1 for c in sizes):

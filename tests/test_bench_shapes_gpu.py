@@ -184,5 +184,6 @@ def test_fuzz_seeds(tool, args):
     other, batched inference_clip vs the oracle's per-clip restatement, the tracker on the HIP bank vs the oracle's, the whole driver vs the
     oracle's at random small configurations.  One child process per tool (they are scripts that exit non-zero on a mismatch)."""
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "oracle") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.setdefault("OMP_NUM_THREADS", "16")                      # the oracle's GEMMs: 16 threads, not the 256 logical CPUs a GPU box shows (conftest.py)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])

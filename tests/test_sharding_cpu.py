@@ -690,3 +690,15 @@ def test_resting_plan_falls_back_inside_the_library_when_a_halo_chunk_would_hold
     planL = sharding.chunk_plan(4 * 15 + 40, T, 1, sizes, world=4)
     own0 = [g for g in sharding.owned_chunks(planL, 4, 0) if planL[g][0]]
     assert len(planL) > 8 and any(g >= 8 for g in own0), (len(planL), own0)
+
+
+def test_overflow_rounds_of_a_halo_exchange_plan_keep_the_root_resting():
+    """Round 6 (found by the 4-rank bench rehearsal): a rank that rests in round q cannot receive the tail its chunk of round q + 1 would
+    start from, so in the halo-exchange form the resting entry repeats in overflow rounds (the recompute form deals them evenly)."""
+    T = CFG.n_frames_test
+    sizes = sharding.rest_root_sizes([7, 7], 4, halo_exchange=True)
+    plan = sharding.chunk_plan(60, T, 1, sizes, halo_exchange=True, world=4)          # 56 planned frames, 4 in overflow
+    assert len(plan) > 8 and all(not plan[g][0] for g in sharding.owned_chunks(plan, 4, 0) if g >= 4)
+    assert sum(len(p[0]) for p in plan) == len(clip_schedule(60, T, 1))
+    plan_r = sharding.chunk_plan(60, T, 1, sharding.rest_root_sizes([7, 7], 4), world=4)
+    assert any(plan_r[g][0] for g in sharding.owned_chunks(plan_r, 4, 0) if g >= 8)   # recompute form: rank 0 works again behind its rest

@@ -22,6 +22,7 @@ python bench.py --config swinl_ovis --frames 40 --steps 5 --warmup 2 --no-fast-m
 MDQE_BENCH_FORCE_SHARDED=1 MDQE_BENCH_LINE=full python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fast-mode > $o/r06_bench_sharded_one_rank_rccl.json 2>/dev/null
 MDQE_BENCH_BACKEND=gloo MDQE_BENCH_ONE_DEVICE=1 MDQE_BENCH_HALO_AB=1 python bench.py --gpus 4 --steps 2 --warmup 1 --frames 48 --no-cpu-baseline --no-fast-mode > $o/r06_bench_n4_gloo_rehearsal.json 2>/dev/null; cp gpurun_out/bench_extras.json $o/r06_bench_n4_gloo_rehearsal_extras.json
 export PYTHONPATH=$(pwd):$(pwd)/oracle:$PYTHONPATH
+export OMP_NUM_THREADS=16                                   # the oracle inside the fuzzers: a GPU box shows 256 logical CPUs, its share is ~16
 python tools/fuzz_msda.py 400 2>&1 | tail -3 > $o/r06_fuzz_msda.txt
 python tools/fuzz_msda_fused.py 200 2>&1 | tail -3 > $o/r06_fuzz_msda_fused.txt
 python tools/fuzz_tracker.py 400 --gpu 2>&1 | tail -3 > $o/r06_fuzz_tracker.txt
