@@ -1333,8 +1333,8 @@ def main():
 FRAME_SIZES = {"R50_ovis_360": (360, 640), "R50_ovis_720": (640, 1138), "swinl_ovis": (480, 853)}
 
 
-TRAFFIC_REF_GEMM = "profiles/r05_pmc_gemm_summary.txt"      # separate --pmc passes (tools/pmc_gemm_r05.sh): FFN1 128x128 tile 1.04x, FFN2 + LN 1.10x of algorithmic
-TRAFFIC_REF_MSDA = "profiles/r04_pmc_msda_v3_summary.txt"   # eight --pmc passes over the 40-frame 360p encoder launch: 989 MB moved vs 732 MB algorithmic
+TRAFFIC_REF_GEMM = "profiles/r06_pmc_gemm_summary.txt"      # separate --pmc passes (tools/pmc_gemm_r05.sh): FFN1 128x128 tile 1.01-1.04x, FFN2 + LN 1.10x of algorithmic
+TRAFFIC_REF_MSDA = "profiles/r06_pmc_msda_enc_summary.txt"  # eight --pmc passes over the 40-frame 360p encoder launch: 963 MB moved vs 732 MB algorithmic (1.32x)
 
 
 def clip_stage_alone(model, cfg, video_dev, meter, L, T):
