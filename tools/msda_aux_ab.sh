@@ -5,6 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 C=mdqe_cvpr2023_amd/csrc
 if [ "$1" = build ]; then
+  mkdir -p tools/lab
   for aux in 2 16 18 1; do
     /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wno-unused-function -Wno-pass-failed -DMSDA_GATHER_AUX=$aux -c $C/msda_fused.hip -o tools/lab/msda_fused_aux$aux.o
     objs=$(ls $C/*.o | grep -v msda_fused.o)
