@@ -436,6 +436,25 @@ def test_r50_ovis_720_geometry_full_size(gemm_precision):
     _direct(ref, model, 640, 1138)
 
 
+def test_r50_ovis_720_shipped_schedule_window_flush_and_carry():
+    """configs[2] (R50_ovis_720) on ITS shipped schedule at full size: 24 frames of 640x1138, 4-frame clips stride 1, WINDOW_FRAME_NUM_TEST =
+    20, MERGE_ON_CPU, APPLY_CLS_THRES 0.2 -- one full 20-frame window flush, the carry across it and a short last window (22 clips) --
+    chained and direct against the CPU oracle (round 6; until now 3 frames).  Near-tie query cells as in the 360p test (`_tie_cells`)."""
+    from mdqe_cvpr2023_amd.config import PRESETS
+    base = PRESETS["R50_ovis_720"]
+    assert base.n_frames_window_test == 20 and base.n_frames_test == 4 and base.clip_stride == 1 and base.merge_on_cpu
+    # (the oracle's tracker bank: [clips, max_inst, window + T frames, 160, 288] fp32 on the host, twice at a flush: 2 x 5 GB at 60 instances)
+    ref = _workload("R50_ovis_720", 640, 1138, 24, base.n_frames_window_test, max_inst=60)
+    assert len(ref["clips"]) == 22 and len(ref["cls_w"]) == 2 and ref["clips"][-1]["last"]
+    assert ref["win_logits"][0].shape[1] == 20 and ref["win_logits"][1].shape[1] == 4
+    model = _model(ref)
+    GROUP["name"] = "R50_ovis_720 24x640x1138 window 20 (shipped schedule) f32 chained"
+    _chain(ref, model, 640, 1138)
+    GROUP["name"] = "R50_ovis_720 24x640x1138 window 20 (shipped schedule) f32 direct"
+    _direct(ref, model, 640, 1138)
+    _workload.cache_clear()
+
+
 def test_msda_640p_level_table_properties():
     """The native op on the 640p level table (S = Q = 15300, B = 2): linearity in value, partition of unity on a constant map,
     agreement with the oracle on a slice of queries of every level."""
@@ -472,6 +491,24 @@ def test_swinl_ovis_480p_full_size(gemm_precision):
     _chain(ref, model, 480, 853)
     GROUP["name"] = "swinl_ovis 3x480x853 %s direct" % gemm_precision
     _direct(ref, model, 480, 853)
+
+
+def test_swinl_ovis_shipped_schedule_window_flush_and_carry():
+    """configs[3] (swinl_ovis) on ITS shipped schedule at full size: 22 frames of 480x853, 2-frame clips stride 1, WINDOW_FRAME_NUM_TEST = 20,
+    MERGE_ON_CPU, APPLY_CLS_THRES 0.1 -- a full window flush, the carry of the overlapping frame across it, a short last window, a
+    one-frame last clip (22 clips) -- chained and direct against the CPU oracle (round 6; until now 3 frames)."""
+    from mdqe_cvpr2023_amd.config import PRESETS
+    base = PRESETS["swinl_ovis"]
+    assert base.n_frames_window_test == 20 and base.n_frames_test == 2 and base.clip_stride == 1 and base.merge_on_cpu
+    ref = _workload("swinl_ovis", 480, 853, 22, base.n_frames_window_test, max_inst=60)
+    assert len(ref["clips"]) == 22 and len(ref["cls_w"]) == 2 and ref["clips"][-1]["last"]
+    assert ref["clips"][-1]["end"] - ref["clips"][-1]["start"] == 1 and ref["win_logits"][0].shape[1] == 20 and ref["win_logits"][1].shape[1] == 2
+    model = _model(ref)
+    GROUP["name"] = "swinl_ovis 22x480x853 window 20 (shipped schedule) f32 chained"
+    _chain(ref, model, 480, 853)
+    GROUP["name"] = "swinl_ovis 22x480x853 window 20 (shipped schedule) f32 direct"
+    _direct(ref, model, 480, 853)
+    _workload.cache_clear()
 
 
 def test_checkpoint_load_path_equals_constructor_path():
