@@ -324,6 +324,14 @@ def test_r50_ovis_360_shipped_schedule_full_window_flush_and_carry():
     _chain(ref, model, 360, 640)
     GROUP["name"] = "R50_ovis_360 34x360x640 window 30 (shipped schedule) f32 direct"
     _direct(ref, model, 360, 640)
+    # ... and the fast mode (f16x3 split precision: what bench.py's `fast_mode` times) on the same video and oracle pass, same bars
+    from mdqe_cvpr2023_amd import ops
+    ops.set_gemm_precision("f16x3")
+    try:
+        GROUP["name"] = "R50_ovis_360 34x360x640 window 30 (shipped schedule) f16x3 direct"
+        _direct(ref, _model(ref), 360, 640)
+    finally:
+        ops.set_gemm_precision("f32")
     _workload.cache_clear()                                          # (34 frames of oracle intermediates: not kept for the later tests)
 
 
